@@ -1,0 +1,230 @@
+"""ctypes front-end of the CPU oracle (oracle/hx_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Nothing under heracles_amd/ may import this module.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_double_p = C.POINTER(C.c_double)
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle if needed (gcc only; no GPU involved)."""
+    so = os.path.join(_HERE, "libhxoracle.so")
+    src = os.path.join(_HERE, "hx_oracle.c")
+    hdr = os.path.join(_HERE, "hx_oracle.h")
+    if (
+        force
+        or not os.path.exists(so)
+        or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.hxo_nlm.restype = C.c_int64
+        L.hxo_map2alm.restype = C.c_int
+        L.hxo_alm2map.restype = C.c_int
+        L.hxo_wigner3j_l3.restype = C.c_int
+        L.hxo_num_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def nlm(lmax: int) -> int:
+    return (lmax + 1) * (lmax + 2) // 2
+
+
+def num_threads() -> int:
+    return lib().hxo_num_threads()
+
+
+def ring_info(nside: int, ring: int):
+    sp = C.c_int64()
+    nphi = C.c_int()
+    z = C.c_double()
+    sth = C.c_double()
+    phi0 = C.c_double()
+    lib().hxo_ring_info(
+        C.c_int(nside), C.c_int(ring), C.byref(sp), C.byref(nphi), C.byref(z),
+        C.byref(sth), C.byref(phi0),
+    )
+    return sp.value, nphi.value, z.value, sth.value, phi0.value
+
+
+def pix2ang(nside: int):
+    """(theta, phi) of all RING pixel centres, from the oracle's ring table."""
+    npix = 12 * nside * nside
+    theta = np.empty(npix)
+    phi = np.empty(npix)
+    for ring in range(1, 4 * nside):
+        sp, nphi, z, sth, phi0 = ring_info(nside, ring)
+        theta[sp : sp + nphi] = np.arctan2(sth, z)
+        phi[sp : sp + nphi] = phi0 + 2 * np.pi * np.arange(nphi) / nphi
+    return theta, phi
+
+
+def map2alm(maps, nside, lmax, spin=0, ring_weights=None, pix_weights=None, niter=0,
+            use_fft=True):
+    maps = np.ascontiguousarray(maps, dtype=np.float64)
+    npix = 12 * nside * nside
+    lead = maps.shape[:-1]
+    m2 = maps.reshape(-1, npix)
+    ncomp = m2.shape[0]
+    alms = np.zeros((ncomp, nlm(lmax)), dtype=np.complex128)
+    rw = None if ring_weights is None else np.ascontiguousarray(ring_weights, dtype=np.float64)
+    pw = None if pix_weights is None else np.ascontiguousarray(pix_weights, dtype=np.float64)
+    rc = lib().hxo_map2alm(
+        C.c_int(nside), C.c_int(lmax), C.c_int(spin), C.c_int(ncomp), _p(m2), _p(alms),
+        _p(rw) if rw is not None else None, _p(pw) if pw is not None else None,
+        C.c_int(niter), C.c_int(1 if use_fft else 0),
+    )
+    if rc != 0:
+        raise ValueError(f"hxo_map2alm failed ({rc})")
+    return alms.reshape(*lead, -1)
+
+
+def alm2map(alms, nside, lmax, spin=0, use_fft=True):
+    alms = np.ascontiguousarray(alms, dtype=np.complex128)
+    lead = alms.shape[:-1]
+    a2 = alms.reshape(-1, nlm(lmax))
+    ncomp = a2.shape[0]
+    npix = 12 * nside * nside
+    maps = np.zeros((ncomp, npix))
+    rc = lib().hxo_alm2map(
+        C.c_int(nside), C.c_int(lmax), C.c_int(spin), C.c_int(ncomp), _p(a2), _p(maps),
+        C.c_int(1 if use_fft else 0),
+    )
+    if rc != 0:
+        raise ValueError(f"hxo_alm2map failed ({rc})")
+    return maps.reshape(*lead, npix)
+
+
+def alm2lmax(n: int) -> int:
+    """heracles/twopoint.py:55-60"""
+    return (int((8 * n + 1) ** 0.5 + 0.01) - 3) // 2
+
+
+def alm2cl(alm, alm2=None, *, lmax=None):
+    """Block alm2cl with the reference's broadcasting (twopoint.py:63-101)."""
+    if alm2 is None:
+        alm2 = alm
+    alm = np.ascontiguousarray(alm, dtype=np.complex128)
+    alm2 = np.ascontiguousarray(alm2, dtype=np.complex128)
+    l1, l2 = alm2lmax(alm.shape[-1]), alm2lmax(alm2.shape[-1])
+    lout = min(l1, l2) if lmax is None else min(lmax, l1, l2)
+    a = alm.reshape(-1, alm.shape[-1])
+    b = alm2.reshape(-1, alm2.shape[-1])
+    out = np.empty((a.shape[0], b.shape[0], lout + 1))
+    tmp = np.empty(lout + 1)
+    for i in range(a.shape[0]):
+        for j in range(b.shape[0]):
+            lib().hxo_alm2cl(_p(a[i]), C.c_int(l1), _p(b[j]), C.c_int(l2), C.c_int(lout), _p(tmp))
+            out[i, j] = tmp
+    return out.reshape(*alm.shape[:-1], *alm2.shape[:-1], lout + 1)
+
+
+def gauss_legendre(n: int):
+    x = np.empty(n)
+    w = np.empty(n)
+    lib().hxo_gauss_legendre(C.c_int(n), _p(x), _p(w))
+    return x, w
+
+
+def wigner_d(lmax: int, a: int, b: int, x: float):
+    out = np.empty(lmax + 1)
+    lib().hxo_wigner_d(C.c_int(lmax), C.c_int(a), C.c_int(b), C.c_double(x), _p(out))
+    return out
+
+
+def legendre_funcs(lmax: int, x: float):
+    P = np.empty(lmax + 1)
+    dP = np.empty(lmax + 1)
+    d20 = np.empty(max(lmax - 1, 0))
+    d22 = np.empty(max(lmax - 1, 0))
+    d2m2 = np.empty(max(lmax - 1, 0))
+    lib().hxo_legendre_funcs(C.c_int(lmax), C.c_double(x), _p(P), _p(dP), _p(d20), _p(d22), _p(d2m2))
+    return (P, dP), (d20, d22, d2m2)
+
+
+def cl2corr(cls, lmax=None):
+    cls = np.asarray(cls, dtype=np.float64)
+    if cls.ndim == 1:
+        cls = np.stack([cls, np.zeros_like(cls), np.zeros_like(cls), np.zeros_like(cls)]).T
+    if lmax is None:
+        lmax = cls.shape[0] - 1
+    cls = np.ascontiguousarray(cls[: lmax + 1])
+    x, w = gauss_legendre(lmax + 1)
+    xw = np.concatenate([x, w])
+    out = np.empty((lmax + 1, 4))
+    lib().hxo_cl2corr(C.c_int(lmax), _p(cls), _p(xw), _p(out))
+    return out
+
+
+def corr2cl(corrs, lmax=None):
+    corrs = np.asarray(corrs, dtype=np.float64)
+    if corrs.ndim == 1:
+        corrs = np.stack([corrs, np.zeros_like(corrs), np.zeros_like(corrs), np.zeros_like(corrs)]).T
+    if lmax is None:
+        lmax = corrs.shape[0] - 1
+    corrs = np.ascontiguousarray(corrs)
+    x, w = gauss_legendre(lmax + 1)
+    xw = np.concatenate([x, w])
+    out = np.empty((lmax + 1, 4))
+    lib().hxo_corr2cl(C.c_int(lmax), _p(corrs), _p(xw), _p(out))
+    return out
+
+
+def wigner3j_l3(l1, l2, m1, m2):
+    out = np.zeros(l1 + l2 + 2)
+    n = C.c_int()
+    jmin = lib().hxo_wigner3j_l3(C.c_int(l1), C.c_int(l2), C.c_int(m1), C.c_int(m2), _p(out), C.byref(n))
+    return jmin, out[: n.value].copy()
+
+
+def _mm_defaults(cl, l1max, l2max, l3max):
+    # defaults of the third-party convolvecl.mixmat are not in the reference tree
+    # [UNVERIFIED]; chosen so that tests/test_twopoint.py:412-462 shapes hold.
+    cl = np.ascontiguousarray(cl, dtype=np.float64)
+    if l3max is None:
+        l3max = cl.shape[-1] - 1
+    if l1max is None:
+        l1max = l3max
+    if l2max is None:
+        l2max = l1max
+    if cl.shape[-1] < l3max + 1:
+        cl = np.concatenate([cl, np.zeros(l3max + 1 - cl.shape[-1])])
+    return cl, l1max, l2max, l3max
+
+
+def mixmat(cl, l1max=None, l2max=None, l3max=None, spin=(0, 0)):
+    cl, l1max, l2max, l3max = _mm_defaults(cl, l1max, l2max, l3max)
+    out = np.empty((l1max + 1, l2max + 1))
+    lib().hxo_mixmat(_p(cl), C.c_int(l1max), C.c_int(l2max), C.c_int(l3max),
+                     C.c_int(spin[0]), C.c_int(spin[1]), _p(out))
+    return out
+
+
+def mixmat_eb(cl, l1max=None, l2max=None, l3max=None, spin=(2, 2)):
+    cl, l1max, l2max, l3max = _mm_defaults(cl, l1max, l2max, l3max)
+    out = np.empty((3, l1max + 1, l2max + 1))
+    lib().hxo_mixmat_eb(_p(cl), C.c_int(l1max), C.c_int(l2max), C.c_int(l3max), _p(out))
+    return out
