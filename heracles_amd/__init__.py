@@ -1,0 +1,31 @@
+"""heracles_amd -- MI355X-native backend for the harmonic-space two-point hot path of
+Heracles (map2alm/alm2map, all-pairs alm x alm -> Cl, Wigner-3j mixing matrices).
+
+Everything numerical runs in libhxsht.so (hand-written HIP for gfx950, C ABI in
+include/hxsht.h).  There is no CPU fallback.
+"""
+
+from . import _lib
+from ._lib import HxError, device_count, init, synchronize
+from .core import Result, TocDict, toc_match, update_metadata
+from .mapper import HipHealpixMapper
+from .sht import Plan, get_plan
+from .transforms import cl2corr, corr2cl, gauss_legendre, wigner_d_table
+from .twopoint import (
+    alm2cl,
+    alm2cl_pairs,
+    alm2lmax,
+    angular_power_spectra,
+    debias_cls,
+    mixing_matrices,
+    mixmat,
+    mixmat_eb,
+)
+from .unmixing import naturalspice
+
+__all__ = [
+    "HipHealpixMapper", "Plan", "get_plan", "HxError", "init", "device_count", "synchronize",
+    "alm2cl", "alm2cl_pairs", "alm2lmax", "angular_power_spectra", "debias_cls",
+    "mixing_matrices", "mixmat", "mixmat_eb", "cl2corr", "corr2cl", "gauss_legendre",
+    "wigner_d_table", "naturalspice", "Result", "TocDict", "toc_match", "update_metadata",
+]

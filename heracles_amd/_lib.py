@@ -1,0 +1,162 @@
+"""ctypes binding of libhxsht.so (include/hxsht.h).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 device is
+usable, every compute call raises :class:`HxError`.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBNAME = os.path.join(_HERE, "libhxsht.so")
+_lock = threading.Lock()
+_lib = None
+
+HX_OK = 0
+HX_ERR_ARG, HX_ERR_NO_DEVICE, HX_ERR_HIP, HX_ERR_MEM, HX_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+
+#: every symbol declared in include/hxsht.h
+SYMBOLS = (
+    "hx_version", "hx_last_error", "hx_device_count", "hx_init", "hx_set_stream",
+    "hx_get_stream", "hx_set_async", "hx_synchronize", "hx_timer_start", "hx_timer_stop",
+    "hx_profile_enable", "hx_profile_reset", "hx_profile_get", "hx_plan_create",
+    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_map2alm", "hx_alm2map",
+    "hx_alm2cl_pairs", "hx_gauss_legendre", "hx_wigner_d_table", "hx_mixmat",
+    "hx_mixmat_eb", "hx_cl2corr", "hx_corr2cl",
+)
+
+
+class HxError(RuntimeError):
+    """Error reported by libhxsht (code, message)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libhxsht error {code}: {msg}")
+        self.code = code
+
+
+def library_path() -> str:
+    return _LIBNAME
+
+
+def load():
+    """Load libhxsht.so (built in-tree by __graft_entry__.build() / make -C csrc)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_LIBNAME):
+            raise HxError(
+                HX_ERR_NO_DEVICE,
+                f"{_LIBNAME} not found: build it with `make -C heracles_amd/csrc` "
+                "(hipcc, gfx950).  heracles_amd has no CPU fallback.",
+            )
+        L = C.CDLL(_LIBNAME)
+        vp, i, dp = C.c_void_p, C.c_int, C.c_void_p
+        L.hx_version.restype = C.c_char_p
+        L.hx_last_error.restype = C.c_char_p
+        L.hx_get_stream.restype = vp
+        L.hx_set_stream.argtypes = [vp]
+        L.hx_plan_create.restype = vp
+        L.hx_plan_create.argtypes = [i, i, i]
+        L.hx_plan_destroy.argtypes = [vp]
+        L.hx_plan_destroy.restype = None
+        L.hx_plan_scratch_bytes.argtypes = [vp]
+        L.hx_plan_scratch_bytes.restype = C.c_int64
+        L.hx_map2alm.argtypes = [vp, i, i, dp, dp, dp, dp, dp, i]
+        L.hx_alm2map.argtypes = [vp, i, i, dp, dp]
+        L.hx_alm2cl_pairs.argtypes = [i, vp, vp, i, i, vp, vp, dp]
+        L.hx_gauss_legendre.argtypes = [i, dp, dp]
+        L.hx_wigner_d_table.argtypes = [i, i, i, i, dp, dp]
+        L.hx_mixmat.argtypes = [dp, i, i, i, i, i, i, dp]
+        L.hx_mixmat_eb.argtypes = [dp, i, i, i, i, dp]
+        L.hx_cl2corr.argtypes = [i, i, dp, dp]
+        L.hx_corr2cl.argtypes = [i, i, dp, dp]
+        L.hx_timer_stop.argtypes = [C.POINTER(C.c_float)]
+        L.hx_profile_get.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        _lib = L
+        return L
+
+
+def check(rc: int):
+    if rc != HX_OK:
+        raise HxError(rc, load().hx_last_error().decode(errors="replace"))
+
+
+def ptr(obj):
+    """Raw address of a numpy array, a torch tensor (host or device), an int, or None."""
+    if obj is None:
+        return None
+    if isinstance(obj, int):
+        return C.c_void_p(obj)
+    if isinstance(obj, np.ndarray):
+        if not obj.flags.c_contiguous:
+            raise ValueError("array must be C-contiguous")
+        return C.c_void_p(obj.ctypes.data)
+    if hasattr(obj, "data_ptr"):  # torch tensor
+        if not obj.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return C.c_void_p(obj.data_ptr())
+    raise TypeError(f"cannot take the address of {type(obj)!r}")
+
+
+def init(device: int | None = None):
+    L = load()
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) % max(L.hx_device_count(), 1)
+    check(L.hx_init(int(device)))
+    global _inited
+    _inited = True
+
+
+_inited = False
+
+
+def ensure_init():
+    """Initialise the library once on the device of this process (LOCAL_RANK aware)."""
+    global _inited
+    if not _inited:
+        init(None)
+        _inited = True
+
+
+def device_count() -> int:
+    return load().hx_device_count()
+
+
+def synchronize():
+    check(load().hx_synchronize())
+
+
+class Timer:
+    """HIP-event timer on the library stream."""
+
+    def __enter__(self):
+        check(load().hx_timer_start())
+        self.ms = None
+        return self
+
+    def __exit__(self, *exc):
+        t = C.c_float()
+        check(load().hx_timer_stop(C.byref(t)))
+        self.ms = float(t.value)
+        return False
+
+
+def profile_enable(on=True):
+    check(load().hx_profile_enable(1 if on else 0))
+
+
+def profile_reset():
+    check(load().hx_profile_reset())
+
+
+def profile_get(name: str):
+    n = C.c_int()
+    ms = C.c_double()
+    check(load().hx_profile_get(name.encode(), C.byref(n), C.byref(ms)))
+    return n.value, ms.value

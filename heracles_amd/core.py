@@ -1,0 +1,131 @@
+"""Small host-side helpers mirroring the parts of heracles.core / heracles.result that the
+hot path touches: dtype-metadata pass-through (heracles/core.py:102-122), the pattern
+matching of two-point keys (core.py:34-58) and a minimal Result container
+(heracles/result.py:75-121).  If the user's own ``heracles`` is importable its classes
+are used instead, so objects returned from here are the types Heracles expects.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any
+
+import numpy as np
+
+try:  # pragma: no cover - exercised only where heracles is installed
+    from heracles.core import TocDict as _TocDict, toc_match as _toc_match
+    from heracles.core import update_metadata as _update_metadata
+    from heracles.result import Result as _Result
+
+    HAVE_HERACLES = True
+except Exception:  # noqa: BLE001 - any import problem means "not available"
+    HAVE_HERACLES = False
+
+
+def update_metadata(array, **metadata):
+    """Attach/merge metadata on ``array.dtype`` in place (same contract as core.py:102)."""
+    md = dict(array.dtype.metadata or {})
+    md.update(metadata)
+    dt = array.dtype
+    base = dt.fields if dt.fields is not None else dt.str
+    new = np.dtype(base, metadata=md)
+    if not np.can_cast(new, array.dtype, casting="no"):
+        raise ValueError("array with unsupported dtype")
+    array.dtype = new
+
+
+def toc_match(key, include=None, exclude=None) -> bool:
+    """Whether a key passes include / exclude pattern lists; ``...`` is a wildcard."""
+    if not isinstance(key, tuple):
+        key = (key,)
+
+    def hit(pattern):
+        return all(p is Ellipsis or p == k for p, k in zip(pattern, key))
+
+    if include is not None and not any(hit(p) for p in include):
+        return False
+    if exclude is not None and any(hit(p) for p in exclude):
+        return False
+    return True
+
+
+class TocDict(dict):
+    """dict whose lookup falls back to prefix patterns with ``...`` wildcards."""
+
+    def __getitem__(self, pattern):
+        try:
+            return dict.__getitem__(self, pattern)
+        except (KeyError, TypeError):
+            pass
+        if not isinstance(pattern, tuple):
+            pattern = (pattern,)
+        if not pattern:
+            return TocDict(self)
+        found = TocDict()
+        for key, value in self.items():
+            if isinstance(key, tuple):
+                if len(key) >= len(pattern) and all(
+                    p == k for p, k in zip(pattern, key) if p is not ...
+                ):
+                    found[key] = value
+            elif pattern in ((...,), (key,)):
+                found[key] = value
+        if not found:
+            raise KeyError(pattern)
+        return found
+
+
+def _axis_tuple(axis, ndim, ell):
+    if axis is None:
+        if ndim == 0:
+            return ()
+        if isinstance(ell, tuple):
+            return tuple(range(ndim - len(ell), ndim))
+        return (ndim - 1,)
+    if isinstance(axis, int):
+        axis = (axis,)
+    return tuple(a % ndim for a in axis)
+
+
+@dataclass(frozen=True, repr=False)
+class Result:
+    """Array plus angular axes, as heracles.result.Result."""
+
+    array: Any
+    ell: Any = None
+    spin: Any = None
+    axis: Any = None
+    lower: Any = None
+    upper: Any = None
+    weight: Any = None
+
+    def __post_init__(self):
+        object.__setattr__(self, "axis", _axis_tuple(self.axis, np.ndim(self.array), self.ell))
+
+    def __repr__(self):
+        return f"Result(axis={self.axis!r})"
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.array, dtype=dtype)
+
+    def __getitem__(self, key):
+        return self.array[key]
+
+    @property
+    def ndim(self):
+        return self.array.ndim
+
+    @property
+    def shape(self):
+        return self.array.shape
+
+    @property
+    def dtype(self):
+        return self.array.dtype
+
+
+if HAVE_HERACLES:  # pragma: no cover
+    TocDict = _TocDict  # noqa: F811
+    toc_match = _toc_match  # noqa: F811
+    update_metadata = _update_metadata  # noqa: F811
+    Result = _Result  # noqa: F811

@@ -1,0 +1,104 @@
+// hx_common.h -- runtime state, error handling and device-buffer helpers shared by the
+// translation units of libhxsht.so.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/hxsht.h"
+
+namespace hx {
+
+// ---- error state -------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+
+#define HX_HIP(call)                                                                     \
+    do {                                                                                 \
+        hipError_t _e = (call);                                                          \
+        if (_e != hipSuccess)                                                            \
+            return ::hx::fail(HX_ERR_HIP, "%s failed: %s (%s:%d)", #call,                \
+                              hipGetErrorString(_e), __FILE__, __LINE__);                \
+    } while (0)
+
+#define HX_TRY(expr)                                                                     \
+    do {                                                                                 \
+        int _rc = (expr);                                                                \
+        if (_rc != HX_OK) return _rc;                                                    \
+    } while (0)
+
+// ---- runtime -----------------------------------------------------------------------
+struct Runtime {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool async = false;
+    bool profiling = false;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    struct Prof {
+        int launches = 0;
+        double ms = 0.0;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    };
+    std::map<std::string, Prof> prof;
+    std::vector<hipEvent_t> event_pool;
+};
+Runtime &rt();
+int ensure_ready();  // lazily hx_init(current device); HX_ERR_NO_DEVICE if none
+
+// Scoped kernel-family timer: records HIP events on the library stream when profiling.
+struct ProfScope {
+    const char *name;
+    hipEvent_t a = nullptr, b = nullptr;
+    explicit ProfScope(const char *n);
+    ~ProfScope();
+};
+
+// ---- device buffers ----------------------------------------------------------------
+bool is_device_ptr(const void *p);
+
+// Owning device allocation.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    int alloc(size_t n);    // (re)allocate exactly n bytes if current capacity < n
+    void release();
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// Input view: device pointer as-is, host pointer copied to a temporary device buffer.
+struct InView {
+    const void *dev = nullptr;
+    DevBuf tmp;
+    int bind(const void *src, size_t bytes);
+    template <class T> const T *as() const { return static_cast<const T *>(dev); }
+};
+
+// Output view: device pointer as-is; host pointer -> temporary device buffer, copied back
+// by finish().
+struct OutView {
+    void *dev = nullptr;
+    void *host = nullptr;
+    size_t bytes = 0;
+    DevBuf tmp;
+    int bind(void *dst, size_t bytes);
+    int finish();
+    template <class T> T *as() const { return static_cast<T *>(dev); }
+};
+
+int finish_call();  // synchronise unless async
+
+// Gauss-Legendre nodes/weights into device arrays (hx_mixmat.hip)
+int launch_gauss_legendre(int n, double *d_x, double *d_w);
+
+}  // namespace hx

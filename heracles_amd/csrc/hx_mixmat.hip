@@ -1,0 +1,376 @@
+// hx_mixmat.hip -- Gauss-Legendre nodes, Wigner-d tables and mode-coupling (mixing) matrices.
+//
+// Replaces convolvecl.mixmat / mixmat_eb as called at heracles/twopoint.py:378-388:
+//   M_{l1 l2} = (2 l2 + 1)/(4 pi) sum_{l3} (2 l3 + 1) W_{l3} (l1 l2 l3; s1 -s1 0)(l1 l2 l3; s2 -s2 0)
+// evaluated in its dense quadrature form:
+//   xi(x) = sum_{l3} (2 l3 + 1)/(4 pi) W_{l3} P_{l3}(x)
+//   G^{(ab)} = D^{(ab)T} diag(w xi) D^{(ab)} diag((2 l2 + 1)/2),   D^{(ab)}[k][l] = d^l_{ab}(x_k)
+// on N >= (l1max + l2max + l3max)/2 + 1 Gauss-Legendre nodes, which is exact.  The
+// (l, l') contraction is a symmetric FP64 GEMM on v_mfma_f64_16x16x4_f64; this is the only
+// place in the engine that is GEMM-shaped, so the only place MFMA is used as a GEMM.
+#include <algorithm>
+#include <cmath>
+
+#include "hx_common.h"
+
+namespace hx {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int GB = 128;   // block tile edge (l, l')
+constexpr int GK = 32;    // nodes per k tile
+constexpr int GLD = GK + 2;
+
+// ---- Gauss-Legendre nodes: Newton on P_n, one thread per node pair ---------------------
+__global__ void k_gauss_legendre(int n, double *__restrict__ x, double *__restrict__ w)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (n + 1) / 2) return;
+    double t = cospi((i + 0.75) / (n + 0.5));
+    double dp = 1.0;
+    for (int it = 0; it < 10; ++it) {
+        double p0 = 1.0, p1 = t;
+        for (int k = 2; k <= n; ++k) {
+            double p2 = ((2.0 * k - 1.0) * t * p1 - (k - 1.0) * p0) / k;
+            p0 = p1;
+            p1 = p2;
+        }
+        dp = n * (t * p1 - p0) / (t * t - 1.0);
+        double dt = p1 / dp;
+        t -= dt;
+        if (fabs(dt) <= 2e-16 * fabs(t)) break;
+    }
+    {
+        double p0 = 1.0, p1 = t;
+        for (int k = 2; k <= n; ++k) {
+            double p2 = ((2.0 * k - 1.0) * t * p1 - (k - 1.0) * p0) / k;
+            p0 = p1;
+            p1 = p2;
+        }
+        dp = n * (t * p1 - p0) / (t * t - 1.0);
+    }
+    const double ww = 2.0 / ((1.0 - t * t) * dp * dp);
+    if ((n & 1) && i == n / 2) t = 0.0;
+    x[i] = -t; x[n - 1 - i] = t;
+    w[i] = ww; w[n - 1 - i] = ww;
+}
+
+// ---- Wigner-d table: out[l*sl + k*sk] = d^l_{ab}(x_k), l = 0..lmax ----------------------
+// coef[l] = (c1x, c1c, c2): d^{l+1} = (c1x x + c1c) d^l - c2 d^{l-1}
+__global__ void k_wigner_table(int lmax, int a, int b, int n, const double *__restrict__ x,
+                               const double4 *__restrict__ coef, double *__restrict__ out,
+                               long long sl, long long sk)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double xx = x[k];
+    const int l0 = max(abs(a), abs(b));
+    double d0;
+    if (a == 0 && b == 0) d0 = 1.0;
+    else if (a == 2 && b == 0) d0 = 0.61237243569579452455 * (1.0 - xx) * (1.0 + xx);
+    else if (a == 2 && b == 2) d0 = 0.25 * (1.0 + xx) * (1.0 + xx);
+    else d0 = 0.25 * (1.0 - xx) * (1.0 - xx);  // (2,-2)
+    for (int l = 0; l < l0 && l <= lmax; ++l) out[l * sl + k * sk] = 0.0;
+    if (l0 > lmax) return;
+    double dp = 0.0, dc = d0;
+    out[l0 * sl + k * sk] = dc;
+    for (int l = l0; l < lmax; ++l) {
+        const double4 c = coef[l];
+        const double dn = fma(fma(c.x, xx, c.y), dc, -c.z * dp);
+        dp = dc;
+        dc = dn;
+        out[(l + 1) * sl + k * sk] = dc;
+    }
+}
+
+// ---- s_k = w_k * xi(x_k), xi = sum_l (2l+1)/(4pi) W_l P_l(x) ----------------------------
+__global__ void k_weight_xi(int l3max, int n, const double *__restrict__ x, const double *__restrict__ w,
+                            const double *__restrict__ cl, double *__restrict__ s)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double xx = x[k];
+    double p0 = 1.0, p1 = xx;
+    double xi = cl[0] * (1.0 / (4.0 * M_PI));
+    if (l3max >= 1) xi += 3.0 / (4.0 * M_PI) * cl[1] * p1;
+    for (int l = 2; l <= l3max; ++l) {
+        const double p2 = ((2.0 * l - 1.0) * xx * p1 - (l - 1.0) * p0) / l;
+        p0 = p1;
+        p1 = p2;
+        xi = fma((2.0 * l + 1.0) / (4.0 * M_PI) * cl[l], p2, xi);
+    }
+    s[k] = w[k] * xi;
+}
+
+// ---- symmetric GEMM: G[i][j] = colscale[j] * sum_k T[i][k] s[k] T[j][k] -----------------
+// T: [rows_pad][kpad] (zero padded), block tiles (bi <= bj) from `tiles`; writes both halves.
+__global__ __launch_bounds__(256) void k_mixmat_gemm(const double *__restrict__ T, int kpad,
+                                                     const double *__restrict__ s,
+                                                     const int2 *__restrict__ tiles, int n1, int n2,
+                                                     const double *__restrict__ colscale,
+                                                     double *__restrict__ G, long long ldg)
+{
+    __shared__ double As[GB][GLD], Bs[GB][GLD];
+    const int2 tl = tiles[blockIdx.x];
+    const int bi = tl.x, bj = tl.y;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    double4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    const double *Ta = T + (long long)bi * GB * kpad, *Tb = T + (long long)bj * GB * kpad;
+    for (int k0 = 0; k0 < kpad; k0 += GK) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = t + 256 * u, row = e >> 4, c2 = (e & 15) * 2;
+            const double2 sa = *reinterpret_cast<const double2 *>(s + k0 + c2);
+            double2 va = *reinterpret_cast<const double2 *>(Ta + (long long)row * kpad + k0 + c2);
+            const double2 vb = *reinterpret_cast<const double2 *>(Tb + (long long)row * kpad + k0 + c2);
+            As[row][c2] = va.x * sa.x; As[row][c2 + 1] = va.y * sa.y;
+            Bs[row][c2] = vb.x;        Bs[row][c2 + 1] = vb.y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GK / 4; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = As[wr * 64 + i * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+                b[i] = Bs[wc * 64 + i * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D layout: row = (lane>>4) + 4*reg, col = lane&15
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = bi * GB + wr * 64 + i * 16 + (lane >> 4) + 4 * r;
+                const int gj = bj * GB + wc * 64 + j * 16 + (lane & 15);
+                const double v = acc[i][j][r];
+                if (gi < n1 && gj < n2) G[(long long)gi * ldg + gj] = v * colscale[gj];
+                if (bi != bj && gj < n1 && gi < n2) G[(long long)gj * ldg + gi] = v * colscale[gi];
+            }
+}
+
+// out0 = (a + b)/2, out1 = (a - b)/2, out2 = b   (a = G22 in out0, b = G2-2 in out2)
+__global__ void k_eb_combine(long long n, double *__restrict__ o0, double *__restrict__ o1,
+                             const double *__restrict__ o2)
+{
+    long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long st = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += st) {
+        const double a = o0[i], b = o2[i];
+        o0[i] = 0.5 * (a + b);
+        o1[i] = 0.5 * (a - b);
+    }
+}
+
+// ---- host helpers --------------------------------------------------------------------
+static void wigner_coefs(int lmax, int a, int b, std::vector<double4> &c)
+{
+    c.assign(lmax + 1, make_double4(0, 0, 0, 0));
+    for (int l = 0; l <= lmax; ++l) {
+        if (l == 0) { c[l] = make_double4(1.0, 0.0, 0.0, 0.0); continue; }
+        long double dl = l, lp = l + 1.0L;
+        long double den = dl * sqrtl((lp * lp - (long double)a * a) * (lp * lp - (long double)b * b));
+        if (den == 0.0L) continue;
+        long double c1x = (2 * dl + 1) * dl * lp / den;
+        long double c1c = -(2 * dl + 1) * (long double)a * b / den;
+        long double c2 = lp * sqrtl((dl * dl - (long double)a * a) * (dl * dl - (long double)b * b)) / den;
+        c[l] = make_double4((double)c1x, (double)c1c, (double)c2, 0.0);
+    }
+}
+
+int launch_gauss_legendre(int n, double *d_x, double *d_w)
+{
+    const int half = (n + 1) / 2;
+    hipLaunchKernelGGL(k_gauss_legendre, dim3((half + 63) / 64), dim3(64), 0, rt().stream, n, d_x, d_w);
+    HX_HIP(hipGetLastError());
+    return HX_OK;
+}
+
+struct GLCache {
+    int n = 0;
+    DevBuf x, w;
+};
+
+static int gl_nodes_device(int n, GLCache &c)
+{
+    if (c.n == n && c.x.p) return HX_OK;
+    HX_TRY(c.x.alloc(sizeof(double) * n));
+    HX_TRY(c.w.alloc(sizeof(double) * n));
+    HX_TRY(launch_gauss_legendre(n, c.x.as<double>(), c.w.as<double>()));
+    c.n = n;
+    return HX_OK;
+}
+
+// Build G^{(ab)} for all requested (a,b) into out matrices (device), (n1 x n2) each, ld = n2.
+static int mixmat_core(const double *d_cl, int l1max, int l2max, int l3max, int nprod,
+                       const int (*ab)[2], double *const *d_out)
+{
+    hipStream_t st = rt().stream;
+    const int L = std::max(l1max, l2max);
+    const int n = (l1max + l2max + l3max) / 2 + 1;
+    const int kpad = (n + GK - 1) / GK * GK;
+    const int rows_pad = (L + 1 + GB - 1) / GB * GB;
+    static thread_local GLCache gl;
+    HX_TRY(gl_nodes_device(n, gl));
+    DevBuf s, T, d_coef, d_tiles, d_cs;
+    HX_TRY(s.alloc(sizeof(double) * kpad));
+    HX_HIP(hipMemsetAsync(s.p, 0, sizeof(double) * kpad, st));
+    hipLaunchKernelGGL(k_weight_xi, dim3((n + 255) / 256), dim3(256), 0, st, l3max, n, gl.x.as<double>(), gl.w.as<double>(), d_cl, s.as<double>());
+    HX_TRY(T.alloc(sizeof(double) * (size_t)rows_pad * kpad));
+    std::vector<int2> tiles;
+    const int nb = rows_pad / GB;
+    for (int i = 0; i < nb; ++i)
+        for (int j = i; j < nb; ++j) tiles.push_back(make_int2(i, j));
+    HX_TRY(d_tiles.alloc(sizeof(int2) * tiles.size()));
+    HX_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice, st));
+    std::vector<double> cs(rows_pad, 0.0);
+    for (int l = 0; l <= L; ++l) cs[l] = (2.0 * l + 1.0) / 2.0;
+    HX_TRY(d_cs.alloc(sizeof(double) * rows_pad));
+    HX_HIP(hipMemcpyAsync(d_cs.p, cs.data(), sizeof(double) * rows_pad, hipMemcpyHostToDevice, st));
+    HX_TRY(d_coef.alloc(sizeof(double4) * (L + 1)));
+    std::vector<double4> coef;
+    for (int p = 0; p < nprod; ++p) {
+        wigner_coefs(L, ab[p][0], ab[p][1], coef);
+        HX_HIP(hipMemcpyAsync(d_coef.p, coef.data(), sizeof(double4) * (L + 1), hipMemcpyHostToDevice, st));
+        HX_HIP(hipMemsetAsync(T.p, 0, sizeof(double) * (size_t)rows_pad * kpad, st));
+        {
+            ProfScope ps("wigner_tables");
+            hipLaunchKernelGGL(k_wigner_table, dim3((n + 63) / 64), dim3(64), 0, st, L, ab[p][0], ab[p][1], n,
+                               gl.x.as<double>(), d_coef.as<double4>(), T.as<double>(), (long long)kpad, 1LL);
+        }
+        {
+            ProfScope ps("mixmat_gemm");
+            hipLaunchKernelGGL(k_mixmat_gemm, dim3((unsigned)tiles.size()), dim3(256), 0, st, T.as<double>(), kpad,
+                               s.as<double>(), d_tiles.as<int2>(), l1max + 1, l2max + 1, d_cs.as<double>(), d_out[p],
+                               (long long)(l2max + 1));
+        }
+        HX_HIP(hipStreamSynchronize(st));  // coef (host vector) is reused next iteration
+    }
+    HX_HIP(hipGetLastError());
+    return HX_OK;
+}
+
+static int stage_cl(const double *cl, int ncl, int l3max, DevBuf &buf)
+{
+    std::vector<double> h(l3max + 1, 0.0);
+    HX_TRY(buf.alloc(sizeof(double) * (l3max + 1)));
+    const int ncopy = std::min(ncl, l3max + 1);
+    if (is_device_ptr(cl)) {
+        HX_HIP(hipMemsetAsync(buf.p, 0, sizeof(double) * (l3max + 1), rt().stream));
+        HX_HIP(hipMemcpyAsync(buf.p, cl, sizeof(double) * ncopy, hipMemcpyDeviceToDevice, rt().stream));
+    } else {
+        for (int i = 0; i < ncopy; ++i) h[i] = cl[i];
+        HX_HIP(hipMemcpy(buf.p, h.data(), sizeof(double) * (l3max + 1), hipMemcpyHostToDevice));
+    }
+    return HX_OK;
+}
+
+}  // namespace hx
+
+using namespace hx;
+
+extern "C" int hx_gauss_legendre(int n, double *x, double *w)
+{
+    HX_TRY(ensure_ready());
+    if (n < 1 || !x || !w) return fail(HX_ERR_ARG, "hx_gauss_legendre: bad argument");
+    GLCache c;
+    HX_TRY(gl_nodes_device(n, c));
+    OutView vx, vw;
+    HX_TRY(vx.bind(x, sizeof(double) * n));
+    HX_TRY(vw.bind(w, sizeof(double) * n));
+    HX_HIP(hipMemcpyAsync(vx.dev, c.x.p, sizeof(double) * n, hipMemcpyDeviceToDevice, rt().stream));
+    HX_HIP(hipMemcpyAsync(vw.dev, c.w.p, sizeof(double) * n, hipMemcpyDeviceToDevice, rt().stream));
+    HX_TRY(vx.finish());
+    HX_TRY(vw.finish());
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    return HX_OK;
+}
+
+extern "C" int hx_wigner_d_table(int lmax, int a, int b, int n, const double *x, double *out)
+{
+    HX_TRY(ensure_ready());
+    if (lmax < 0 || n < 1 || !x || !out) return fail(HX_ERR_ARG, "hx_wigner_d_table: bad argument");
+    if (!((a == 0 && b == 0) || (a == 2 && b == 0) || (a == 2 && b == 2) || (a == 2 && b == -2)))
+        return fail(HX_ERR_UNSUPPORTED, "hx_wigner_d_table: (a,b)=(%d,%d) not supported", a, b);
+    InView vx;
+    OutView vo;
+    HX_TRY(vx.bind(x, sizeof(double) * n));
+    HX_TRY(vo.bind(out, sizeof(double) * (size_t)n * (lmax + 1)));
+    std::vector<double4> coef;
+    wigner_coefs(lmax, a, b, coef);
+    DevBuf d_coef;
+    HX_TRY(d_coef.alloc(sizeof(double4) * (lmax + 1)));
+    HX_HIP(hipMemcpy(d_coef.p, coef.data(), sizeof(double4) * (lmax + 1), hipMemcpyHostToDevice));
+    {
+        ProfScope ps("wigner_tables");
+        hipLaunchKernelGGL(k_wigner_table, dim3((n + 63) / 64), dim3(64), 0, rt().stream, lmax, a, b, n, vx.as<double>(),
+                           d_coef.as<double4>(), vo.as<double>(), 1LL, (long long)(lmax + 1));
+    }
+    HX_HIP(hipGetLastError());
+    HX_TRY(vo.finish());
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    return HX_OK;
+}
+
+static int mixmat_args(const double *cl, int ncl, int l1max, int l2max, int l3max, double *out)
+{
+    if (!cl || !out || ncl < 1 || l1max < 0 || l2max < 0 || l3max < 0)
+        return fail(HX_ERR_ARG, "mixmat: bad argument");
+    return HX_OK;
+}
+
+extern "C" int hx_mixmat(const double *cl, int ncl, int l1max, int l2max, int l3max, int s1, int s2, double *out)
+{
+    HX_TRY(ensure_ready());
+    HX_TRY(mixmat_args(cl, ncl, l1max, l2max, l3max, out));
+    int ab[1][2];
+    if (s1 == 0 && s2 == 0) { ab[0][0] = 0; ab[0][1] = 0; }
+    else if ((abs(s1) == 2 && s2 == 0) || (s1 == 0 && abs(s2) == 2)) { ab[0][0] = 2; ab[0][1] = 0; }
+    else return fail(HX_ERR_UNSUPPORTED, "hx_mixmat: spin (%d,%d) not supported (use hx_mixmat_eb for (2,2))", s1, s2);
+    DevBuf d_cl;
+    HX_TRY(stage_cl(cl, ncl, l3max, d_cl));
+    OutView vo;
+    HX_TRY(vo.bind(out, sizeof(double) * (size_t)(l1max + 1) * (l2max + 1)));
+    double *outs[1] = {vo.as<double>()};
+    HX_TRY(mixmat_core(d_cl.as<double>(), l1max, l2max, l3max, 1, ab, outs));
+    HX_TRY(vo.finish());
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    return HX_OK;
+}
+
+extern "C" int hx_mixmat_eb(const double *cl, int ncl, int l1max, int l2max, int l3max, double *out)
+{
+    HX_TRY(ensure_ready());
+    HX_TRY(mixmat_args(cl, ncl, l1max, l2max, l3max, out));
+    const size_t sz = (size_t)(l1max + 1) * (l2max + 1);
+    DevBuf d_cl;
+    HX_TRY(stage_cl(cl, ncl, l3max, d_cl));
+    OutView vo;
+    HX_TRY(vo.bind(out, sizeof(double) * 3 * sz));
+    int ab[2][2] = {{2, 2}, {2, -2}};
+    double *outs[2] = {vo.as<double>(), vo.as<double>() + 2 * sz};
+    HX_TRY(mixmat_core(d_cl.as<double>(), l1max, l2max, l3max, 2, ab, outs));
+    hipLaunchKernelGGL(k_eb_combine, dim3(1024), dim3(256), 0, rt().stream, (long long)sz, vo.as<double>(),
+                       vo.as<double>() + sz, vo.as<double>() + 2 * sz);
+    HX_HIP(hipGetLastError());
+    HX_TRY(vo.finish());
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    return HX_OK;
+}
+
+// hx_cl2corr / hx_corr2cl live in hx_transforms.hip

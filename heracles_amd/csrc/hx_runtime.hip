@@ -1,0 +1,281 @@
+// hx_runtime.hip -- device selection, streams, timers, error state of libhxsht.so.
+#include "hx_common.h"
+
+namespace hx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+Runtime &rt()
+{
+    static Runtime r;
+    return r;
+}
+
+int ensure_ready()
+{
+    if (rt().ready) return HX_OK;
+    int dev = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(HX_ERR_NO_DEVICE, "no HIP device available (libhxsht has no CPU fallback)");
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return hx_init(dev);
+}
+
+ProfScope::ProfScope(const char *n) : name(n)
+{
+    Runtime &r = rt();
+    if (!r.profiling) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        a = b = nullptr;
+        return;
+    }
+    (void)hipEventRecord(a, r.stream);
+}
+
+ProfScope::~ProfScope()
+{
+    Runtime &r = rt();
+    if (!a || !b) return;
+    (void)hipEventRecord(b, r.stream);
+    r.prof[name].pending.emplace_back(a, b);
+}
+
+bool is_device_ptr(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // clear: plain host memory is reported as an error
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+int DevBuf::alloc(size_t n)
+{
+    if (n <= bytes && p) return HX_OK;
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) {
+        p = nullptr;
+        return fail(HX_ERR_MEM, "hipMalloc of %zu bytes failed: %s", n, hipGetErrorString(e));
+    }
+    bytes = n;
+    return HX_OK;
+}
+
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+int InView::bind(const void *src, size_t bytes)
+{
+    if (!src) {
+        dev = nullptr;
+        return HX_OK;
+    }
+    if (is_device_ptr(src)) {
+        dev = src;
+        return HX_OK;
+    }
+    HX_TRY(tmp.alloc(bytes));
+    HX_HIP(hipMemcpyAsync(tmp.p, src, bytes, hipMemcpyHostToDevice, rt().stream));
+    dev = tmp.p;
+    return HX_OK;
+}
+
+int OutView::bind(void *dst, size_t n)
+{
+    bytes = n;
+    if (is_device_ptr(dst)) {
+        dev = dst;
+        host = nullptr;
+        return HX_OK;
+    }
+    HX_TRY(tmp.alloc(n));
+    dev = tmp.p;
+    host = dst;
+    return HX_OK;
+}
+
+int OutView::finish()
+{
+    if (!host) return HX_OK;
+    HX_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, rt().stream));
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    return HX_OK;
+}
+
+int finish_call()
+{
+    HX_HIP(hipGetLastError());
+    if (!rt().async) HX_HIP(hipStreamSynchronize(rt().stream));
+    return HX_OK;
+}
+
+}  // namespace hx
+
+using namespace hx;
+
+extern "C" {
+
+const char *hx_version(void) { return "hxsht 0.1 (gfx950)"; }
+
+const char *hx_last_error(void) { return hx::g_err; }
+
+int hx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int hx_init(int device)
+{
+    Runtime &r = rt();
+    int n = hx_device_count();
+    if (n <= 0) return fail(HX_ERR_NO_DEVICE, "no HIP device available (libhxsht has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(HX_ERR_ARG, "device %d out of range [0,%d)", device, n);
+    HX_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HX_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(HX_ERR_NO_DEVICE, "device %d is %s; libhxsht is built for gfx950 only", device,
+                    prop.gcnArchName);
+    if (r.ready && r.device == device) return HX_OK;
+    if (r.own_stream && r.stream) (void)hipStreamDestroy(r.stream);
+    HX_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+    r.own_stream = true;
+    if (!r.t0) HX_HIP(hipEventCreate(&r.t0));
+    if (!r.t1) HX_HIP(hipEventCreate(&r.t1));
+    r.device = device;
+    r.ready = true;
+    return HX_OK;
+}
+
+int hx_set_stream(void *stream)
+{
+    HX_TRY(ensure_ready());
+    Runtime &r = rt();
+    if (stream == nullptr) {
+        if (!r.own_stream) {
+            HX_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+            r.own_stream = true;
+        }
+        return HX_OK;
+    }
+    if (r.own_stream && r.stream) (void)hipStreamDestroy(r.stream);
+    r.stream = static_cast<hipStream_t>(stream);
+    r.own_stream = false;
+    return HX_OK;
+}
+
+void *hx_get_stream(void)
+{
+    if (ensure_ready() != HX_OK) return nullptr;
+    return rt().stream;
+}
+
+int hx_set_async(int on)
+{
+    rt().async = on != 0;
+    return HX_OK;
+}
+
+int hx_synchronize(void)
+{
+    HX_TRY(ensure_ready());
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    return HX_OK;
+}
+
+int hx_timer_start(void)
+{
+    HX_TRY(ensure_ready());
+    HX_HIP(hipEventRecord(rt().t0, rt().stream));
+    return HX_OK;
+}
+
+int hx_timer_stop(float *ms)
+{
+    HX_TRY(ensure_ready());
+    HX_HIP(hipEventRecord(rt().t1, rt().stream));
+    HX_HIP(hipEventSynchronize(rt().t1));
+    float t = 0.f;
+    HX_HIP(hipEventElapsedTime(&t, rt().t0, rt().t1));
+    if (ms) *ms = t;
+    return HX_OK;
+}
+
+int hx_profile_enable(int on)
+{
+    rt().profiling = on != 0;
+    return HX_OK;
+}
+
+static void drain(Runtime::Prof &p)
+{
+    for (auto &ev : p.pending) {
+        float t = 0.f;
+        if (hipEventSynchronize(ev.second) == hipSuccess &&
+            hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) {
+            p.ms += t;
+            p.launches += 1;
+        }
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    p.pending.clear();
+}
+
+int hx_profile_reset(void)
+{
+    for (auto &kv : rt().prof) {
+        drain(kv.second);
+        kv.second.ms = 0.0;
+        kv.second.launches = 0;
+    }
+    return HX_OK;
+}
+
+int hx_profile_get(const char *name, int *launches, double *total_ms)
+{
+    auto it = rt().prof.find(name ? name : "");
+    if (it == rt().prof.end()) {
+        if (launches) *launches = 0;
+        if (total_ms) *total_ms = 0.0;
+        return HX_OK;
+    }
+    drain(it->second);
+    if (launches) *launches = it->second.launches;
+    if (total_ms) *total_ms = it->second.ms;
+    return HX_OK;
+}
+
+}  // extern "C"

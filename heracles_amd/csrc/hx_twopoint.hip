@@ -1,0 +1,165 @@
+// hx_twopoint.hip -- all-pairs alm x alm -> Cl reduction (HBM-bound).
+//
+// Replaces heracles.twopoint.alm2cl (heracles/twopoint.py:63-101) for a list of component
+// pairs:   cl_l = [Re a_l0 Re b_l0 + 2 sum_{m=1..l} Re(a_lm conj b_lm)] / (2l+1)
+// (the imaginary part of m=0 is ignored, twopoint.py:88).
+//
+// Layout: alm is m-major, so for fixed m consecutive l are contiguous: lanes map to l
+// (1 KiB coalesced per wave-load), the sum over m runs in-lane; the four waves of a
+// workgroup split m round-robin and are combined through LDS in a fixed order, so results
+// are bit-reproducible run to run.  Components are tiled T x T so every alm value loaded is
+// used for T products (the reference re-reads each alm once per partner).
+#include "hx_common.h"
+
+namespace hx {
+
+constexpr int CL_T = 4;        // component tile edge
+constexpr int CL_WAVES = 4;    // waves per workgroup (m split)
+constexpr int CL_LB = 64;      // l values per workgroup
+
+struct ClTile {
+    int i0, j0;               // first component of the tile along each axis
+    int out[CL_T * CL_T];     // pair index of (i0+a, j0+b) or -1
+};
+
+__global__ __launch_bounds__(CL_WAVES * 64) void k_alm2cl_tiles(
+    const double2 *const *__restrict__ comp, const int *__restrict__ comp_lmax, int ncomp,
+    const ClTile *__restrict__ tiles, int lmax_out, int nlblk, double *__restrict__ cls)
+{
+    __shared__ double red[CL_WAVES][CL_T * CL_T][CL_LB];
+    // heavy (high-l) blocks first
+    const int lblk = nlblk - 1 - (int)(blockIdx.x % nlblk);
+    const ClTile tile = tiles[blockIdx.x / nlblk];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l = lblk * CL_LB + lane;
+    const int lhi = min(lblk * CL_LB + CL_LB - 1, lmax_out);
+
+    const double2 *pa[CL_T], *pb[CL_T];
+    long long La[CL_T], Lb[CL_T];
+#pragma unroll
+    for (int t = 0; t < CL_T; ++t) {
+        int ia = min(tile.i0 + t, ncomp - 1), ib = min(tile.j0 + t, ncomp - 1);
+        pa[t] = comp[ia]; La[t] = comp_lmax[ia];
+        pb[t] = comp[ib]; Lb[t] = comp_lmax[ib];
+    }
+    double acc[CL_T * CL_T];
+#pragma unroll
+    for (int t = 0; t < CL_T * CL_T; ++t) acc[t] = 0.0;
+
+    for (int m = w; m <= lhi; m += CL_WAVES) {
+        if (m <= l && l <= lmax_out) {
+            double2 a[CL_T], b[CL_T];
+#pragma unroll
+            for (int t = 0; t < CL_T; ++t) {
+                a[t] = pa[t][(long long)m * (2 * La[t] + 1 - m) / 2 + l];
+                b[t] = pb[t][(long long)m * (2 * Lb[t] + 1 - m) / 2 + l];
+            }
+            const double wgt = m == 0 ? 1.0 : 2.0;
+#pragma unroll
+            for (int s = 0; s < CL_T; ++s)
+#pragma unroll
+                for (int t = 0; t < CL_T; ++t) {
+                    double p = a[s].x * b[t].x;
+                    if (m != 0) p = fma(a[s].y, b[t].y, p);
+                    acc[s * CL_T + t] = fma(wgt, p, acc[s * CL_T + t]);
+                }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < CL_T * CL_T; ++t) red[w][t][lane] = acc[t];
+    __syncthreads();
+    // fixed-order combine; thread (w, lane) finishes pairs t = w, w+4, ...
+    if (l <= lmax_out) {
+        for (int t = w; t < CL_T * CL_T; t += CL_WAVES) {
+            int o = tile.out[t];
+            if (o < 0) continue;
+            double s = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < CL_WAVES; ++ww) s += red[ww][t][lane];
+            cls[(long long)o * (lmax_out + 1) + l] = s / (2.0 * l + 1.0);
+        }
+    }
+}
+
+}  // namespace hx
+
+using namespace hx;
+
+extern "C" int hx_alm2cl_pairs(int ncomp, const int *lmax_i, const double *const *alms,
+                               int lmax_out, int npairs, const int *pair_i, const int *pair_j,
+                               double *cls)
+{
+    HX_TRY(ensure_ready());
+    if (ncomp <= 0 || npairs < 0 || !lmax_i || !alms || !pair_i || !pair_j || !cls || lmax_out < 0)
+        return fail(HX_ERR_ARG, "hx_alm2cl_pairs: bad argument");
+    if (npairs == 0) return HX_OK;
+    for (int c = 0; c < ncomp; ++c)
+        if (!alms[c] || lmax_i[c] < 0) return fail(HX_ERR_ARG, "hx_alm2cl_pairs: component %d invalid", c);
+    for (int p = 0; p < npairs; ++p) {
+        if (pair_i[p] < 0 || pair_i[p] >= ncomp || pair_j[p] < 0 || pair_j[p] >= ncomp)
+            return fail(HX_ERR_ARG, "hx_alm2cl_pairs: pair %d out of range", p);
+        if (lmax_i[pair_i[p]] < lmax_out || lmax_i[pair_j[p]] < lmax_out)
+            return fail(HX_ERR_ARG, "hx_alm2cl_pairs: lmax_out exceeds lmax of pair %d", p);
+    }
+    hipStream_t st = rt().stream;
+
+    // stage components (device pointers are used in place)
+    std::vector<InView> views(ncomp);
+    std::vector<const double2 *> ptrs(ncomp);
+    for (int c = 0; c < ncomp; ++c) {
+        size_t nlm = (size_t)(lmax_i[c] + 1) * (lmax_i[c] + 2) / 2;
+        HX_TRY(views[c].bind(alms[c], nlm * sizeof(double2)));
+        ptrs[c] = views[c].as<double2>();
+    }
+    // tiles
+    const int nb = (ncomp + CL_T - 1) / CL_T;
+    std::map<std::pair<int, int>, int> tile_of;
+    std::vector<ClTile> tiles;
+    for (int p = 0; p < npairs; ++p) {
+        int bi = pair_i[p] / CL_T, bj = pair_j[p] / CL_T;
+        auto key = std::make_pair(bi, bj);
+        auto it = tile_of.find(key);
+        if (it == tile_of.end()) {
+            ClTile t;
+            t.i0 = bi * CL_T;
+            t.j0 = bj * CL_T;
+            for (int k = 0; k < CL_T * CL_T; ++k) t.out[k] = -1;
+            tiles.push_back(t);
+            it = tile_of.emplace(key, (int)tiles.size() - 1).first;
+        }
+        ClTile &t = tiles[it->second];
+        int slot = (pair_i[p] - t.i0) * CL_T + (pair_j[p] - t.j0);
+        if (t.out[slot] >= 0) {
+            // duplicate pair in the list: give it its own tile so each output is written
+            ClTile d;
+            d.i0 = t.i0; d.j0 = t.j0;
+            for (int k = 0; k < CL_T * CL_T; ++k) d.out[k] = -1;
+            d.out[slot] = p;
+            tiles.push_back(d);
+        } else
+            t.out[slot] = p;
+    }
+    (void)nb;
+    DevBuf d_ptrs, d_lmax, d_tiles;
+    HX_TRY(d_ptrs.alloc(sizeof(void *) * ncomp));
+    HX_TRY(d_lmax.alloc(sizeof(int) * ncomp));
+    HX_TRY(d_tiles.alloc(sizeof(ClTile) * tiles.size()));
+    HX_HIP(hipMemcpyAsync(d_ptrs.p, ptrs.data(), sizeof(void *) * ncomp, hipMemcpyHostToDevice, st));
+    HX_HIP(hipMemcpyAsync(d_lmax.p, lmax_i, sizeof(int) * ncomp, hipMemcpyHostToDevice, st));
+    HX_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), sizeof(ClTile) * tiles.size(), hipMemcpyHostToDevice, st));
+    OutView out;
+    HX_TRY(out.bind(cls, sizeof(double) * (size_t)npairs * (lmax_out + 1)));
+
+    const int nlblk = (lmax_out + CL_LB) / CL_LB;
+    {
+        ProfScope ps("alm2cl");
+        hipLaunchKernelGGL(k_alm2cl_tiles, dim3((unsigned)(nlblk * tiles.size())), dim3(CL_WAVES * 64), 0, st,
+                           d_ptrs.as<const double2 *>(), d_lmax.as<int>(), ncomp, d_tiles.as<ClTile>(),
+                           lmax_out, nlblk, out.as<double>());
+    }
+    HX_HIP(hipGetLastError());
+    HX_TRY(out.finish());
+    // temporaries (views, tables) are freed on return: make sure the kernel is done
+    HX_HIP(hipStreamSynchronize(st));
+    return HX_OK;
+}

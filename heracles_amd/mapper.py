@@ -1,0 +1,200 @@
+"""HEALPix mapper backed by the HIP spherical harmonic transform.
+
+``HipHealpixMapper`` satisfies the ``heracles.mapper.Mapper`` protocol
+(heracles/mapper.py:33-74) and mirrors ``heracles.healpy.HealpixMapper``
+(heracles/healpy.py:68-209): same constructor, properties, dtype-metadata and spin
+dispatch; ``transform`` runs on the GPU through libhxsht instead of ``healpy.map2alm``.
+
+Data healpy ships but this repository cannot (pixel-window tables, pixel-weight files)
+is taken from the caller: pass ``pixwin=(pw_T, pw_P)`` / ``pixel_weights=...``; if they
+are omitted and the user's environment has healpy, its tables are used.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import sht
+from .core import update_metadata
+
+
+def pixel_window(nside, lmax, pixwin=None):
+    """(pw_T, pw_P) up to lmax: explicit arrays, a callable(nside, lmax), or healpy's table."""
+    if pixwin is not None:
+        if callable(pixwin):
+            pw0, pw2 = pixwin(nside, lmax)
+        else:
+            pw0, pw2 = pixwin
+        pw0, pw2 = np.asarray(pw0, dtype=float), np.asarray(pw2, dtype=float)
+        if pw0.shape[-1] < lmax + 1 or pw2.shape[-1] < lmax + 1:
+            raise ValueError("pixel window shorter than lmax+1")
+        return pw0[: lmax + 1], pw2[: lmax + 1]
+    try:
+        import healpy as hp
+    except ImportError as exc:
+        raise RuntimeError(
+            "pixel-window deconvolution needs the HEALPix pixel window table: pass "
+            "pixwin=(pw_T, pw_P) to HipHealpixMapper (or install healpy for its table), "
+            "or use deconvolve=False"
+        ) from exc
+    return hp.pixwin(nside, lmax=lmax, pol=True)
+
+
+def _native(arr):
+    """heracles/healpy.py:43-55: inputs in non-native byte order are byteswapped."""
+    arr = np.asanyarray(arr)
+    if arr.dtype.byteorder not in ("=", "|"):
+        arr = arr.view(arr.dtype.newbyteorder("=")).byteswap()
+    return arr
+
+
+def ang2pix_ring(nside, lon, lat):
+    """RING pixel index of (lon, lat) in degrees -- the HEALPix ang2pix definition
+    (Gorski et al. 2005), the function ``hp.ang2pix(nside, lon, lat, lonlat=True)``
+    provides at heracles/healpy.py:157.  Host-side numpy; a HIP version is the first
+    "next" row of SURVEY.md section 8f."""
+    lon = np.asarray(lon, dtype=np.float64)
+    lat = np.asarray(lat, dtype=np.float64)
+    theta = np.radians(90.0 - lat)
+    z = np.cos(theta)
+    za = np.abs(z)
+    tt = np.mod(np.radians(lon), 2 * np.pi) * (2.0 / np.pi)  # in [0,4)
+    tt = np.where(tt >= 4.0, tt - 4.0, tt)
+    nl4 = 4 * nside
+    npix = 12 * nside * nside
+    ncap = 2 * nside * (nside - 1)
+    out = np.empty(z.shape, dtype=np.int64)
+    eq = za <= 2.0 / 3.0
+    # equatorial region
+    temp1 = nside * (0.5 + tt)
+    temp2 = nside * z * 0.75
+    jp = np.floor(temp1 - temp2).astype(np.int64)
+    jm = np.floor(temp1 + temp2).astype(np.int64)
+    ir = nside + 1 + jp - jm
+    kshift = 1 - (ir & 1)
+    ip = (jp + jm - nside + kshift + 1) // 2
+    ip = np.mod(ip, nl4)
+    pe = ncap + (ir - 1) * nl4 + ip
+    # polar caps
+    tp = tt - np.floor(tt)
+    sth = np.sin(theta)
+    big = za >= 0.99
+    tmp = np.where(big, nside * sth / np.sqrt((1.0 + za) / 3.0), nside * np.sqrt(3.0 * (1.0 - za)))
+    jp2 = np.floor(tp * tmp).astype(np.int64)
+    jm2 = np.floor((1.0 - tp) * tmp).astype(np.int64)
+    ir2 = jp2 + jm2 + 1
+    ip2 = np.floor(tt * ir2).astype(np.int64)
+    ip2 = np.mod(ip2, 4 * ir2)
+    pn = 2 * ir2 * (ir2 - 1) + ip2
+    ps = npix - 2 * ir2 * (ir2 + 1) + ip2
+    out = np.where(eq, pe, np.where(z > 0, pn, ps))
+    return out
+
+
+class HipHealpixMapper:
+    """Mapper for HEALPix maps whose ``transform`` runs on MI355X."""
+
+    #: kept for interface compatibility with HealpixMapper.DATAPATH (heracles/healpy.py:73)
+    DATAPATH = None
+
+    def __init__(self, nside, lmax=None, *, deconvolve=None, dtype=np.float64, niter=3,
+                 pixwin=None, pixel_weights=None, ring_weights=None):
+        if lmax is None:
+            lmax = 3 * nside // 2
+        if deconvolve is None:
+            deconvolve = True
+        self.__nside = nside
+        self.__lmax = lmax
+        self.__deconv = deconvolve
+        self.__dtype = np.dtype(dtype)
+        #: Jacobi iterations; healpy.map2alm's default is iter=3 and the reference passes none
+        self.niter = niter
+        self.pixwin = pixwin
+        self.pixel_weights = pixel_weights
+        self.ring_weights = ring_weights
+
+    @property
+    def nside(self):
+        return self.__nside
+
+    @property
+    def lmax(self):
+        return self.__lmax
+
+    @property
+    def deconvolve(self):
+        return self.__deconv
+
+    @property
+    def area(self):
+        """Pixel area in steradians (hp.nside2pixarea, heracles/healpy.py:117-122)."""
+        return 4.0 * np.pi / (12 * self.__nside**2)
+
+    def create(self, *dims, spin=0):
+        m = np.zeros((*dims, 12 * self.__nside**2), dtype=self.__dtype)
+        update_metadata(m, geometry="healpix", kernel="healpix", nside=self.__nside,
+                        lmax=self.__lmax, deconv=self.__deconv, spin=spin)
+        return m
+
+    def map_values(self, lon, lat, data, values, spin=0):
+        """Add values to the pixels containing (lon, lat) [degrees]; heracles/healpy.py:144-160."""
+        ipix = ang2pix_ring(self.__nside, _native(lon), _native(lat))
+        values = _native(values)
+        flat = data.reshape(-1, data.shape[-1])
+        vals = np.asarray(values).reshape(-1, np.shape(values)[-1])
+        for row in range(flat.shape[0]):
+            np.add.at(flat[row], ipix, vals[row])
+
+    def _fl(self, spin):
+        if not self.__deconv:
+            return None
+        pw0, pw2 = pixel_window(self.__nside, self.__lmax, self.pixwin)
+        pw = pw0 if spin == 0 else pw2
+        fl = np.ones(self.__lmax + 1)
+        fl[abs(spin):] /= pw[abs(spin):]
+        return fl
+
+    def transform(self, data, spin=0):
+        """Spherical harmonic transform of HEALPix maps; heracles/healpy.py:162-203."""
+        md = data.dtype.metadata or {}
+        if spin not in (0, 2):
+            raise NotImplementedError(f"spin-{spin} maps not yet supported")
+        fl = self._fl(spin)
+        plan = sht.get_plan(self.__nside, self.__lmax)
+        maps = np.ascontiguousarray(_native(data), dtype=np.float64)
+        if spin == 2 and (maps.ndim < 2 or maps.shape[-2] != 2):
+            raise ValueError("spin-2 maps must have shape (..., 2, npix)")
+        alm = plan.map2alm(maps, spin, ring_weights=self.ring_weights,
+                           pix_weights=self.pixel_weights, fl=fl, niter=self.niter)
+        update_metadata(alm, **{**md, "deconv": self.__deconv})
+        return alm
+
+    def transform_many(self, maps, spins):
+        """Batched transform of a list of maps (the loop of heracles/mapping.py:151-172 as
+        one call): spin-0 maps are stacked 8 to a launch, spin-2 maps 4 to a launch."""
+        out = [None] * len(maps)
+        for s in (0, 2):
+            idx = [i for i, sp in enumerate(spins) if sp == s]
+            if not idx:
+                continue
+            stack = np.stack([np.ascontiguousarray(_native(maps[i]), dtype=np.float64) for i in idx])
+            fl = self._fl(s)
+            plan = sht.get_plan(self.__nside, self.__lmax)
+            alms = plan.map2alm(stack.reshape(-1, stack.shape[-1]), s, ring_weights=self.ring_weights,
+                                pix_weights=self.pixel_weights, fl=fl, niter=self.niter)
+            alms = alms.reshape(*stack.shape[:-1], -1)
+            for k, i in enumerate(idx):
+                a = np.array(alms[k])
+                update_metadata(a, **{**(maps[i].dtype.metadata or {}), "deconv": self.__deconv})
+                out[i] = a
+        for i, sp in enumerate(spins):
+            if sp not in (0, 2):
+                raise NotImplementedError(f"spin-{sp} maps not yet supported")
+        return out
+
+    def resample(self, data):
+        """Change resolution (hp.ud_grade, heracles/healpy.py:205-209).  Only the identity
+        case is provided here; NSIDE changes are a "next" row."""
+        if data.shape[-1] == 12 * self.__nside**2:
+            return np.array(data, dtype=self.__dtype)
+        raise NotImplementedError("ud_grade between different NSIDE is not part of the hot path")

@@ -1,0 +1,114 @@
+"""Plan-level interface to the HIP spherical harmonic transforms (libhxsht)."""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+def nlm(lmax: int) -> int:
+    return (lmax + 1) * (lmax + 2) // 2
+
+
+def _is_tensor(a) -> bool:
+    return hasattr(a, "data_ptr") and not isinstance(a, np.ndarray)
+
+
+class Plan:
+    """Ring tables, recursion tables and device scratch for one (nside, lmax).
+
+    Replaces the implicit plan inside ``healpy.map2alm`` (heracles/healpy.py:183-189).
+    Inputs may be numpy arrays (host; staged by the library) or contiguous torch CUDA
+    tensors of dtype float64 / complex128 (used in place, results stay in HBM).
+    """
+
+    def __init__(self, nside: int, lmax: int, max_comp: int = 8):
+        L = _lib.load()
+        _lib.ensure_init()
+        self.nside, self.lmax = int(nside), int(lmax)
+        self.npix = 12 * self.nside**2
+        self.nlm = nlm(self.lmax)
+        self._h = L.hx_plan_create(self.nside, self.lmax, int(max_comp))
+        if not self._h:
+            raise _lib.HxError(-1, L.hx_last_error().decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().hx_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    @property
+    def scratch_bytes(self) -> int:
+        return int(_lib.load().hx_plan_scratch_bytes(self._h))
+
+    # -- helpers ------------------------------------------------------------------
+    def _out_like(self, ref, shape, complex_):
+        if _is_tensor(ref):
+            import torch
+
+            return torch.empty(shape, dtype=torch.complex128 if complex_ else torch.float64,
+                               device=ref.device)
+        return np.empty(shape, dtype=np.complex128 if complex_ else np.float64)
+
+    @staticmethod
+    def _prep(a, dtype):
+        if a is None:
+            return None
+        if _is_tensor(a):
+            return a.contiguous()
+        return np.ascontiguousarray(a, dtype=dtype)
+
+    # -- transforms ---------------------------------------------------------------
+    def map2alm(self, maps, spin=0, *, ring_weights=None, pix_weights=None, fl=None,
+                niter=0, out=None):
+        """maps (..., npix) -> alm (..., nlm).  spin 2: the leading axis pairs (Q, U) -> (E, B)."""
+        maps = self._prep(maps, np.float64)
+        lead = tuple(maps.shape[:-1])
+        if maps.shape[-1] != self.npix:
+            raise ValueError(f"map has {maps.shape[-1]} pixels, plan expects {self.npix}")
+        ncomp = int(np.prod(lead)) if lead else 1
+        if out is None:
+            out = self._out_like(maps, lead + (self.nlm,), True)
+        rw = self._prep(ring_weights, np.float64)
+        pw = self._prep(pix_weights, np.float64)
+        flv = self._prep(fl, np.float64)
+        if flv is not None and flv.shape[-1] != self.lmax + 1:
+            raise ValueError("fl must have lmax+1 entries")
+        _lib.check(_lib.load().hx_map2alm(self._h, int(spin), ncomp, _lib.ptr(maps), _lib.ptr(out),
+                                          _lib.ptr(rw), _lib.ptr(pw), _lib.ptr(flv), int(niter)))
+        return out
+
+    def alm2map(self, alms, spin=0, *, out=None):
+        alms = self._prep(alms, np.complex128)
+        lead = tuple(alms.shape[:-1])
+        if alms.shape[-1] != self.nlm:
+            raise ValueError(f"alm has {alms.shape[-1]} coefficients, plan expects {self.nlm}")
+        ncomp = int(np.prod(lead)) if lead else 1
+        if out is None:
+            out = self._out_like(alms, lead + (self.npix,), False)
+        _lib.check(_lib.load().hx_alm2map(self._h, int(spin), ncomp, _lib.ptr(alms), _lib.ptr(out)))
+        return out
+
+
+_plans: dict = {}
+
+
+def get_plan(nside: int, lmax: int) -> Plan:
+    """Process-wide plan cache (tables for nside=4096 take a few hundred MB of HBM)."""
+    key = (int(nside), int(lmax))
+    if key not in _plans:
+        _plans[key] = Plan(nside, lmax)
+    return _plans[key]
+
+
+def clear_plans():
+    for p in _plans.values():
+        p.close()
+    _plans.clear()

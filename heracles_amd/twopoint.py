@@ -1,0 +1,335 @@
+"""Two-point functions of the hot path, backed by libhxsht.
+
+Mirrors the call surface of ``heracles.twopoint`` (heracles/twopoint.py): ``alm2lmax``,
+``alm2cl``, ``angular_power_spectra``, ``debias_cls``, ``mixing_matrices`` and the
+``convolvecl.mixmat`` / ``mixmat_eb`` functions the reference imports at
+heracles/twopoint.py:330.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import time
+from itertools import combinations_with_replacement, product
+
+import numpy as np
+
+from . import _lib
+from .core import Result, TocDict, toc_match, update_metadata
+
+logger = logging.getLogger(__name__)
+
+
+def alm2lmax(alm, mmax=None):
+    """lmax of an alm array from its last-axis length (heracles/twopoint.py:55-60)."""
+    n = np.shape(alm)[-1]
+    return (int((8 * n + 1) ** 0.5 + 0.01) - 3) // 2
+
+
+def _is_tensor(a):
+    return hasattr(a, "data_ptr") and not isinstance(a, np.ndarray)
+
+
+def alm2cl_pairs(comps, pairs, lmax_out):
+    """All requested component-pair spectra in one launch.
+
+    comps: list of 1-D complex128 arrays (numpy, or torch CUDA tensors); pairs: list of
+    (i, j) indices into comps.  Returns a float64 array (npairs, lmax_out+1).
+    """
+    L = _lib.load()
+    _lib.ensure_init()
+    ncomp = len(comps)
+    keep = []
+    ptrs = (C.c_void_p * ncomp)()
+    lmaxs = (C.c_int * ncomp)()
+    for k, a in enumerate(comps):
+        if not _is_tensor(a):
+            a = np.ascontiguousarray(a, dtype=np.complex128)
+        elif not a.is_contiguous():
+            a = a.contiguous()
+        keep.append(a)
+        ptrs[k] = _lib.ptr(a).value
+        lmaxs[k] = alm2lmax(a)
+    npairs = len(pairs)
+    pi = (C.c_int * max(npairs, 1))(*[p[0] for p in pairs])
+    pj = (C.c_int * max(npairs, 1))(*[p[1] for p in pairs])
+    out = np.zeros((npairs, lmax_out + 1))
+    if npairs:
+        _lib.check(L.hx_alm2cl_pairs(ncomp, lmaxs, ptrs, int(lmax_out), npairs, pi, pj, _lib.ptr(out)))
+    return out
+
+
+def alm2cl(alm, alm2=None, *, lmax=None):
+    """Angular (cross-)power spectrum block, same semantics as heracles/twopoint.py:63-101.
+
+    Leading axes are component axes and broadcast to a block
+    ``(*alm.shape[:-1], *alm2.shape[:-1], L)``; the two inputs may have different lmax.
+    """
+    if alm2 is None:
+        alm2 = alm
+    alm = np.asanyarray(alm)
+    alm2 = np.asanyarray(alm2)
+    lmax1, lmax2 = alm2lmax(alm), alm2lmax(alm2)
+    lout = min(lmax1, lmax2) if lmax is None else min(lmax, lmax1, lmax2)
+    a = np.ascontiguousarray(alm, dtype=np.complex128).reshape(-1, alm.shape[-1])
+    same = alm2 is alm
+    b = a if same else np.ascontiguousarray(alm2, dtype=np.complex128).reshape(-1, alm2.shape[-1])
+    comps = list(a) + ([] if same else list(b))
+    offs = 0 if same else a.shape[0]
+    pairs = [(i, offs + j) for i in range(a.shape[0]) for j in range(b.shape[0])]
+    cl = alm2cl_pairs(comps, pairs, lout)
+    return cl.reshape(*alm.shape[:-1], *alm2.shape[:-1], lout + 1)
+
+
+def _pixwin_for(md, i, s, lmax, pixwin):
+    """Pixel window of field i for debiasing (heracles/twopoint.py:147-165)."""
+    if md.get(f"kernel_{i}") != "healpix":
+        return None
+    nside = md.get(f"nside_{i}")
+    deconv = md.get(f"deconv_{i}", True)
+    if nside is None or not deconv or s not in (0, 2):
+        return None
+    from .mapper import pixel_window
+
+    pw0, pw2 = pixel_window(nside, lmax, pixwin)
+    return pw0 if s == 0 else pw2
+
+
+def _debias_cl(cl, bias=None, md=None, *, inplace=False, pixwin=None):
+    """Remove additive bias from a spectrum block (heracles/twopoint.py:104-170)."""
+    if md is None:
+        md = cl.dtype.metadata or {}
+    if not inplace:
+        cl = cl.copy()
+        update_metadata(cl, **md)
+    if bias is None:
+        bias = md.get("bias")
+        if bias is None:
+            return cl
+    spin1, spin2 = md.get("spin_1", 0), md.get("spin_2", 0)
+    lmin = max(abs(spin1), abs(spin2))
+    lmax = cl.shape[-1] - 1
+    bl = np.zeros(cl.shape)
+    if spin1 != 0 and spin2 != 0:
+        assert cl.shape[:2] == (2, 2)
+        bl[[0, 1], [0, 1], ..., lmin:] = bias
+    else:
+        bl[..., lmin:] = bias
+    for i, s in (1, spin1), (2, spin2):
+        pw = _pixwin_for(md, i, s, lmax, pixwin)
+        if pw is not None:
+            bl[..., lmin:] /= pw[lmin:]
+    cl[:] -= bl
+    return cl
+
+
+def debias_cls(cls, bias=None, *, inplace=False, pixwin=None):
+    """Remove bias from a set of spectra (heracles/twopoint.py:302-313)."""
+    out = cls if inplace else TocDict()
+    for key in cls:
+        out[key] = _debias_cl(cls[key], bias and bias.get(key), inplace=inplace, pixwin=pixwin)
+    return out
+
+
+def angular_power_spectra(alms, alms2=None, *, lmax=None, debias=True, bins=None, weights=None,
+                          include=None, exclude=None, out=None, pixwin=None):
+    """All auto/cross spectra of a set of alms: heracles/twopoint.py:173-299.
+
+    Pair enumeration, duplicate skipping, key canonicalisation, metadata merge and the
+    auto-spectrum bias rule follow the reference; the arithmetic of every pair is done by
+    ONE all-pairs launch (each alm is read from HBM once per component tile instead of
+    once per partner).
+    """
+    logger.info("computing cls for %d%s alm(s)", len(alms), f"x{len(alms2)}" if alms2 is not None else "")
+    t0 = time.monotonic()
+    if alms2 is None:
+        pairs = combinations_with_replacement(alms, 2)
+        alms2 = alms
+    else:
+        pairs = product(alms, alms2)
+    names = set()
+    cls = TocDict() if out is None else out
+    # pass 1: host logic exactly as the reference's loop, collecting the work list
+    todo = []
+    seen = set()
+    for (k1, i1), (k2, i2) in pairs:
+        if (k1, k2, i1, i2) in cls or (k2, k1, i2, i1) in cls:
+            continue
+        if (k1, k2, i1, i2) in seen or (k2, k1, i2, i1) in seen:
+            continue
+        if (k1, k2) not in names and (k2, k1) in names:
+            i1, i2 = i2, i1
+            k1, k2 = k2, k1
+            swapped = True
+        else:
+            swapped = False
+        if not toc_match((k1, k2, i1, i2), include, exclude):
+            continue
+        if swapped:
+            alm1, alm2 = alms2[k1, i1], alms[k2, i2]
+        else:
+            alm1, alm2 = alms[k1, i1], alms2[k2, i2]
+        todo.append(((k1, k2, i1, i2), alm1, alm2))
+        seen.add((k1, k2, i1, i2))
+        names.add((k1, k2))
+    # pass 2: one launch for every component pair of every map pair
+    comps, index, plist, shapes = [], {}, [], []
+
+    def comp_ids(arr):
+        a2 = np.ascontiguousarray(arr, dtype=np.complex128).reshape(-1, arr.shape[-1])
+        ids = []
+        for row in range(a2.shape[0]):
+            key = (id(arr), row)
+            if key not in index:
+                index[key] = len(comps)
+                comps.append(a2[row])
+            ids.append(index[key])
+        return ids
+
+    louts = []
+    for key, alm1, alm2 in todo:
+        l1, l2 = alm2lmax(alm1), alm2lmax(alm2)
+        louts.append(min(l1, l2) if lmax is None else min(lmax, l1, l2))
+    # the kernel writes a common output length; group by output lmax
+    results = [None] * len(todo)
+    for lo in sorted(set(louts)):
+        plist, owners = [], []
+        for n, (key, alm1, alm2) in enumerate(todo):
+            if louts[n] != lo:
+                continue
+            ia, ib = comp_ids(alm1), comp_ids(alm2)
+            owners.append((n, len(plist), len(ia), len(ib)))
+            plist.extend((a, b) for a in ia for b in ib)
+        block = alm2cl_pairs(comps, plist, lo)
+        for n, start, na, nb in owners:
+            key, alm1, alm2 = todo[n]
+            results[n] = block[start : start + na * nb].reshape(*alm1.shape[:-1], *alm2.shape[:-1], lo + 1).copy()
+    # pass 3: metadata, bias, wrapping -- per pair, as the reference
+    for (key, alm1, alm2), cl in zip(todo, results):
+        k1, k2, i1, i2 = key
+        md1 = alm1.dtype.metadata or {}
+        md2 = alm2.dtype.metadata or {}
+        s1, s2 = md1.get("spin", None), md2.get("spin", None)
+        if s1 is None or s2 is None:
+            raise ValueError(f"missing spin metadata for {k1} or {k2}")
+        md = {}
+        for k, v in md1.items():
+            md[f"{k}_1"] = v
+        for k, v in md2.items():
+            md[f"{k}_2"] = v
+        bias = None
+        if k1 == k2 and i1 == i2:
+            _fsky, _musq, _dens = md1.get("fsky"), md1.get("musq"), md1.get("dens")
+            if _fsky is not None and _musq is not None and _dens is not None:
+                factor = 0.5 if s1 == s2 == 2 else 1.0
+                bias = factor * _fsky * _musq / _dens
+        if bias is not None:
+            md["bias"] = bias
+        if debias and bias is not None:
+            _debias_cl(cl, bias, md, inplace=True, pixwin=pixwin)
+        update_metadata(cl, **md)
+        res = Result(cl, spin=(s1, s2), axis=-1)
+        if bins is not None:
+            from .core import HAVE_HERACLES
+
+            if not HAVE_HERACLES:
+                raise NotImplementedError("binning needs heracles.result.binned (host post-processing, out of scope)")
+            from heracles.result import binned
+
+            res = binned(res, bins, weights)
+        cls[k1, k2, i1, i2] = res
+    logger.info("computed %d cl(s) in %.3f s", len(cls), time.monotonic() - t0)
+    return cls
+
+
+# ---- mixing matrices -------------------------------------------------------------------
+def _mm_args(cl, l1max, l2max, l3max):
+    # Defaults of the third-party convolvecl functions are not in the reference tree
+    # [UNVERIFIED]; chosen so that the shapes used by tests/test_twopoint.py:412-462 hold:
+    # l3max = len(cl)-1, l1max = l3max, l2max = l1max.
+    cl = np.ascontiguousarray(np.asarray(cl, dtype=np.float64))
+    if cl.ndim != 1:
+        raise ValueError("cl must be one-dimensional")
+    if l3max is None:
+        l3max = cl.shape[0] - 1
+    if l1max is None:
+        l1max = l3max
+    if l2max is None:
+        l2max = l1max
+    return cl, int(l1max), int(l2max), int(l3max)
+
+
+def mixmat(cl, l1max=None, l2max=None, l3max=None, spin=(0, 0)):
+    """Mixing matrix of a mask spectrum for spins (0,0), (0,2) or (2,0); replaces
+    ``convolvecl.mixmat`` as called at heracles/twopoint.py:382-388.  Shape (l1max+1, l2max+1),
+    axis 0 is the output multipole."""
+    cl, l1max, l2max, l3max = _mm_args(cl, l1max, l2max, l3max)
+    s1, s2 = spin
+    out = np.empty((l1max + 1, l2max + 1))
+    _lib.ensure_init()
+    _lib.check(_lib.load().hx_mixmat(_lib.ptr(cl), cl.shape[0], l1max, l2max, l3max, int(s1), int(s2), _lib.ptr(out)))
+    return out
+
+
+def mixmat_eb(cl, l1max=None, l2max=None, l3max=None, spin=(2, 2)):
+    """E/B mixing matrices (EE->EE, EE->BB, EB->EB); replaces ``convolvecl.mixmat_eb``."""
+    cl, l1max, l2max, l3max = _mm_args(cl, l1max, l2max, l3max)
+    if tuple(abs(s) for s in spin) != (2, 2):
+        raise NotImplementedError(f"mixmat_eb for spin {spin} not supported")
+    out = np.empty((3, l1max + 1, l2max + 1))
+    _lib.ensure_init()
+    _lib.check(_lib.load().hx_mixmat_eb(_lib.ptr(cl), cl.shape[0], l1max, l2max, l3max, _lib.ptr(out)))
+    return out
+
+
+class _NoProgress:
+    def update(self, *a):
+        pass
+
+    def task(self, *a):
+        from contextlib import nullcontext
+
+        return nullcontext()
+
+
+def mixing_matrices(fields, cls, *, l1max=None, l2max=None, l3max=None, bins=None, weights=None,
+                    out=None, progress=None):
+    """Mixing matrices for fields from mask spectra: heracles/twopoint.py:316-401."""
+    if out is None:
+        out = TocDict()
+    if progress is None:
+        progress = _NoProgress()
+    masks = {}
+    for key, field in fields.items():
+        if field.mask is not None:
+            masks.setdefault(field.mask, {})[key] = field
+    done = set()
+    current, total = 0, len(cls)
+    for (k1, k2, i1, i2), cl in cls.items():
+        current += 1
+        progress.update(current, total)
+        try:
+            fields1, fields2 = masks[k1], masks[k2]
+        except KeyError:
+            continue
+        for f1, f2 in product(fields1, fields2):
+            if (f1, f2, i1, i2) in done or (f2, f1, i2, i1) in done:
+                continue
+            done.add((f1, f2, i1, i2))
+            with progress.task(f"({f1}, {f2}, {i1}, {i2})"):
+                spin1, spin2 = fields1[f1].spin, fields2[f2].spin
+                fn = mixmat if (spin1 == 0 or spin2 == 0) else mixmat_eb
+                mm = fn(np.asarray(cl), l1max=l1max, l2max=l2max, l3max=l3max, spin=(spin1, spin2))
+                ell = np.arange(mm.shape[-2])
+                mm = Result(mm, spin=(spin1, spin2), ell=ell, axis=-2)
+                if bins is not None:
+                    from .core import HAVE_HERACLES
+
+                    if not HAVE_HERACLES:
+                        raise NotImplementedError("binning needs heracles.result.binned")
+                    from heracles.result import binned
+
+                    mm = binned(mm, bins, weights)
+                out[f1, f2, i1, i2] = mm
+    return out

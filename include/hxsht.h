@@ -1,0 +1,108 @@
+/* hxsht.h -- C ABI of libhxsht.so, the MI355X (gfx950) harmonic-space two-point engine.
+ *
+ * Drop-in boundary for the hot path of heracles-ec/heracles.  The
+ * reference is pure Python and binds no native library itself; each entry point below
+ * replaces the third-party / numpy call the reference makes at the cited file:line, and
+ * INTEGRATION.md shows the ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  Every pointer argument may be a HOST pointer or a
+ *    DEVICE (HBM) pointer; the library detects which (hipPointerGetAttributes) and stages
+ *    host buffers through its own device scratch.  The caller owns all buffers.
+ *  - Complex arrays are interleaved (re, im) doubles == numpy complex128.
+ *  - alm layout: m-major, mmax == lmax, idx(l,m) = m*(2*lmax+1-m)/2 + l
+ *    (heracles/twopoint.py:90-99, heracles/ducc.py:157-161).
+ *  - Maps are HEALPix RING ordered, npix = 12*nside^2 (heracles/healpy.py:124-142).
+ *  - Return value 0 = ok, negative = error; message via hx_last_error() (thread local).
+ *  - Calls are synchronous on return unless hx_set_async(1) was called.
+ *  - There is NO CPU fallback: every compute entry point fails with HX_ERR_NO_DEVICE when
+ *    no gfx950 device is usable.
+ */
+#ifndef HXSHT_H
+#define HXSHT_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HX_OK 0
+#define HX_ERR_ARG (-1)
+#define HX_ERR_NO_DEVICE (-2)
+#define HX_ERR_HIP (-3)
+#define HX_ERR_MEM (-4)
+#define HX_ERR_UNSUPPORTED (-5)
+
+typedef struct hx_plan hx_plan;
+
+/* ---- runtime ------------------------------------------------------------------- */
+const char *hx_version(void);
+const char *hx_last_error(void);
+int hx_device_count(void);
+int hx_init(int device);          /* select device, create the library stream           */
+int hx_set_stream(void *stream);  /* use a caller-owned hipStream_t (NULL = own stream)  */
+void *hx_get_stream(void);
+int hx_set_async(int on);         /* 1: do not synchronise before returning (device ptrs) */
+int hx_synchronize(void);
+
+/* HIP-event timers on the library stream (bench.py's timed region / roofline). */
+int hx_timer_start(void);
+int hx_timer_stop(float *ms);
+/* per-kernel profile: accumulate HIP-event durations of every launch of the named kernel
+ * family ("legendre_analysis", "legendre_synthesis", "ring_fft", "alm2cl", "mixmat_gemm",
+ * "wigner_tables").  hx_profile_get returns launches and total milliseconds. */
+int hx_profile_enable(int on);
+int hx_profile_reset(void);
+int hx_profile_get(const char *name, int *launches, double *total_ms);
+
+/* ---- spherical harmonic transforms --------------------------------------------- */
+/* Replaces healpy.map2alm / alm2map as called at heracles/healpy.py:183-189 and
+ * heracles/io.py:377.  A plan owns ring tables, recursion tables, Bluestein tables and
+ * device scratch for up to max_comp map components per call. */
+hx_plan *hx_plan_create(int nside, int lmax, int max_comp);
+void hx_plan_destroy(hx_plan *plan);
+int64_t hx_plan_scratch_bytes(const hx_plan *plan);
+
+/* maps  : [ncomp][npix] double; spin 2: components come in (Q,U) pairs, ncomp even
+ * alms  : [ncomp][nlm] complex; spin 2: (E,B) pairs
+ * ring_weights : NULL or [2*nside] quadrature weights of ring pairs (north ring 1..2nside)
+ * pix_weights  : NULL or [npix] per-pixel weights (healpy use_pixel_weights=True data)
+ * fl    : NULL or [lmax+1] filter applied to the output, alm[l,m] *= fl[l]
+ *         (pixel-window deconvolution, heracles/healpy.py:172-196)
+ * niter : Jacobi refinement iterations (healpy's `iter`)                              */
+int hx_map2alm(hx_plan *plan, int spin, int ncomp, const double *maps, double *alms,
+               const double *ring_weights, const double *pix_weights, const double *fl,
+               int niter);
+int hx_alm2map(hx_plan *plan, int spin, int ncomp, const double *alms, double *maps);
+
+/* ---- two-point reduction -------------------------------------------------------- */
+/* Replaces heracles.twopoint.alm2cl (heracles/twopoint.py:63-101) for a whole list of
+ * component pairs in one launch.  alms[i] points to component i with lmax_i[i];
+ * cls is [npairs][lmax_out+1]; requires lmax_out <= min over used components.         */
+int hx_alm2cl_pairs(int ncomp, const int *lmax_i, const double *const *alms, int lmax_out,
+                    int npairs, const int *pair_i, const int *pair_j, double *cls);
+
+/* ---- mixing matrices / Wigner-d ------------------------------------------------- */
+/* Gauss-Legendre nodes (ascending) and weights; the `gauss_legendre` hook of
+ * heracles/transforms.py:25-43. */
+int hx_gauss_legendre(int n, double *x, double *w);
+
+/* D[k][l] = d^l_{ab}(x_k), l = 0..lmax, (a,b) in {(0,0),(2,0),(2,2),(2,-2)};
+ * out is [n][lmax+1] row-major.  (Functions of heracles/transforms.py:46-112.)       */
+int hx_wigner_d_table(int lmax, int a, int b, int n, const double *x, double *out);
+
+/* Replaces convolvecl.mixmat / mixmat_eb as called at heracles/twopoint.py:378-388.
+ * cl has ncl entries (mask spectrum, zero-extended to l3max).  out: [l1max+1][l2max+1]
+ * (mixmat) or [3][l1max+1][l2max+1] (mixmat_eb: EE->EE, EE->BB, EB->EB).              */
+int hx_mixmat(const double *cl, int ncl, int l1max, int l2max, int l3max, int s1, int s2,
+              double *out);
+int hx_mixmat_eb(const double *cl, int ncl, int l1max, int l2max, int l3max, double *out);
+
+/* Replaces heracles.transforms._cl2corr / _corr2cl (heracles/transforms.py:115-204) for
+ * nspec spectra at once: cls [nspec][lmax+1][4] <-> corrs [nspec][lmax+1][4].          */
+int hx_cl2corr(int lmax, int nspec, const double *cls, double *corrs);
+int hx_corr2cl(int lmax, int nspec, const double *corrs, double *cls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,140 @@
+"""GPU parity: Gauss-Legendre nodes, Wigner-d tables, mixing matrices and Cl <-> xi
+transforms through the C ABI, against the oracle (3j recursion, pinned by sympy) and the
+reference's golden vectors."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gauss_legendre(oracle):
+    import heracles_amd as hx
+
+    for n in (1, 2, 3, 64, 97, 1000, 4097):
+        x, w = hx.gauss_legendre(n)
+        xo, wo = oracle.gauss_legendre(n)
+        np.testing.assert_allclose(x, xo, atol=3e-16 * 4)
+        np.testing.assert_allclose(w, wo, rtol=2e-12)
+        assert abs(w.sum() - 2) < 1e-12
+
+
+@pytest.mark.parametrize("ab", [(0, 0), (2, 0), (2, 2), (2, -2)])
+def test_wigner_tables(oracle, ab):
+    import heracles_amd as hx
+
+    lmax = 150
+    x = np.array([-0.999, -0.93, -0.2, 0.0, 0.31, 0.9, 0.9985, 0.99995])
+    T = hx.wigner_d_table(lmax, ab[0], ab[1], x)
+    ref = np.array([oracle.wigner_d(lmax, ab[0], ab[1], float(xx)) for xx in x])
+    np.testing.assert_allclose(T, ref, atol=1e-13)
+
+
+@pytest.mark.parametrize("L,spin", [(16, (0, 0)), (16, (0, 2)), (16, (2, 0)), (40, (0, 0)), (40, (2, 0)), (130, (0, 2))])
+def test_mixmat_vs_3j(oracle, L, spin):
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(L)
+    cl = rng.uniform(0.5, 1.5, L + 1) / (1 + np.arange(L + 1)) ** 2
+    out = hx.mixmat(cl, spin=spin)
+    ref = oracle.mixmat(cl, spin=spin)
+    assert out.shape == (L + 1, L + 1)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("L", [16, 40, 130])
+def test_mixmat_eb_vs_3j(oracle, L):
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(L + 1)
+    cl = rng.uniform(0.5, 1.5, L + 1) / (1 + np.arange(L + 1)) ** 2
+    out = hx.mixmat_eb(cl)
+    ref = oracle.mixmat_eb(cl)
+    assert out.shape == (3, L + 1, L + 1)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+    np.testing.assert_allclose(out[2], out[0] - out[1], atol=1e-14)
+
+
+def test_mixmat_shapes_and_identities(oracle):
+    import heracles_amd as hx
+
+    L = 48
+    cl = np.zeros(L + 1)
+    cl[0] = 4 * np.pi
+    np.testing.assert_allclose(hx.mixmat(cl), np.eye(L + 1), atol=1e-13)
+    eb = hx.mixmat_eb(cl)
+    np.testing.assert_allclose(eb[0][2:, 2:], np.eye(L - 1), atol=1e-13)
+    np.testing.assert_allclose(eb[1], 0, atol=1e-13)
+    rng = np.random.default_rng(2)
+    cl = rng.uniform(0.5, 1.5, 31)
+    for kw in ({"l1max": 10, "l2max": 20}, {"l1max": 20, "l2max": 10}, {"l1max": 5, "l2max": 5, "l3max": 12},
+               {"l1max": 150, "l2max": 129}):
+        out = hx.mixmat(cl, spin=(0, 0), **kw)
+        ref = oracle.mixmat(cl, spin=(0, 0), **kw)
+        assert out.shape == ref.shape
+        np.testing.assert_allclose(out, ref, atol=1e-13 * np.abs(ref).max())
+        oe, re_ = hx.mixmat_eb(cl, **kw), oracle.mixmat_eb(cl, **kw)
+        np.testing.assert_allclose(oe, re_, atol=1e-13 * np.abs(re_).max())
+    with pytest.raises(hx.HxError):
+        hx.mixmat(cl, spin=(1, 1))
+
+
+def test_mixmat_large_properties():
+    """L = 1024: row-sum rule and E/B relations (oracle-free, size-independent)."""
+    import heracles_amd as hx
+
+    L = 1024
+    ell = np.arange(L + 1)
+    cl = 4 * np.pi * 0.3 * np.exp(-ell * (ell + 1) / 5000.0) + 1e-3 / (1 + ell) ** 2
+    M = hx.mixmat(cl, l1max=64, l2max=2 * L + 64, l3max=L)
+    target = ((2 * ell + 1) * cl).sum() / (4 * np.pi)
+    np.testing.assert_allclose(M.sum(axis=1), target, rtol=1e-10)
+    eb = hx.mixmat_eb(cl, l1max=256, l2max=256)
+    np.testing.assert_allclose(eb[2], eb[0] - eb[1], atol=1e-12)
+    M00 = hx.mixmat(cl, l1max=256, l2max=256)
+    # detailed balance: M_{l1 l2} (2 l1 + 1) symmetric
+    S = M00 * (2 * np.arange(257) + 1)[:, None]
+    np.testing.assert_allclose(S, S.T, atol=1e-11 * np.abs(S).max())
+
+
+@pytest.mark.parametrize("lm", [12, 40, 97])
+def test_cl2corr_corr2cl_golden(golden, lm):
+    import heracles_amd as hx
+    from heracles_amd import transforms as tr
+
+    cls = golden[f"c2c/{lm}/cls"]
+    np.testing.assert_allclose(tr._cl2corr(cls), golden[f"c2c/{lm}/corr"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(tr._corr2cl(golden[f"c2c/{lm}/corr"]), golden[f"c2c/{lm}/cls_back"], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(tr._cl2corr(cls[:, 0]), golden[f"c2c/{lm}/corr1d"], rtol=1e-9, atol=1e-12)
+    # round trip (tests/test_transforms.py:5-13 of the reference)
+    back = tr._corr2cl(tr._cl2corr(cls))
+    np.testing.assert_allclose(back[2:], cls[2:], rtol=1e-6, atol=1e-9)
+    assert hx.gauss_legendre(lm + 1)[0].shape == (lm + 1,)
+
+
+def test_dict_transforms_and_naturalspice_golden(golden):
+    import types
+
+    import heracles_amd as hx
+    from heracles_amd.core import Result
+    from helpers import key_str
+
+    L = 24
+    ell = np.arange(L + 1)
+    keys = {("POS", "POS", 0, 0): (0, 0), ("POS", "SHE", 0, 0): (0, 2), ("SHE", "SHE", 0, 0): (2, 2)}
+    d = {k: Result(np.array(golden[f"dict/d/{key_str(k)}"]), spin=s, axis=-1, ell=ell) for k, s in keys.items()}
+    wd = hx.cl2corr(d)
+    back = hx.corr2cl(wd)
+    for k in d:
+        np.testing.assert_allclose(wd[k].array, golden[f"dict/wd/{key_str(k)}"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(back[k].array, golden[f"dict/back/{key_str(k)}"], rtol=1e-8, atol=1e-12)
+    Lm = 2 * L
+    ellm = np.arange(Lm + 1)
+    fields = {"POS": types.SimpleNamespace(mask="VIS", spin=0), "SHE": types.SimpleNamespace(mask="WHT", spin=2)}
+    for tag, tm in (("default", None), ("theta30", 30.0)):
+        m = {k: Result(np.array(golden[f"ns/m/{key_str(k)}"]), spin=(0, 0), axis=-1, ell=ellm)
+             for k in (("VIS", "VIS", 0, 0), ("VIS", "WHT", 0, 0), ("WHT", "WHT", 0, 0))}
+        res = hx.naturalspice(d, m, fields, theta_max=tm)
+        for k in d:
+            ref = golden[f"ns/{tag}/{key_str(k)}"]
+            np.testing.assert_allclose(res[k].array, ref, rtol=1e-6, atol=1e-9 * np.abs(ref).max())

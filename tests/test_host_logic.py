@@ -1,0 +1,232 @@
+"""Host-side logic of heracles_amd that needs no GPU: key handling, metadata, bias rule,
+mask -> field fan-out.  Arithmetic kernels are replaced by the oracle (as a checker stub)
+so the Python drivers can be compared with the reference's golden outputs on CPU."""
+
+import types
+
+import numpy as np
+import pytest
+
+import heracles_amd
+from heracles_amd import twopoint as tp
+from helpers import key_str
+
+NAMES = [("POS", 0), ("POS", 1), ("SHE", 0), ("SHE", 1)]
+
+
+@pytest.fixture
+def cpu_kernels(monkeypatch, oracle):
+    """Stub the HIP entry points with the oracle so driver logic runs without a GPU."""
+
+    def pairs(comps, plist, lmax_out):
+        out = np.zeros((len(plist), lmax_out + 1))
+        for n, (i, j) in enumerate(plist):
+            out[n] = oracle.alm2cl(np.asarray(comps[i]), np.asarray(comps[j]), lmax=lmax_out)
+        return out
+
+    monkeypatch.setattr(tp, "alm2cl_pairs", pairs)
+    return oracle
+
+
+def golden_alms(golden, with_bias=True):
+    alms = {}
+    for n, i in NAMES:
+        a = np.array(golden[f"alm/{key_str((n, i))}"])
+        md = {"nside": 32, "spin": 0 if n == "POS" else 2}
+        if with_bias and i == 0:
+            md.update(fsky=0.5, musq=1.2, dens=3.4)
+        md.update(geometry="plain", kernel="plain")
+        a.dtype = np.dtype(a.dtype, metadata=md)
+        alms[n, i] = a
+    return alms
+
+
+def test_alm2lmax(golden):
+    for n, v in zip(golden["alm2lmax_sizes"], golden["alm2lmax_values"]):
+        assert tp.alm2lmax(np.zeros(int(n))) == v
+
+
+def test_alm2cl_driver_shapes(cpu_kernels, golden):
+    from itertools import combinations_with_replacement
+
+    for k1, k2 in combinations_with_replacement(NAMES, 2):
+        a, b = golden[f"alm/{key_str(k1)}"], golden[f"alm/{key_str(k2)}"]
+        ref = golden[f"alm2cl/{key_str(k1)}/{key_str(k2)}"]
+        out = tp.alm2cl(a, b)
+        assert out.shape == ref.shape
+        np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-14)
+    out = tp.alm2cl(golden["uneq/a1"], golden["uneq/a2"], lmax=20)
+    np.testing.assert_allclose(out, golden["uneq/cl_lmax20"], rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("plain", {}), ("nodebias", {"debias": False}), ("lmax16", {"lmax": 16}),
+    ("incl", {"include": [("POS", "SHE", ..., ...)]}), ("excl", {"exclude": [("SHE", "SHE")]}),
+])
+def test_angular_power_spectra_vs_reference(cpu_kernels, golden, tag, kw):
+    cls = tp.angular_power_spectra(golden_alms(golden), **kw)
+    assert [key_str(k) for k in cls] == list(golden[f"aps/{tag}/keys"])  # order included
+    for k, v in cls.items():
+        np.testing.assert_allclose(np.asarray(v.array), golden[f"aps/{tag}/cl/{key_str(k)}"], rtol=1e-12, atol=1e-14)
+        md = v.array.dtype.metadata or {}
+        assert sorted(f"{a}={md[a]!r}" for a in md) == list(golden[f"aps/{tag}/md/{key_str(k)}"])
+        assert v.axis == (v.ndim - 1,)
+        assert v.spin == (md["spin_1"], md["spin_2"])
+
+
+def test_angular_power_spectra_cross_and_reversed(cpu_kernels, golden):
+    alms = golden_alms(golden)
+    a1 = {k: v for k, v in alms.items() if k[1] == 0}
+    a2 = {k: v for k, v in alms.items() if k[1] == 1}
+    cls = tp.angular_power_spectra(a1, a2)
+    assert [key_str(k) for k in cls] == list(golden["aps/cross/keys"])
+    for k, v in cls.items():
+        np.testing.assert_allclose(np.asarray(v.array), golden[f"aps/cross/cl/{key_str(k)}"], rtol=1e-12, atol=1e-14)
+    rev = dict(reversed(list(alms.items())))
+    cls = tp.angular_power_spectra(rev)
+    assert [key_str(k) for k in cls] == list(golden["aps/rev/keys"])
+    for k, v in cls.items():
+        np.testing.assert_allclose(np.asarray(v.array), golden[f"aps/rev/cl/{key_str(k)}"], rtol=1e-12, atol=1e-14)
+
+
+def test_angular_power_spectra_bias_rule(cpu_kernels):
+    # restates tests/test_twopoint.py:154-193 of the reference
+    lmax = 32
+    size = (lmax + 1) * (lmax + 2) // 2
+    fsky, musq, dens = 0.5, 1.2, 3.4
+    a = np.zeros(size, dtype=complex)
+    a.dtype = np.dtype(a.dtype, metadata={"spin": 0, "fsky": fsky, "musq": musq, "dens": dens})
+    cls = tp.angular_power_spectra({("F", 0): a}, debias=False)
+    assert cls["F", "F", 0, 0].dtype.metadata["bias"] == pytest.approx(fsky * musq / dens)
+    b = np.zeros((2, size), dtype=complex)
+    b.dtype = np.dtype(b.dtype, metadata={"spin": 2, "fsky": fsky, "musq": musq, "dens": dens})
+    cls2 = tp.angular_power_spectra({("G", 0): b}, debias=False)
+    assert cls2["G", "G", 0, 0].dtype.metadata["bias"] == pytest.approx(0.5 * fsky * musq / dens)
+    cross = tp.angular_power_spectra({("F", 0): a, ("F", 1): a.copy()}, debias=False)
+    assert "bias" not in (cross["F", "F", 0, 1].dtype.metadata or {})
+    c = np.zeros(size, dtype=complex)
+    c.dtype = np.dtype(c.dtype, metadata={"spin": 0})
+    ext = tp.angular_power_spectra({("F", 0): c}, debias=False)
+    assert "bias" not in (ext["F", "F", 0, 0].dtype.metadata or {})
+    d = np.zeros(size, dtype=complex)
+    with pytest.raises(ValueError, match="missing spin metadata"):
+        tp.angular_power_spectra({("F", 0): d})
+
+
+def test_debias_cl_vs_reference(golden):
+    cases = {"a": (1.23, {}), "c": (None, {"bias": 4.56, "spin_2": 2}),
+             "d": (7.89, {"spin_1": 2, "spin_2": 2}), "e": (7.89, {"spin_1": 0, "spin_2": 0})}
+    for k, (bias, md) in cases.items():
+        arr = np.array(golden[f"debias/{k}/in"])
+        arr.dtype = np.dtype(arr.dtype, metadata=md)
+        out = tp._debias_cl(arr, bias)
+        np.testing.assert_array_equal(out, golden[f"debias/{k}/out"])
+        assert out is not arr
+
+
+def test_debias_healpix_pixwin_rule():
+    # restates tests/test_twopoint.py:243-290 with an explicit pixel window table
+    lmax = 99
+    pw0 = 1.0 / (1.0 + 1e-4 * np.arange(lmax + 1) ** 2)
+    pw2 = 1.0 / (1.0 + 2e-4 * np.arange(lmax + 1) ** 2)
+    md1 = {"kernel_1": "healpix", "nside_1": 64, "kernel_2": "healpix", "nside_2": 64, "spin_2": 2}
+    md2 = {"kernel_1": "healpix", "nside_1": 64, "spin_2": 2}
+    md3 = dict(md1, deconv_2=False)
+    cls = {i: np.zeros((2, 100), dtype=np.dtype(float, metadata=md)) for i, md in ((1, md1), (2, md2), (3, md3))}
+    tp.debias_cls(cls, {1: 1.23, 2: 4.56, 3: 7.89}, inplace=True, pixwin=(pw0, pw2))
+    np.testing.assert_array_equal(cls[1][:, :2], 0.0)
+    np.testing.assert_array_equal(cls[1][0, 2:], -1.23 / pw0[2:] / pw2[2:])
+    np.testing.assert_array_equal(cls[2][1, 2:], -4.56 / pw0[2:])
+    np.testing.assert_array_equal(cls[3][0, 2:], -7.89 / pw0[2:])
+
+
+def test_mixing_matrices_driver_vs_reference(monkeypatch, golden):
+    calls = []
+
+    def fake(name):
+        def f(cl, l1max=None, l2max=None, l3max=None, spin=None):
+            calls.append((name, tuple(spin), l1max, l2max, l3max))
+            n = len(cl)
+            return np.zeros((n, n)) if name == "mixmat" else np.zeros((3, n, n))
+
+        return f
+
+    monkeypatch.setattr(tp, "mixmat", fake("mixmat"))
+    monkeypatch.setattr(tp, "mixmat_eb", fake("mixmat_eb"))
+    cl = np.arange(21.0)
+    mm_cls = {("VIS", "VIS", 0, 1): cl, ("VIS", "WHT", 0, 1): cl, ("WHT", "VIS", 0, 1): cl,
+              ("WHT", "WHT", 0, 1): cl, ("X", "Y", 0, 1): cl, ("WHT", "WHT", 1, 1): cl}
+    flds = {"POS": types.SimpleNamespace(mask="VIS", spin=0), "SHE": types.SimpleNamespace(mask="WHT", spin=2),
+            "POS2": types.SimpleNamespace(mask="VIS", spin=0), "NOMASK": types.SimpleNamespace(mask=None, spin=0)}
+    mms = tp.mixing_matrices(flds, mm_cls, l1max=10, l2max=12, l3max=20)
+    assert [key_str(k) for k in mms] == list(golden["mm/keys"])
+    assert [repr(c) for c in calls] == list(golden["mm/calls"])
+    assert [repr(v.axis) for v in mms.values()] == list(golden["mm/axis"])
+
+
+def test_core_helpers():
+    from heracles_amd.core import Result, TocDict, toc_match, update_metadata
+
+    a = np.zeros(4)
+    update_metadata(a, x=1)
+    update_metadata(a, y=2)
+    assert a.dtype.metadata == {"x": 1, "y": 2}
+    assert toc_match(("a", "b", 0, 1), include=[("a", ..., 0)])
+    assert not toc_match(("a", "b", 0, 1), exclude=[(..., "b")])
+    d = TocDict({("a", "b", 0, 1): 1, ("a", "c", 0, 1): 2, ("x", "b", 1, 1): 3})
+    assert d["a"] == {("a", "b", 0, 1): 1, ("a", "c", 0, 1): 2}
+    assert d[..., "b"] == {("a", "b", 0, 1): 1, ("x", "b", 1, 1): 3}
+    with pytest.raises(KeyError):
+        d["zzz"]
+    r = Result(np.zeros((2, 5)), spin=(0, 2), axis=-1)
+    assert r.axis == (1,) and r.shape == (2, 5)
+    assert Result(np.zeros((3, 4, 5)), axis=-2).axis == (1,)
+
+
+def test_mapper_interface_and_metadata():
+    from heracles_amd import HipHealpixMapper
+
+    nside, lmax = 8, 12
+    mapper = HipHealpixMapper(nside, lmax, deconvolve=False)
+    assert mapper.nside == nside and mapper.lmax == lmax and mapper.deconvolve is False
+    assert HipHealpixMapper(16).lmax == 24 and HipHealpixMapper(16).deconvolve is True
+    assert mapper.area == pytest.approx(4 * np.pi / (12 * nside**2))
+    for attr in ("area", "create", "map_values", "transform", "resample"):
+        assert hasattr(mapper, attr)
+    m = mapper.create(1, 2, 3, spin=-3)
+    assert m.shape == (1, 2, 3, 12 * nside**2)
+    assert m.dtype.metadata == {"geometry": "healpix", "kernel": "healpix", "nside": nside,
+                                "lmax": lmax, "deconv": False, "spin": -3}
+    with pytest.raises(NotImplementedError, match="spin-1 maps not yet supported"):
+        mapper.transform(mapper.create(), spin=1)
+
+
+def test_ang2pix_and_map_values(oracle):
+    from heracles_amd import HipHealpixMapper
+    from heracles_amd.mapper import ang2pix_ring
+
+    for nside in (1, 2, 4, 16, 32):
+        theta, phi = oracle.pix2ang(nside)
+        ipix = ang2pix_ring(nside, np.degrees(phi), 90.0 - np.degrees(theta))
+        np.testing.assert_array_equal(ipix, np.arange(12 * nside**2))
+    rng = np.random.default_rng(7)
+    nside = 16
+    lon = rng.uniform(-360, 720, 5000)
+    lat = np.degrees(np.arcsin(rng.uniform(-1, 1, 5000)))
+    ipix = ang2pix_ring(nside, lon, lat)
+    assert ipix.min() >= 0 and ipix.max() < 12 * nside**2
+    # every point is nearer to its own pixel centre than to any ring-neighbour centre
+    theta, phi = oracle.pix2ang(nside)
+    vec = np.stack([np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)], 1)
+    t, p = np.radians(90 - lat), np.radians(lon)
+    v = np.stack([np.sin(t) * np.cos(p), np.sin(t) * np.sin(p), np.cos(t)], 1)
+    d_own = np.arccos(np.clip((v * vec[ipix]).sum(1), -1, 1))
+    assert d_own.max() < 1.5 * np.sqrt(4 * np.pi / (12 * nside**2))
+    mapper = HipHealpixMapper(nside, deconvolve=False)
+    x, y = rng.standard_normal(5000), rng.standard_normal(5000)
+    m = mapper.create(2)
+    mapper.map_values(lon, lat, m, np.stack([x, y]))
+    exp = np.zeros((2, 12 * nside**2))
+    np.add.at(exp[0], ipix, x)
+    np.add.at(exp[1], ipix, y)
+    np.testing.assert_array_equal(m, exp)
