@@ -22,6 +22,26 @@
 
 typedef double _Complex cplx;
 
+/* cpu_baseline sampling: only every g_mstride-th m is processed in the Legendre stage
+ * (outputs of the skipped m stay zero).  1 = full transform (the default, used by tests). */
+static int g_mstride = 1;
+void hxo_set_mstride(int s) { g_mstride = s > 0 ? s : 1; }
+/* wall-clock seconds of the last hxo_map2alm call, split by stage (bench sampling) */
+static double g_t_fourier = 0.0, g_t_legendre = 0.0;
+void hxo_last_timings(double *t_fourier, double *t_legendre)
+{
+    *t_fourier = g_t_fourier;
+    *t_legendre = g_t_legendre;
+}
+static double wall(void)
+{
+#ifdef _OPENMP
+    return omp_get_wtime();
+#else
+    return 0.0;
+#endif
+}
+
 int hxo_num_threads(void)
 {
 #ifdef _OPENMP
@@ -298,6 +318,29 @@ static void ring_synthesise(const cplx *F, int nphi, int shifted, int mmax, int 
 /* ------------------------------------------------------------------------------------
  * Legendre stage.  F layout: F[(c*nrings + r)*(mmax+1) + m]
  * ---------------------------------------------------------------------------------- */
+/* lambda_mm seeds for all (m, north ring), built incrementally in m: O(1) per entry */
+typedef struct { double *v; int *e; } seedtab;
+
+static seedtab make_seeds0(const geom *g, int mmax)
+{
+    int nrp = 2 * g->nside;
+    seedtab t;
+    t.v = malloc(sizeof(double) * (size_t)(mmax + 1) * nrp);
+    t.e = malloc(sizeof(int) * (size_t)(mmax + 1) * nrp);
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < nrp; ++r) {
+        sval s = { sqrt(1.0 / (4.0 * M_PI)), 0 };
+        t.v[r] = s.v; t.e[r] = s.e;
+        for (int m = 1; m <= mmax; ++m) {
+            s.v *= -g->sth[r] * sqrt((2.0 * m + 1.0) / (2.0 * m));
+            snorm(&s);
+            t.v[(size_t)m * nrp + r] = s.v; t.e[(size_t)m * nrp + r] = s.e;
+        }
+    }
+    return t;
+}
+static void free_seeds(seedtab *t) { free(t->v); free(t->e); }
+
 static void legendre_analysis(const geom *g, int lmax, int spin, int ncomp,
                               const cplx *F, const double *rw, cplx *alm, int add)
 {
@@ -305,12 +348,16 @@ static void legendre_analysis(const geom *g, int lmax, int spin, int ncomp,
     int64_t nlm = hxo_nlm(lmax);
     double wpix = 4.0 * M_PI / (12.0 * (double)nside * nside);
     if (!add) memset(alm, 0, sizeof(cplx) * nlm * ncomp);
+    seedtab sd = {0, 0};
+    if (spin == 0) sd = make_seeds0(g, mmax);
 #pragma omp parallel
     {
         cplx *acc = malloc(sizeof(cplx) * (lmax + 1) * ncomp);
         double *ca = malloc(sizeof(double) * (lmax + 2) * 6);
+        cplx *fe = malloc(sizeof(cplx) * ncomp * 2), *fo = malloc(sizeof(cplx) * ncomp * 2);
 #pragma omp for schedule(dynamic, 1)
-        for (int m = 0; m <= mmax; ++m) {
+        for (int mi = 0; mi <= mmax / g_mstride; ++mi) {
+            int m = mi * g_mstride;
             int l0 = spin == 0 ? m : (m > 2 ? m : 2);
             memset(acc, 0, sizeof(cplx) * (lmax + 1) * ncomp);
             if (l0 > lmax) continue;
@@ -329,24 +376,23 @@ static void legendre_analysis(const geom *g, int lmax, int spin, int ncomp,
                 int has_s = rs != r;
                 double x = g->z[r], w = wpix * (rw ? rw[r] : 1.0);
                 if (spin == 0) {
-                    sval s;
-                    lam0_seed(m, g->sth[r], &s);
-                    double vp = 0.0, vc = s.v;
-                    int e = s.e;
+                    double vp = 0.0, vc = sd.v[(size_t)m * 2 * nside + r];
+                    int e = sd.e[(size_t)m * 2 * nside + r];
+                    for (int c = 0; c < ncomp; ++c) {
+                        cplx fn = F[((int64_t)c * nr + r) * (mmax + 1) + m];
+                        cplx fs = has_s ? F[((int64_t)c * nr + rs) * (mmax + 1) + m] : 0.0;
+                        fe[c] = w * (fn + fs); fo[c] = w * (fn - fs);
+                    }
                     for (int l = m; l <= lmax; ++l) {
                         if (l > m) {
                             double vn = ca[l] * (x * vc - (l - 1 > m ? vp / ca[l - 1] : 0.0));
                             vp = vc; vc = vn;
-                            if (fabs(vc) > TWO_P) { vc *= TWO_M; vp *= TWO_M; e += SC; }
+                            if (e != 0 && fabs(vc) > TWO_P) { vc *= TWO_M; vp *= TWO_M; e += SC; }
                         }
-                        double lam = sget(vc, e) * w;
+                        double lam = e == 0 ? vc : sget(vc, e);
                         if (lam == 0.0) continue;
-                        double par = ((l + m) & 1) ? -1.0 : 1.0;
-                        for (int c = 0; c < ncomp; ++c) {
-                            cplx fn = F[((int64_t)c * nr + r) * (mmax + 1) + m];
-                            cplx fs = has_s ? F[((int64_t)c * nr + rs) * (mmax + 1) + m] : 0.0;
-                            acc[c * (lmax + 1) + l] += lam * (fn + par * fs);
-                        }
+                        const cplx *ff = ((l + m) & 1) ? fo : fe;
+                        for (int c = 0; c < ncomp; ++c) acc[c * (lmax + 1) + l] += lam * ff[c];
                     }
                 } else {
                     sval sp, sm;
@@ -354,33 +400,37 @@ static void legendre_analysis(const geom *g, int lmax, int spin, int ncomp,
                     /* bring both to a common exponent */
                     double pp = 0.0, pc = sp.v, mp = 0.0, mc = sm.v;
                     int ep = sp.e, em = sm.e;
+                    /* F1_S = par F1_N, F2_S = -par F2_N: per parity, the operands multiplying
+                     * F1 and F2 for E ([c]) and B ([c+1]); fe = even (par=+1), fo = odd */
+                    for (int c = 0; c < ncomp; c += 2) {
+                        cplx qn = F[((int64_t)c * nr + r) * (mmax + 1) + m];
+                        cplx un = F[((int64_t)(c + 1) * nr + r) * (mmax + 1) + m];
+                        cplx qs = 0.0, us = 0.0;
+                        if (has_s) {
+                            qs = F[((int64_t)c * nr + rs) * (mmax + 1) + m];
+                            us = F[((int64_t)(c + 1) * nr + rs) * (mmax + 1) + m];
+                        }
+                        /* E += -(f1 q1 + i f2 u2), B += -(f1 u1 - i f2 q2) */
+                        fe[c] = -w * (qn + qs);           fe[ncomp + c] = -w * I * (un - us);
+                        fe[c + 1] = -w * (un + us);       fe[ncomp + c + 1] = w * I * (qn - qs);
+                        fo[c] = -w * (qn - qs);           fo[ncomp + c] = -w * I * (un + us);
+                        fo[c + 1] = -w * (un - us);       fo[ncomp + c + 1] = w * I * (qn + qs);
+                    }
                     for (int l = l0; l <= lmax; ++l) {
                         if (l > l0) {
                             const double *k = &ca[6 * (l - 1)];
                             double pn = (k[0] * x + k[1]) * pc - k[2] * pp;
                             double mn = (k[3] * x + k[4]) * mc - k[5] * mp;
                             pp = pc; pc = pn; mp = mc; mc = mn;
-                            if (fabs(pc) > TWO_P) { pc *= TWO_M; pp *= TWO_M; ep += SC; }
-                            if (fabs(mc) > TWO_P) { mc *= TWO_M; mp *= TWO_M; em += SC; }
+                            if (ep != 0 && fabs(pc) > TWO_P) { pc *= TWO_M; pp *= TWO_M; ep += SC; }
+                            if (em != 0 && fabs(mc) > TWO_P) { mc *= TWO_M; mp *= TWO_M; em += SC; }
                         }
                         double lp2 = sget(pc, ep), lm2 = sget(mc, em);
                         if (lp2 == 0.0 && lm2 == 0.0) continue;
-                        double f1 = 0.5 * (lp2 + lm2) * w, f2 = 0.5 * (lp2 - lm2) * w;
-                        double par = ((l + m) & 1) ? -1.0 : 1.0;
-                        for (int c = 0; c < ncomp; c += 2) {
-                            cplx qn = F[((int64_t)c * nr + r) * (mmax + 1) + m];
-                            cplx un = F[((int64_t)(c + 1) * nr + r) * (mmax + 1) + m];
-                            cplx qs = 0.0, us = 0.0;
-                            if (has_s) {
-                                qs = F[((int64_t)c * nr + rs) * (mmax + 1) + m];
-                                us = F[((int64_t)(c + 1) * nr + rs) * (mmax + 1) + m];
-                            }
-                            /* F1_S = par F1_N, F2_S = -par F2_N */
-                            cplx q1 = qn + par * qs, q2 = qn - par * qs;
-                            cplx u1 = un + par * us, u2 = un - par * us;
-                            acc[c * (lmax + 1) + l] += -(f1 * q1 + I * f2 * u2);
-                            acc[(c + 1) * (lmax + 1) + l] += -(f1 * u1 - I * f2 * q2);
-                        }
+                        double f1 = 0.5 * (lp2 + lm2), f2 = 0.5 * (lp2 - lm2);
+                        const cplx *ff = ((l + m) & 1) ? fo : fe;
+                        for (int c = 0; c < ncomp; ++c)
+                            acc[c * (lmax + 1) + l] += f1 * ff[c] + f2 * ff[ncomp + c];
                     }
                 }
             }
@@ -388,8 +438,9 @@ static void legendre_analysis(const geom *g, int lmax, int spin, int ncomp,
                 for (int l = l0; l <= lmax; ++l)
                     alm[c * nlm + almidx(lmax, l, m)] += acc[c * (lmax + 1) + l];
         }
-        free(acc); free(ca);
+        free(acc); free(ca); free(fe); free(fo);
     }
+    if (spin == 0) free_seeds(&sd);
 }
 
 static void legendre_synthesis(const geom *g, int lmax, int spin, int ncomp,
@@ -534,8 +585,12 @@ int hxo_map2alm(int nside, int lmax, int spin, int ncomp, const double *maps, cp
     int64_t npix = 12 * (int64_t)nside * nside;
     cplx *F = malloc(sizeof(cplx) * (size_t)ncomp * g.nrings * (lmax + 1));
     if (!F) { free_geom(&g); return -2; }
+    double t0 = wall();
     fourier_analysis(&g, lmax, ncomp, maps, pix_weights, use_fft, F);
+    double t1 = wall();
     legendre_analysis(&g, lmax, spin, ncomp, F, ring_weights, alms, 0);
+    g_t_fourier = t1 - t0;
+    g_t_legendre = wall() - t1;
     if (niter > 0) {
         double *res = malloc(sizeof(double) * npix * ncomp);
         for (int it = 0; it < niter; ++it) {

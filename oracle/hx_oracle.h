@@ -75,6 +75,10 @@ void hxo_mixmat(const double *cl, int l1max, int l2max, int l3max, int s1, int s
 void hxo_mixmat_eb(const double *cl, int l1max, int l2max, int l3max, double *out);
 
 int hxo_num_threads(void);
+/* bench sampling: process only every s-th m in the Legendre stage of map2alm (default 1) */
+void hxo_set_mstride(int s);
+/* stage timings (seconds) of the last hxo_map2alm call (niter = 0 part) */
+void hxo_last_timings(double *t_fourier, double *t_legendre);
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,17 @@ def num_threads() -> int:
     return lib().hxo_num_threads()
 
 
+def set_mstride(s: int):
+    """bench sampling knob: Legendre stage of map2alm processes only every s-th m."""
+    lib().hxo_set_mstride(C.c_int(int(s)))
+
+
+def last_timings():
+    a, b = C.c_double(), C.c_double()
+    lib().hxo_last_timings(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
 def ring_info(nside: int, ring: int):
     sp = C.c_int64()
     nphi = C.c_int()
