@@ -172,7 +172,7 @@ def main():
     flops_step = nbins * F0 + nbins * 3 * F0
     nl, ms = hx._lib.profile_get("legendre_analysis")
     prof = {}
-    for k in ("ring_fft", "fourier_combine", "legendre_analysis", "alm_reduce", "alm2cl"):
+    for k in ("ring_fft", "fourier_combine", "legendre_analysis", "legendre_analysis_s0", "legendre_analysis_s2", "alm_reduce", "alm2cl"):
         n_, ms_ = hx._lib.profile_get(k)
         prof[k] = {"launches": n_, "ms_per_step": ms_ / max(args.steps, 1)}
     achieved = flops_step * args.steps / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

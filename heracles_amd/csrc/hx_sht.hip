@@ -19,6 +19,7 @@
 //   4. k_alm_reduce        fixed-order sum of the ring-group partials -> alm (x fl).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "hx_common.h"
 #include "hx_fft_core.h"
@@ -29,7 +30,7 @@ using namespace hxfft;
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int LA_WAVES = 8;       // waves (64-ring-pair blocks) per Legendre workgroup
-constexpr int TILE_LD = 66;       // LDS row stride (doubles) of a 16 x 64 lambda tile
+constexpr int TILE_LD = 64;       // LDS row stride (doubles) of a 16 x 64 lambda tile (XOR-swizzled columns)
 constexpr int LBLK = 32;          // l values per block (16 even-parity + 16 odd-parity rows)
 constexpr int NCOL = 16;          // MFMA N: real columns per batch (8 spin-0 maps / 4 spin-2 fields)
 constexpr double SC_BIG = 0x1p+300, SC_SMALL = 0x1p-300;
@@ -66,7 +67,7 @@ struct hx_plan {
     int nrp = 0, nrp_pad = 0, nrb = 0, twN = 1;
     long long npix = 0, ny = 0, nlm = 0;
     size_t lds_fft = 0;
-    hx::DevBuf z, omz, sth, rwdef, nsub, shifted, startN, startS, bhat_off, tw, bhat, mfac, kfac2, rec0, rec2;
+    hx::DevBuf z, omz, sth, rwdef, nsub, shifted, startN, startS, bhat_off, tw, bhat, mfac, kfac2, rec0, rec0b, rec2;
     std::vector<double> h_sth, h_z;
     std::vector<int> h_nsub;
     struct TaskSet {
@@ -105,6 +106,28 @@ __global__ void k_init_rec0(int lmax, double2 *__restrict__ rec)
                 b = a / ap;
             }
             r = make_double2(a, b);
+        }
+        rec[almidx(lmax, l, m)] = r;
+    }
+}
+
+// Two-step spin-0 table: recb[idx(l,m)] = (A, B, C, 0) with
+//   lambda_{l+2} = (A x^2 + B) lambda_l - C lambda_{l-2},   a_l = sqrt((4l^2-1)/(l^2-m^2)),
+//   A = a_{l+1} a_{l+2},  B = -(a_{l+2}/a_{l+1} + a_{l+2} a_{l+1}/a_l^2),  C = a_{l+2} a_{l+1}/(a_l a_{l-1})
+// (terms with a_m = infinity vanish).
+__global__ void k_init_rec0b(int lmax, double4 *__restrict__ rec)
+{
+    const int m = blockIdx.x;
+    const double dm = m;
+    auto a = [dm](double l) { return sqrt((4.0 * l * l - 1.0) / (l * l - dm * dm)); };
+    for (int l = m + threadIdx.x; l <= lmax; l += blockDim.x) {
+        const double dl = l;
+        const double a1 = a(dl + 1.0), a2 = a(dl + 2.0);
+        double4 r = make_double4(a1 * a2, -a2 / a1, 0.0, 0.0);
+        if (l > m) {
+            const double a0 = a(dl);
+            r.y -= a2 * a1 / (a0 * a0);
+            if (l > m + 1) r.z = a2 * a1 / (a0 * a(dl - 1.0));
         }
         rec[almidx(lmax, l, m)] = r;
     }
@@ -367,16 +390,31 @@ __device__ inline double sval_true(double v, int e)
 
 struct LegParams {
     PlanDev P;
-    const LegTask *tasks;
-    const double *F;
-    double *partial;
+    const LegTask *__restrict__ tasks;
+    const double *__restrict__ F;
+    const double2 *__restrict__ rec0;
+    const double4 *__restrict__ rec2;
+    double *__restrict__ partial;
+    int ablate;  // diagnostic only (HX_ABLATE): 1 skip MFMA, 2 skip recursion, 4 skip flush, 8 count paths
+    unsigned long long *counters;  // [dead, live, mixed, wave_off] block counts when ablate & 8
 };
 
+// broadcast lane `src` of a wave-distributed double to all lanes (-> SGPR pair)
+__device__ inline double bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 template <int SPIN>
-__global__ __launch_bounds__(LA_WAVES * 64) void k_legendre_analysis(LegParams A)
+__global__ __launch_bounds__(LA_WAVES * 64) void k_legendre_analysis(LegParams A,
+                                                                   const double4 *__restrict__ rec2)
 {
     constexpr int NOP = SPIN == 0 ? 1 : 2;
-    __shared__ double tiles[LA_WAVES][2][16][TILE_LD];
+    __shared__ double tiles[LA_WAVES][2][16][TILE_LD];  // 128 KiB; after the MFMA phase the first
+                                                        // 4 KiB of each wave's tiles carry its D tiles
+    __shared__ double4 coefs[2][LBLK];                  // recursion coefficients of this / the next block
     const PlanDev &P = A.P;
     const LegTask task = A.tasks[blockIdx.x];
     const int m = task.m, lmax = P.lmax;
@@ -396,7 +434,7 @@ __global__ __launch_bounds__(LA_WAVES * 64) void k_legendre_analysis(LegParams A
         const int j = lane & 15, k = lane >> 4;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const long long row = (long long)m * P.nrp_pad + rb * 64 + 4 * q + k;
+            const long long row = (long long)m * P.nrp_pad + rb * 64 + q + 16 * k;
 #pragma unroll
             for (int par = 0; par < 2; ++par)
 #pragma unroll
@@ -440,103 +478,163 @@ __global__ __launch_bounds__(LA_WAVES * 64) void k_legendre_analysis(LegParams A
     }
 
     double *mytile = &tiles[w][0][0][0];
+    double *myflush = mytile;
     const int ai = lane & 15, ak = lane >> 4;
+    // tile element (row r of parity tile p, ring c) lives at ((p*16 + r)*64 + (c ^ r));
+    // MFMA q contracts the rings {q, q+16, q+32, q+48} of this wave (k = lane>>4).
+    auto mfma_block = [&](int op, double4_t (&acc)[2]) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // tile is private to the wave:
+        __builtin_amdgcn_wave_barrier();                        // order LDS writes before reads
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (A.ablate & 1) return;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const double a = mytile[(par * 16 + ai) * TILE_LD + ((q + 16 * ak) ^ ai)];
+                acc[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[op][par][q], acc[par], 0, 0, 0);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto scale_of = [](int e) { return e == 0 ? 1.0 : (e == -1 ? SC_SMALL : 0.0); };
 
-    for (int lb = l0; lb <= lmax; lb += LBLK) {
+    // spin 0: the two-step recursion lambda_{l+2} = (A x^2 + B) lambda_l - C lambda_{l-2}
+    // gives two independent chains (even / odd l - m) per ring: twice the ILP of the
+    // one-step form in a loop that is bound by FP64 latency, and each chain feeds one
+    // parity tile.  State of chain p: (wp[p], wc[p]) = lambda at l-2, l.
+    double wc[2] = {0.0, 0.0}, wp[2] = {0.0, 0.0};
+    const double x2 = x * x;
+    if (SPIN == 0) {
+        wc[0] = vc[0];
+        wc[1] = sqrt(2.0 * m + 3.0) * x * vc[0];  // lambda_{m+1,m} = sqrt(2m+3) x lambda_mm
+    }
+    double scf[NOP];
+#pragma unroll
+    for (int op = 0; op < NOP; ++op) scf[op] = scale_of(sc[op]);
+
+    // The coefficients are the same for every wave of the workgroup: each block's 32 entries
+    // are fetched one block ahead by threads 0..127 (one double each) and handed over through
+    // LDS, so the recursion never waits on global / scalar memory.
+    const int coff = SPIN == 0 ? 0 : 1;  // spin-2 tables are indexed by the target l
+    double cpre = 0.0;
+    if (threadIdx.x < 4 * LBLK)
+        (&coefs[0][0].x)[threadIdx.x] = reinterpret_cast<const double *>(rec2 + cb + l0 + coff)[threadIdx.x];
+    __syncthreads();
+    int cbuf = 0;
+    for (int lb = l0; lb <= lmax; lb += LBLK, cbuf ^= 1) {
+        if (threadIdx.x < 4 * LBLK)
+            cpre = reinterpret_cast<const double *>(rec2 + cb + lb + LBLK + coff)[threadIdx.x];
+        const double4 *cf = coefs[cbuf];
         double4_t acc[2];
         acc[0] = (double4_t){0.0, 0.0, 0.0, 0.0};
         acc[1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        if (wave_on && !(A.ablate & 2)) {
+            if (SPIN == 0) {
+                const bool all_live = __all(sc[0] == 0 || !valid);
+                const bool all_dead = __all(sc[0] <= -3 || !valid);
+                if ((A.ablate & 8) && lane == 0) atomicAdd(&A.counters[all_dead ? 0 : (all_live ? 1 : 2)], 1ULL);
+                auto advance2 = [&](int j) {
 #pragma unroll
-        for (int op = 0; op < NOP; ++op) {
-            if (!wave_on) continue;
-            // block state: all lanes in true scale / all lanes negligible
-            const bool lane_live0 = sc[op] == 0 || !valid;
-            const bool lane_dead = sc[op] <= -3 || !valid;
-            const bool all_live = __all(lane_live0);
-            const bool all_dead = __all(lane_dead);
-            if (all_dead) {
-                // silent recursion: no tile, no MFMA
-                for (int s = 0; s < LBLK; ++s) {
-                    const int l = lb + s + 1;
-                    double vn;
-                    if (SPIN == 0) {
-                        const double2 c = P.rec0[cb + l];
-                        vn = fma(c.x * x, vc[op], -c.y * vp[op]);
-                    } else {
-                        const double4 c = P.rec2[cb + l];
-                        const double cc = op == 0 ? c.y : -c.y;
-                        vn = fma(fma(c.x, x, cc), vc[op], -c.z * vp[op]);
+                    for (int p = 0; p < 2; ++p) {
+                        const double4 c = cf[2 * j + p];
+                        const double vn = fma(fma(c.x, x2, c.y), wc[p], -c.z * wp[p]);
+                        wp[p] = wc[p];
+                        wc[p] = vn;
                     }
-                    vp[op] = vc[op]; vc[op] = vn;
-                    if (fabs(vc[op]) > SC_BIG) { vc[op] *= SC_SMALL; vp[op] *= SC_SMALL; sc[op] += 1; }
-                }
-                continue;
-            }
-            if (all_live) {
-#pragma unroll 8
-                for (int s = 0; s < LBLK; ++s) {
-                    const int l = lb + s + 1;
-                    mytile[(((s + off) & 1) * 16 + (s >> 1)) * TILE_LD + lane] = vc[op];
-                    double vn;
-                    if (SPIN == 0) {
-                        const double2 c = P.rec0[cb + l];
-                        vn = fma(c.x * x, vc[op], -c.y * vp[op]);
-                    } else {
-                        const double4 c = P.rec2[cb + l];
-                        const double cc = op == 0 ? c.y : -c.y;
-                        vn = fma(fma(c.x, x, cc), vc[op], -c.z * vp[op]);
+                };
+                auto rescale = [&]() {
+                    if (__any(fabs(wc[0]) > SC_BIG || fabs(wc[1]) > SC_BIG)) {
+                        if (fabs(wc[0]) > SC_BIG || fabs(wc[1]) > SC_BIG) {
+                            wc[0] *= SC_SMALL; wp[0] *= SC_SMALL; wc[1] *= SC_SMALL; wp[1] *= SC_SMALL;
+                            sc[0] += 1;
+                            scf[0] = scale_of(sc[0]);
+                        }
                     }
-                    vp[op] = vc[op]; vc[op] = vn;
+                };
+                if (all_dead) {
+                    for (int j = 0; j < LBLK / 2; ++j) { advance2(j); rescale(); }
+                } else {
+                    if (all_live) {
+#pragma unroll
+                        for (int j = 0; j < LBLK / 2; ++j) {
+                            mytile[(0 * 16 + j) * TILE_LD + (lane ^ j)] = wc[0];
+                            mytile[(1 * 16 + j) * TILE_LD + (lane ^ j)] = wc[1];
+                            advance2(j);
+                        }
+                    } else {
+#pragma unroll 4
+                        for (int j = 0; j < LBLK / 2; ++j) {
+                            mytile[(0 * 16 + j) * TILE_LD + (lane ^ j)] = wc[0] * scf[0];
+                            mytile[(1 * 16 + j) * TILE_LD + (lane ^ j)] = wc[1] * scf[0];
+                            advance2(j);
+                            rescale();
+                        }
+                    }
+                    mfma_block(0, acc);
                 }
             } else {
-#pragma unroll 4
-                for (int s = 0; s < LBLK; ++s) {
-                    const int l = lb + s + 1;
-                    mytile[(((s + off) & 1) * 16 + (s >> 1)) * TILE_LD + lane] = sval_true(vc[op], sc[op]);
-                    double vn;
-                    if (SPIN == 0) {
-                        const double2 c = P.rec0[cb + l];
-                        vn = fma(c.x * x, vc[op], -c.y * vp[op]);
-                    } else {
-                        const double4 c = P.rec2[cb + l];
-                        const double cc = op == 0 ? c.y : -c.y;
-                        vn = fma(fma(c.x, x, cc), vc[op], -c.z * vp[op]);
+#pragma unroll
+                for (int op = 0; op < NOP; ++op) {
+                    const bool all_live = __all(sc[op] == 0 || !valid);
+                    const bool all_dead = __all(sc[op] <= -3 || !valid);
+                    if ((A.ablate & 8) && lane == 0) atomicAdd(&A.counters[all_dead ? 0 : (all_live ? 1 : 2)], 1ULL);
+                    const double sgn = op == 0 ? 1.0 : -1.0;
+                    auto advance = [&](int s) {
+                        const double4 c = cf[s];
+                        const double vn = fma(fma(c.x, x, sgn * c.y), vc[op], -c.z * vp[op]);
+                        vp[op] = vc[op];
+                        vc[op] = vn;
+                    };
+                    auto rescale = [&]() {
+                        if (__any(fabs(vc[op]) > SC_BIG)) {
+                            if (fabs(vc[op]) > SC_BIG) {
+                                vc[op] *= SC_SMALL; vp[op] *= SC_SMALL;
+                                sc[op] += 1;
+                                scf[op] = scale_of(sc[op]);
+                            }
+                        }
+                    };
+                    if (all_dead) {
+                        for (int s = 0; s < LBLK; ++s) { advance(s); rescale(); }
+                        continue;
                     }
-                    vp[op] = vc[op]; vc[op] = vn;
-                    if (fabs(vc[op]) > SC_BIG) { vc[op] *= SC_SMALL; vp[op] *= SC_SMALL; sc[op] += 1; }
+                    if (all_live) {
+#pragma unroll 8
+                        for (int s = 0; s < LBLK; ++s) {
+                            mytile[(((s + off) & 1) * 16 + (s >> 1)) * TILE_LD + (lane ^ (s >> 1))] = vc[op];
+                            advance(s);
+                        }
+                    } else {
+#pragma unroll 4
+                        for (int s = 0; s < LBLK; ++s) {
+                            mytile[(((s + off) & 1) * 16 + (s >> 1)) * TILE_LD + (lane ^ (s >> 1))] = vc[op] * scf[op];
+                            advance(s);
+                            rescale();
+                        }
+                    }
+                    mfma_block(op, acc);
                 }
             }
-            // the tile is private to this wave: order LDS writes before reads
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int par = 0; par < 2; ++par)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const double a = mytile[(par * 16 + ai) * TILE_LD + 4 * q + ak];
-                    acc[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[op][par][q], acc[par], 0, 0, 0);
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
         // ---- flush: combine the waves' partial tiles through LDS ---------------------
         // D layout of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4*reg, col = lane&15
+        if (threadIdx.x < 4 * LBLK) (&coefs[cbuf ^ 1][0].x)[threadIdx.x] = cpre;
 #pragma unroll
         for (int par = 0; par < 2; ++par)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                mytile[par * 16 * TILE_LD + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[par][r];
+                myflush[par * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[par][r];
         __syncthreads();
         {
             const int t = threadIdx.x, par = t >> 8, r16 = (t >> 4) & 15, col = t & 15;
             double s = 0.0;
 #pragma unroll
-            for (int ww = 0; ww < LA_WAVES; ++ww) s += (&tiles[ww][par][0][0])[r16 * 16 + col];
+            for (int ww = 0; ww < LA_WAVES; ++ww) s += (&tiles[ww][0][0][0])[par * 256 + r16 * 16 + col];
             const int l = lb + 2 * r16 + (par ^ off);
             if (l <= lmax) A.partial[(task.pout + (l - l0)) * NCOL + col] = s;
         }
-        __syncthreads();
+        __syncthreads();  // D tiles consumed: the tile buffers may be overwritten by the next block
     }
 }
 
@@ -937,11 +1035,14 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
     chk(upload(pl->startN, sN)); chk(upload(pl->startS, sS)); chk(upload(pl->bhat_off, boff));
     chk(upload(pl->tw, tw)); chk(upload(pl->mfac, mfac)); chk(upload(pl->kfac2, kfac2));
     chk(pl->bhat.alloc(sizeof(double2) * std::max<long long>(btot, 1)));
-    chk(pl->rec0.alloc(sizeof(double2) * (pl->nlm + 64)));
+    chk(pl->rec0.alloc(sizeof(double2) * (pl->nlm + 128)));
     if (rc != HX_OK) { delete pl; return nullptr; }
     hipStream_t st = rt().stream;
-    (void)hipMemsetAsync(pl->rec0.p, 0, sizeof(double2) * (pl->nlm + 64), st);
+    (void)hipMemsetAsync(pl->rec0.p, 0, sizeof(double2) * (pl->nlm + 128), st);
     hipLaunchKernelGGL(k_init_rec0, dim3(lmax + 1), dim3(256), 0, st, lmax, pl->rec0.as<double2>());
+    if (pl->rec0b.alloc(sizeof(double4) * (pl->nlm + 128)) != HX_OK) { delete pl; return nullptr; }
+    (void)hipMemsetAsync(pl->rec0b.p, 0, sizeof(double4) * (pl->nlm + 128), st);
+    hipLaunchKernelGGL(k_init_rec0b, dim3(lmax + 1), dim3(256), 0, st, lmax, pl->rec0b.as<double4>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_bhat), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -970,15 +1071,15 @@ extern "C" void hx_plan_destroy(hx_plan *plan)
 extern "C" int64_t hx_plan_scratch_bytes(const hx_plan *pl)
 {
     if (!pl) return 0;
-    return (int64_t)(pl->Y.bytes + pl->F.bytes + pl->partial.bytes + pl->rec0.bytes + pl->rec2.bytes +
+    return (int64_t)(pl->Y.bytes + pl->F.bytes + pl->partial.bytes + pl->rec0.bytes + pl->rec0b.bytes + pl->rec2.bytes +
                      pl->bhat.bytes + pl->stage_maps.bytes + pl->stage_alms.bytes + pl->resid.bytes + pl->Fsyn.bytes);
 }
 
 static int ensure_rec2(hx_plan *pl)
 {
     if (pl->rec2.p) return HX_OK;
-    HX_TRY(pl->rec2.alloc(sizeof(double4) * (pl->nlm + 64)));
-    HX_HIP(hipMemsetAsync(pl->rec2.p, 0, sizeof(double4) * (pl->nlm + 64), rt().stream));
+    HX_TRY(pl->rec2.alloc(sizeof(double4) * (pl->nlm + 128)));
+    HX_HIP(hipMemsetAsync(pl->rec2.p, 0, sizeof(double4) * (pl->nlm + 128), rt().stream));
     hipLaunchKernelGGL(k_init_rec2, dim3(pl->lmax + 1), dim3(256), 0, rt().stream, pl->lmax, pl->rec2.as<double4>());
     HX_HIP(hipGetLastError());
     return HX_OK;
@@ -1012,12 +1113,29 @@ static int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, d
     }
     {
         ProfScope ps("legendre_analysis");
+        ProfScope ps2(spin == 0 ? "legendre_analysis_s0" : "legendre_analysis_s2");
         LegParams A;
         A.P = P; A.tasks = ts.d_tasks.as<LegTask>(); A.F = pl->F.as<double>(); A.partial = pl->partial.as<double>();
+        A.rec0 = pl->rec0.as<double2>(); A.rec2 = pl->rec2.as<double4>();
+        {
+            const char *e = getenv("HX_ABLATE");
+            A.ablate = e ? atoi(e) : 0;
+            A.counters = nullptr;
+            if (A.ablate & 8) {
+                HX_TRY(pl->d_rw.alloc(64));
+                HX_HIP(hipMemsetAsync(pl->d_rw.p, 0, 64, st));
+                A.counters = pl->d_rw.as<unsigned long long>();
+            }
+        }
         if (spin == 0)
-            hipLaunchKernelGGL(k_legendre_analysis<0>, dim3((unsigned)ts.tasks.size()), dim3(LA_WAVES * 64), 0, st, A);
+            hipLaunchKernelGGL(k_legendre_analysis<0>, dim3((unsigned)ts.tasks.size()), dim3(LA_WAVES * 64), 0, st, A, (const double4 *)pl->rec0b.as<double4>());
         else
-            hipLaunchKernelGGL(k_legendre_analysis<2>, dim3((unsigned)ts.tasks.size()), dim3(LA_WAVES * 64), 0, st, A);
+            hipLaunchKernelGGL(k_legendre_analysis<2>, dim3((unsigned)ts.tasks.size()), dim3(LA_WAVES * 64), 0, st, A, (const double4 *)pl->rec2.as<double4>());
+    }
+    if (pl->d_rw.p && getenv("HX_ABLATE") && (atoi(getenv("HX_ABLATE")) & 8)) {
+        unsigned long long h[4] = {0, 0, 0, 0};
+        HX_HIP(hipMemcpy(h, pl->d_rw.p, 32, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[hx] spin %d legendre blocks: dead %llu live %llu mixed %llu\n", spin, h[0], h[1], h[2]);
     }
     {
         ProfScope ps("alm_reduce");
