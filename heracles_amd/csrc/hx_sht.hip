@@ -67,7 +67,7 @@ struct hx_plan {
     int nrp = 0, nrp_pad = 0, nrb = 0, twN = 1;
     long long npix = 0, ny = 0, nlm = 0;
     size_t lds_fft = 0;
-    hx::DevBuf z, omz, sth, rwdef, nsub, shifted, startN, startS, bhat_off, tw, bhat, mfac, kfac2, rec0, rec0b, rec2;
+    hx::DevBuf z, omz, sth, rwdef, nsub, shifted, startN, startS, bhat_off, tw, bhat, mfac, kfac2, rec0, rec2, cn0, al0, cn2, al2;
     std::vector<double> h_sth, h_z;
     std::vector<int> h_nsub;
     struct TaskSet {
@@ -111,25 +111,64 @@ __global__ void k_init_rec0(int lmax, double2 *__restrict__ rec)
     }
 }
 
-// Two-step spin-0 table: recb[idx(l,m)] = (A, B, C, 0) with
-//   lambda_{l+2} = (A x^2 + B) lambda_l - C lambda_{l-2},   a_l = sqrt((4l^2-1)/(l^2-m^2)),
-//   A = a_{l+1} a_{l+2},  B = -(a_{l+2}/a_{l+1} + a_{l+2} a_{l+1}/a_l^2),  C = a_{l+2} a_{l+1}/(a_l a_{l-1})
-// (terms with a_m = infinity vanish).
-__global__ void k_init_rec0b(int lmax, double4 *__restrict__ rec)
+// Normalised recursions used by the analysis kernel (two FMAs per new value, after the
+// scheme of libsharp/ducc's Ylmgen): with lambda_l = alpha_l mu_l,
+//   spin 0 (two-step):  mu_{l+2} = (A' x^2 + B') mu_l - mu_{l-2}
+//       A = a_{l+1} a_{l+2},  B = -(a_{l+2}/a_{l+1} + a_{l+2} a_{l+1}/a_l^2),  a_l = sqrt((4l^2-1)/(l^2-m^2)),
+//       alpha_{l+2} alpha_l = a_{l+2} a_{l+1} / 4,   A' = A alpha_l/alpha_{l+2},  B' likewise;
+//       coef[idx(l,m)] = (A', B') is indexed by the SOURCE l, alpha[idx(l,m)] = alpha_l.
+//   spin 2 (one-step):  mu_{l+1} = (p' x +- q') mu_l - mu_{l-1}   (+ for d^l_{m,-2}, - for d^l_{m,+2})
+//       alpha_{l+1} = r_l alpha_{l-1},  p' = p alpha_l/alpha_{l+1},  q' likewise;
+//       coef[idx(l+1,m)] = (p', q') is indexed by the TARGET l.
+// One thread per (m, chain): the alpha recursion is sequential in l.
+__global__ void k_init_norm0(int lmax, double2 *__restrict__ coef, double *__restrict__ alpha)
 {
-    const int m = blockIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = t >> 1, par = t & 1;
+    if (m > lmax) return;
     const double dm = m;
     auto a = [dm](double l) { return sqrt((4.0 * l * l - 1.0) / (l * l - dm * dm)); };
-    for (int l = m + threadIdx.x; l <= lmax; l += blockDim.x) {
+    double al = 1.0;
+    for (int l = m + par; l <= lmax; l += 2) {
         const double dl = l;
         const double a1 = a(dl + 1.0), a2 = a(dl + 2.0);
-        double4 r = make_double4(a1 * a2, -a2 / a1, 0.0, 0.0);
+        const double A = a1 * a2;
+        double B = -a2 / a1;
         if (l > m) {
             const double a0 = a(dl);
-            r.y -= a2 * a1 / (a0 * a0);
-            if (l > m + 1) r.z = a2 * a1 / (a0 * a(dl - 1.0));
+            B -= a2 * a1 / (a0 * a0);
         }
-        rec[almidx(lmax, l, m)] = r;
+        const double an = 0.25 * a2 * a1 / al;
+        coef[almidx(lmax, l, m)] = make_double2(A * al / an, B * al / an);
+        alpha[almidx(lmax, l, m)] = al;
+        al = an;
+    }
+}
+
+__global__ void k_init_norm2(int lmax, double2 *__restrict__ coef, double *__restrict__ alpha)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m > lmax) return;
+    const int l0 = m > 2 ? m : 2;
+    double am1 = 1.0, a0 = 1.0;  // alpha_{l-1}, alpha_l
+    for (int l = l0; l <= lmax; ++l) {
+        alpha[almidx(lmax, l, m)] = a0;
+        if (l == lmax) break;
+        // coefficients of the step l -> l+1 (n = -2)
+        const double k = l, lp = l + 1.0, dm = m, dn = -2.0;
+        const double den = k * sqrt((lp * lp - dm * dm) * (lp * lp - dn * dn));
+        const double r1 = sqrt((2.0 * k + 3.0) / (2.0 * k + 1.0));
+        const double p = r1 * (2.0 * k + 1.0) * k * lp / den;
+        const double q = -r1 * (2.0 * k + 1.0) * dm * dn / den;
+        double a1 = 1.0;
+        if (l > l0) {
+            const double r2 = sqrt((2.0 * k + 3.0) / (2.0 * k - 1.0));
+            const double r = r2 * lp * sqrt((k * k - dm * dm) * (k * k - dn * dn)) / den;
+            a1 = r * am1;
+        }
+        coef[almidx(lmax, l + 1, m)] = make_double2(p * a0 / a1, q * a0 / a1);
+        am1 = a0;
+        a0 = a1;
     }
 }
 
@@ -409,12 +448,13 @@ __device__ inline double bcast(double v, int src)
 
 template <int SPIN>
 __global__ __launch_bounds__(LA_WAVES * 64) void k_legendre_analysis(LegParams A,
-                                                                   const double4 *__restrict__ rec2)
+                                                                   const double2 *__restrict__ coefn,
+                                                                   const double *__restrict__ alphan)
 {
     constexpr int NOP = SPIN == 0 ? 1 : 2;
     __shared__ double tiles[LA_WAVES][2][16][TILE_LD];  // 128 KiB; after the MFMA phase the first
                                                         // 4 KiB of each wave's tiles carry its D tiles
-    __shared__ double4 coefs[2][LBLK];                  // recursion coefficients of this / the next block
+    __shared__ double2 coefs[2][LBLK];                  // recursion coefficients of this / the next block
     const PlanDev &P = A.P;
     const LegTask task = A.tasks[blockIdx.x];
     const int m = task.m, lmax = P.lmax;
@@ -499,10 +539,10 @@ __global__ __launch_bounds__(LA_WAVES * 64) void k_legendre_analysis(LegParams A
     };
     auto scale_of = [](int e) { return e == 0 ? 1.0 : (e == -1 ? SC_SMALL : 0.0); };
 
-    // spin 0: the two-step recursion lambda_{l+2} = (A x^2 + B) lambda_l - C lambda_{l-2}
-    // gives two independent chains (even / odd l - m) per ring: twice the ILP of the
-    // one-step form in a loop that is bound by FP64 latency, and each chain feeds one
-    // parity tile.  State of chain p: (wp[p], wc[p]) = lambda at l-2, l.
+    // spin 0: the normalised two-step recursion mu_{l+2} = (A' x^2 + B') mu_l - mu_{l-2}
+    // (lambda_l = alpha_l mu_l) gives two independent chains (even / odd l - m) per ring,
+    // each feeding one parity tile; alpha_l is applied to the output rows at the flush.
+    // State of chain p: (wp[p], wc[p]) = mu at l-2, l; alpha_m = alpha_{m+1} = 1.
     double wc[2] = {0.0, 0.0}, wp[2] = {0.0, 0.0};
     const double x2 = x * x;
     if (SPIN == 0) {
@@ -516,16 +556,16 @@ __global__ __launch_bounds__(LA_WAVES * 64) void k_legendre_analysis(LegParams A
     // The coefficients are the same for every wave of the workgroup: each block's 32 entries
     // are fetched one block ahead by threads 0..127 (one double each) and handed over through
     // LDS, so the recursion never waits on global / scalar memory.
-    const int coff = SPIN == 0 ? 0 : 1;  // spin-2 tables are indexed by the target l
+    const int coff = SPIN == 0 ? 0 : 1;  // spin-2 coefficients are indexed by the target l
     double cpre = 0.0;
-    if (threadIdx.x < 4 * LBLK)
-        (&coefs[0][0].x)[threadIdx.x] = reinterpret_cast<const double *>(rec2 + cb + l0 + coff)[threadIdx.x];
+    if (threadIdx.x < 2 * LBLK)
+        (&coefs[0][0].x)[threadIdx.x] = reinterpret_cast<const double *>(coefn + cb + l0 + coff)[threadIdx.x];
     __syncthreads();
     int cbuf = 0;
     for (int lb = l0; lb <= lmax; lb += LBLK, cbuf ^= 1) {
-        if (threadIdx.x < 4 * LBLK)
-            cpre = reinterpret_cast<const double *>(rec2 + cb + lb + LBLK + coff)[threadIdx.x];
-        const double4 *cf = coefs[cbuf];
+        if (threadIdx.x < 2 * LBLK)
+            cpre = reinterpret_cast<const double *>(coefn + cb + lb + LBLK + coff)[threadIdx.x];
+        const double2 *cf = coefs[cbuf];
         double4_t acc[2];
         acc[0] = (double4_t){0.0, 0.0, 0.0, 0.0};
         acc[1] = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -537,8 +577,8 @@ __global__ __launch_bounds__(LA_WAVES * 64) void k_legendre_analysis(LegParams A
                 auto advance2 = [&](int j) {
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
-                        const double4 c = cf[2 * j + p];
-                        const double vn = fma(fma(c.x, x2, c.y), wc[p], -c.z * wp[p]);
+                        const double2 c = cf[2 * j + p];
+                        const double vn = fma(fma(c.x, x2, c.y), wc[p], -wp[p]);
                         wp[p] = wc[p];
                         wc[p] = vn;
                     }
@@ -581,8 +621,8 @@ __global__ __launch_bounds__(LA_WAVES * 64) void k_legendre_analysis(LegParams A
                     if ((A.ablate & 8) && lane == 0) atomicAdd(&A.counters[all_dead ? 0 : (all_live ? 1 : 2)], 1ULL);
                     const double sgn = op == 0 ? 1.0 : -1.0;
                     auto advance = [&](int s) {
-                        const double4 c = cf[s];
-                        const double vn = fma(fma(c.x, x, sgn * c.y), vc[op], -c.z * vp[op]);
+                        const double2 c = cf[s];
+                        const double vn = fma(fma(c.x, x, sgn * c.y), vc[op], -vp[op]);
                         vp[op] = vc[op];
                         vc[op] = vn;
                     };
@@ -619,20 +659,20 @@ __global__ __launch_bounds__(LA_WAVES * 64) void k_legendre_analysis(LegParams A
         }
         // ---- flush: combine the waves' partial tiles through LDS ---------------------
         // D layout of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4*reg, col = lane&15
-        if (threadIdx.x < 4 * LBLK) (&coefs[cbuf ^ 1][0].x)[threadIdx.x] = cpre;
+        if (threadIdx.x < 2 * LBLK) (&coefs[cbuf ^ 1][0].x)[threadIdx.x] = cpre;
 #pragma unroll
         for (int par = 0; par < 2; ++par)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 myflush[par * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[par][r];
         __syncthreads();
-        {
-            const int t = threadIdx.x, par = t >> 8, r16 = (t >> 4) & 15, col = t & 15;
+        for (int t = threadIdx.x; t < 512; t += LA_WAVES * 64) {
+            const int par = t >> 8, r16 = (t >> 4) & 15, col = t & 15;
             double s = 0.0;
 #pragma unroll
             for (int ww = 0; ww < LA_WAVES; ++ww) s += (&tiles[ww][0][0][0])[par * 256 + r16 * 16 + col];
             const int l = lb + 2 * r16 + (par ^ off);
-            if (l <= lmax) A.partial[(task.pout + (l - l0)) * NCOL + col] = s;
+            if (l <= lmax) A.partial[(task.pout + (l - l0)) * NCOL + col] = s * alphan[cb + l];
         }
         __syncthreads();  // D tiles consumed: the tile buffers may be overwritten by the next block
     }
@@ -1040,9 +1080,13 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
     hipStream_t st = rt().stream;
     (void)hipMemsetAsync(pl->rec0.p, 0, sizeof(double2) * (pl->nlm + 128), st);
     hipLaunchKernelGGL(k_init_rec0, dim3(lmax + 1), dim3(256), 0, st, lmax, pl->rec0.as<double2>());
-    if (pl->rec0b.alloc(sizeof(double4) * (pl->nlm + 128)) != HX_OK) { delete pl; return nullptr; }
-    (void)hipMemsetAsync(pl->rec0b.p, 0, sizeof(double4) * (pl->nlm + 128), st);
-    hipLaunchKernelGGL(k_init_rec0b, dim3(lmax + 1), dim3(256), 0, st, lmax, pl->rec0b.as<double4>());
+    if (pl->cn0.alloc(sizeof(double2) * (pl->nlm + 128)) != HX_OK || pl->al0.alloc(sizeof(double) * (pl->nlm + 128)) != HX_OK) {
+        delete pl;
+        return nullptr;
+    }
+    (void)hipMemsetAsync(pl->cn0.p, 0, sizeof(double2) * (pl->nlm + 128), st);
+    (void)hipMemsetAsync(pl->al0.p, 0, sizeof(double) * (pl->nlm + 128), st);
+    hipLaunchKernelGGL(k_init_norm0, dim3((2 * (lmax + 1) + 63) / 64), dim3(64), 0, st, lmax, pl->cn0.as<double2>(), pl->al0.as<double>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_bhat), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1071,7 +1115,7 @@ extern "C" void hx_plan_destroy(hx_plan *plan)
 extern "C" int64_t hx_plan_scratch_bytes(const hx_plan *pl)
 {
     if (!pl) return 0;
-    return (int64_t)(pl->Y.bytes + pl->F.bytes + pl->partial.bytes + pl->rec0.bytes + pl->rec0b.bytes + pl->rec2.bytes +
+    return (int64_t)(pl->Y.bytes + pl->F.bytes + pl->partial.bytes + pl->rec0.bytes + pl->rec2.bytes + pl->cn0.bytes + pl->al0.bytes + pl->cn2.bytes + pl->al2.bytes +
                      pl->bhat.bytes + pl->stage_maps.bytes + pl->stage_alms.bytes + pl->resid.bytes + pl->Fsyn.bytes);
 }
 
@@ -1081,6 +1125,11 @@ static int ensure_rec2(hx_plan *pl)
     HX_TRY(pl->rec2.alloc(sizeof(double4) * (pl->nlm + 128)));
     HX_HIP(hipMemsetAsync(pl->rec2.p, 0, sizeof(double4) * (pl->nlm + 128), rt().stream));
     hipLaunchKernelGGL(k_init_rec2, dim3(pl->lmax + 1), dim3(256), 0, rt().stream, pl->lmax, pl->rec2.as<double4>());
+    HX_TRY(pl->cn2.alloc(sizeof(double2) * (pl->nlm + 128)));
+    HX_TRY(pl->al2.alloc(sizeof(double) * (pl->nlm + 128)));
+    HX_HIP(hipMemsetAsync(pl->cn2.p, 0, sizeof(double2) * (pl->nlm + 128), rt().stream));
+    HX_HIP(hipMemsetAsync(pl->al2.p, 0, sizeof(double) * (pl->nlm + 128), rt().stream));
+    hipLaunchKernelGGL(k_init_norm2, dim3((pl->lmax + 64) / 64), dim3(64), 0, rt().stream, pl->lmax, pl->cn2.as<double2>(), pl->al2.as<double>());
     HX_HIP(hipGetLastError());
     return HX_OK;
 }
@@ -1128,14 +1177,15 @@ static int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, d
             }
         }
         if (spin == 0)
-            hipLaunchKernelGGL(k_legendre_analysis<0>, dim3((unsigned)ts.tasks.size()), dim3(LA_WAVES * 64), 0, st, A, (const double4 *)pl->rec0b.as<double4>());
+            hipLaunchKernelGGL(k_legendre_analysis<0>, dim3((unsigned)ts.tasks.size()), dim3(LA_WAVES * 64), 0, st, A, (const double2 *)pl->cn0.as<double2>(), (const double *)pl->al0.as<double>());
         else
-            hipLaunchKernelGGL(k_legendre_analysis<2>, dim3((unsigned)ts.tasks.size()), dim3(LA_WAVES * 64), 0, st, A, (const double4 *)pl->rec2.as<double4>());
+            hipLaunchKernelGGL(k_legendre_analysis<2>, dim3((unsigned)ts.tasks.size()), dim3(LA_WAVES * 64), 0, st, A, (const double2 *)pl->cn2.as<double2>(), (const double *)pl->al2.as<double>());
     }
     if (pl->d_rw.p && getenv("HX_ABLATE") && (atoi(getenv("HX_ABLATE")) & 8)) {
         unsigned long long h[4] = {0, 0, 0, 0};
+        HX_HIP(hipStreamSynchronize(st));
         HX_HIP(hipMemcpy(h, pl->d_rw.p, 32, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[hx] spin %d legendre blocks: dead %llu live %llu mixed %llu\n", spin, h[0], h[1], h[2]);
+        fprintf(stderr, "[hx] spin %d legendre wave-blocks: dead %llu live %llu mixed %llu\n", spin, h[0], h[1], h[2]);
     }
     {
         ProfScope ps("alm_reduce");
