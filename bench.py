@@ -170,18 +170,24 @@ def main():
     # ---- roofline of the dominant kernel (Legendre analysis, FP64 MFMA) ---------------
     F0 = 8.0 * 2 * nside * nlm  # algorithmic flops of one spin-0 component
     flops_step = nbins * F0 + nbins * 3 * F0
-    nl, ms = hx._lib.profile_get("legendre_analysis")
     prof = {}
-    for k in ("ring_fft", "fourier_combine", "legendre_analysis", "legendre_analysis_s0", "legendre_analysis_s2", "alm_reduce", "alm2cl"):
+    for k in ("ring_fft", "fourier_combine", "legendre_analysis", "legendre_analysis_s0", "legendre_analysis_s2",
+              "alm_reduce", "alm2cl"):
         n_, ms_ = hx._lib.profile_get(k)
         prof[k] = {"launches": n_, "ms_per_step": ms_ / max(args.steps, 1)}
-    achieved = flops_step * args.steps / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    roofline = {
-        "kernel": "k_legendre_analysis", "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
-        "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-        "launches": nl, "avg_launch_ms": ms / nl if nl else None,
-        "algorithmic_flops_per_step": flops_step,
-    }
+
+    def roof(name, kernel, flops_per_step):
+        nl_, ms_ = hx._lib.profile_get(name)
+        ach = flops_per_step * args.steps / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
+        return {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "launches": nl_,
+                "avg_launch_ms": ms_ / nl_ if nl_ else None,
+                "algorithmic_flops_per_launch": flops_per_step * args.steps / nl_ if nl_ else None}
+
+    # dominant kernel: the spin-2 Legendre/Wigner-d analysis (3 F0 per (Q,U) field)
+    roofline = roof("legendre_analysis_s2", "hx::k_legendre_analysis<2>", nbins * 3 * F0)
+    roofline_s0 = roof("legendre_analysis_s0", "hx::k_legendre_analysis<0>", nbins * F0)
+    roofline_all = roof("legendre_analysis", "hx::k_legendre_analysis<0|2>", flops_step)
 
     out = None
     if rank == 0:
@@ -219,6 +225,8 @@ def main():
             "mixmat_build_sec": mix["seconds"] if mix else None,
             "mixmat": mix,
             "roofline": roofline,
+            "roofline_spin0_kernel": roofline_s0,
+            "roofline_both_kernels": roofline_all,
             "cpu_baseline": cpu,
             "kernels": prof,
         }
