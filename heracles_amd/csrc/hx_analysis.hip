@@ -1,0 +1,504 @@
+// hx_analysis.hip -- Legendre / Wigner-d analysis stage of hx_map2alm on FP64 MFMA.
+//
+// Replaces the Legendre half of healpy.map2alm (heracles/healpy.py:183-189):
+//     a_lm = sum_rings lambda_lm(theta_r) F_m(r)               (spin 0)
+//     E_lm, B_lm from  sum_rings  (+2)lambda, (-2)lambda ...    (spin 2)
+//
+// The sum over rings is the reduction the three-term recursion wants on the LANES, so it is
+// given to v_mfma_f64_16x16x4_f64: per m,  a[l][col] = Lambda_m[l][ring] x F_m[ring][col]  is a
+// GEMM whose A operand is generated on the fly and whose K dimension is the ring index.
+//
+//   workgroup  = one m  x  NW waves x 32 ring pairs
+//   lane       = (h = lane>>5, ring = lane&31):   spin 0: h = parity chain of the two-step
+//                recursion (l-m even / odd);  spin 2: h = which function (d_{m,-2} / d_{m,+2}).
+//                Every lane runs ONE normalised recursion chain (2 FMAs per value).
+//   tile       = 16 rows (l) x 64 lanes in LDS, XOR-swizzled so that the row-wise stores and
+//                the [16 l x 4 rings] A-operand reads are both bank-conflict free.
+//   MFMA q     contracts rings {q, q+8, q+16, q+24} of the wave; its B operand (F of 8 maps =
+//                16 real columns, x NG column groups) stays in registers for the whole l sweep.
+//   flush      per 32-l block the waves' D tiles are summed through LDS in fixed order
+//                (bit-reproducible) and scaled by alpha_l into `partial`.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+#include "hx_sht_common.h"
+
+namespace hx {
+using namespace hxfft;
+
+template <int SPIN>
+struct LegCfg {
+    static constexpr int NW = SPIN == 0 ? 16 : 8;   // waves per workgroup
+    static constexpr int NT = SPIN == 0 ? 1 : 2;    // 16x64 tiles per wave
+    static constexpr int NOP = SPIN == 0 ? 1 : 2;   // A-operand functions per ring
+};
+
+struct LegParams {
+    PlanDev P;
+    const LegTask *__restrict__ tasks;
+    const double *__restrict__ F;      // [m - m0][rp][par][op][16*NG]
+    double *__restrict__ partial;      // [row - row0][16*NG]
+    int m0;                            // first m of the chunk held in F
+    long long row0;                    // first partial row of the chunk
+    int ng;                            // active column groups (<= NG)
+    int ablate;                        // diagnostic only (HX_ABLATE): 1 skip MFMA, 2 skip recursion, 8 count paths
+    unsigned long long *counters;
+};
+
+// =====================================================================================
+// Y -> F operands:  un-pack N/S, ring phase, quadrature weight, parity combinations
+// =====================================================================================
+__device__ inline double2 ring_mode(const PlanDev &P, const double2 *__restrict__ Yc, int rp, int n, int mm)
+{
+    return Yc[P.startN[rp] + (long long)(mm & 3) * n + (mm >> 2)];  // Z[mm], X[4k+r] = Y_r[k]
+}
+
+// F_N(m), F_S(m) of ring pair rp for component c, including phase and quadrature weight
+__device__ inline void ring_modes_ns(const PlanDev &P, const double2 *__restrict__ Y, int c, int rp, int m,
+                                     double w, double2 &FN, double2 &FS)
+{
+    const int n = P.nsub[rp];
+    const int nphi = 4 * n;
+    const int mm = m % nphi, mc = (nphi - mm) % nphi;
+    const double2 *Yc = Y + (long long)c * P.ny;
+    const double2 a = ring_mode(P, Yc, rp, n, mm), b = cconj(ring_mode(P, Yc, rp, n, mc));
+    const double2 xn = cscale(cadd(a, b), 0.5);
+    const double2 xs = mul_mi(cscale(csub(a, b), 0.5));  // (a-b)/(2i)
+    double2 ph = make_double2(w, 0.0);
+    if (P.shifted[rp]) ph = cscale(expipi(-(double)(m % (2 * nphi)) / (double)nphi), w);
+    FN = cmul(xn, ph);
+    FS = P.startS[rp] >= 0 ? cmul(xs, ph) : make_double2(0.0, 0.0);
+}
+
+// grid: x = m - m0, y = tiles of 32 ring pairs; block 256 = 32 ring pairs x 8 slots.
+// Component c lives in column group c/8, slot c%8 (spin 2: field f = c/2 in group f/4).
+template <int SPIN>
+__global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double2 *__restrict__ Y, int ncomp, int ng,
+                                                         int m0, const double *__restrict__ rw,
+                                                         double *__restrict__ F)
+{
+    constexpr int NOP = LegCfg<SPIN>::NOP;
+    const int m = m0 + blockIdx.x;
+    const int rp = blockIdx.y * 32 + (threadIdx.x >> 3);
+    const int slot = threadIdx.x & 7;
+    if (rp >= P.nrp_pad) return;
+    const bool live = rp < P.nrp;
+    const double w = live ? (rw ? rw[rp] : 1.0) * (4.0 * M_PI / (double)P.npix) : 0.0;
+    const int ncol = NCOL * ng;
+    double *row = F + (((long long)blockIdx.x * P.nrp_pad + rp) * 2) * NOP * ncol;
+    for (int g = 0; g < ng; ++g) {
+        if (SPIN == 0) {
+            const int c = g * 8 + slot;
+            double2 s = make_double2(0.0, 0.0), d = s;
+            if (live && c < ncomp) {
+                double2 fn, fs;
+                ring_modes_ns(P, Y, c, rp, m, w, fn, fs);
+                s = cadd(fn, fs);
+                d = csub(fn, fs);
+            }
+            *reinterpret_cast<double2 *>(row + g * NCOL + 2 * slot) = s;
+            *reinterpret_cast<double2 *>(row + ncol + g * NCOL + 2 * slot) = d;
+        } else {
+            const int f = g * 4 + (slot >> 1), op = slot & 1;
+            double4 o0 = make_double4(0.0, 0.0, 0.0, 0.0), o1 = o0;
+            if (live && 2 * f + 1 < ncomp) {
+                double2 qn, qs, un, us;
+                ring_modes_ns(P, Y, 2 * f, rp, m, w, qn, qs);
+                ring_modes_ns(P, Y, 2 * f + 1, rp, m, w, un, us);
+                // P+ = -(Q + iU)/2, P- = -(Q - iU)/2
+                const double2 ppn = cscale(cadd(qn, mul_pi(un)), -0.5), pmn = cscale(csub(qn, mul_pi(un)), -0.5);
+                const double2 pps = cscale(cadd(qs, mul_pi(us)), -0.5), pms = cscale(csub(qs, mul_pi(us)), -0.5);
+                // B+(P) = [Pr, Pi, Pi, -Pr]  (E_re, E_im, B_re, B_im columns; operand of lambda+)
+                // B-(P) = [Pr, Pi, -Pi, Pr]  (operand of lambda-);  lambda+-_S = p lambda-+_N
+                double4 x, y;
+                if (op == 0) {
+                    x = make_double4(ppn.x, ppn.y, ppn.y, -ppn.x);  // B+(P+_N)
+                    y = make_double4(pms.x, pms.y, -pms.y, pms.x);  // B-(P-_S)
+                } else {
+                    x = make_double4(pmn.x, pmn.y, -pmn.y, pmn.x);  // B-(P-_N)
+                    y = make_double4(pps.x, pps.y, pps.y, -pps.x);  // B+(P+_S)
+                }
+                o0 = make_double4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+                o1 = make_double4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+            }
+            const int col = g * NCOL + 4 * (slot >> 1);
+            *reinterpret_cast<double4 *>(row + (0 * NOP + op) * ncol + col) = o0;
+            *reinterpret_cast<double4 *>(row + (1 * NOP + op) * ncol + col) = o1;
+        }
+    }
+}
+
+// =====================================================================================
+// Legendre analysis
+// =====================================================================================
+// XOR swizzle of the tile column by the row: bits {4,2,1,0} of the column index
+__device__ __host__ inline int tile_swz(int r) { return (r & 7) | ((r & 8) << 1); }
+
+template <int SPIN, int NG>
+__global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(LegParams A,
+                                                                           const double2 *__restrict__ coefn,
+                                                                           const double *__restrict__ alphan)
+{
+    using C = LegCfg<SPIN>;
+    constexpr int NW = C::NW, NT = C::NT, NOP = C::NOP, NCOLS = NCOL * NG;
+    __shared__ double tiles[NW][NT][16][64];  // 128 KiB; after the MFMA phase each wave's tiles carry its D tiles
+    __shared__ double2 coefs[2][LBLK];        // recursion coefficients of this / the next block
+    const PlanDev &P = A.P;
+    const LegTask task = A.tasks[blockIdx.x];
+    const int m = task.m, lmax = P.lmax;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = lane >> 5, r32 = lane & 31;
+    const bool wave_on = w < task.nrb;
+    const int rb = task.rb0 + (wave_on ? w : 0);
+    const int rp = rb * RBLK + r32;
+    const bool valid = wave_on && rp < P.nrp;
+    const double x = valid ? P.z[rp] : 0.0;
+    const double xx = SPIN == 0 ? x * x : x;  // the variable of the recursion
+    const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
+    const int off = (l0 + m) & 1;
+    const long long cb = almidx(lmax, 0, m);
+    const int ai = lane & 15, ak = lane >> 4;
+
+    // ---- B operands: F[m - m0][rp][par][op][g*16 + j], lane (k = lane>>4, j = lane&15) ----
+    double fr[NG][2][NOP][8];
+    {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const long long row = (long long)(m - A.m0) * P.nrp_pad + rb * RBLK + q + 8 * ak;
+#pragma unroll
+            for (int par = 0; par < 2; ++par)
+#pragma unroll
+                for (int op = 0; op < NOP; ++op)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        fr[g][par][op][q] = (wave_on && g < A.ng)
+                                                ? A.F[((row * 2 + par) * NOP + op) * (NCOL * A.ng) + g * NCOL + ai]
+                                                : 0.0;
+        }
+    }
+
+    // ---- seed of this lane's chain -------------------------------------------------------
+    double vc = 0.0, vp = 0.0;
+    int sc = -100;
+    if (valid) {
+        if (SPIN == 0) {
+            SVal s = spow(P.sth[rp], m);
+            s.v *= P.mfac[m];
+            if (h) s.v *= sqrt(2.0 * m + 3.0) * x;  // lambda_{m+1,m} = sqrt(2m+3) x lambda_mm
+            snorm_small(s);
+            vc = s.v; sc = s.e;
+        } else {
+            SVal sp, sm;
+            spin2_seeds(m, P.sth[rp], P.omz[rp], P.kfac2[m], sp, sm);
+            vc = h ? sm.v : sp.v;
+            sc = h ? sm.e : sp.e;
+        }
+    }
+    const double sgn = (SPIN == 2 && h) ? -1.0 : 1.0;  // q' enters with opposite sign for d_{m,+2}
+    auto scale_of = [](int e) { return e == 0 ? 1.0 : (e == -1 ? SC_SMALL : 0.0); };
+    double scf = scale_of(sc);
+
+    double *mytile = &tiles[w][0][0][0];
+
+    // The coefficients are the same for every wave: each block's 32 entries are fetched one
+    // block ahead by threads 0..63 (one double each) and handed over through LDS.
+    const int coff = SPIN == 0 ? 0 : 1;  // spin-2 coefficients are indexed by the target l
+    double cpre = 0.0;
+    if (threadIdx.x < 2 * LBLK)
+        (&coefs[0][0].x)[threadIdx.x] = reinterpret_cast<const double *>(coefn + cb + l0 + coff)[threadIdx.x];
+    __syncthreads();
+    int cbuf = 0;
+    for (int lb = l0; lb <= lmax; lb += LBLK, cbuf ^= 1) {
+        if (threadIdx.x < 2 * LBLK)
+            cpre = reinterpret_cast<const double *>(coefn + cb + lb + LBLK + coff)[threadIdx.x];
+        const double2 *cf = coefs[cbuf];
+        double4_t acc[NG][2];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            acc[g][0] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            acc[g][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        }
+        if (wave_on && !(A.ablate & 2)) {
+            const bool all_live = __all(sc == 0 || !valid);
+            const bool all_dead = __all(sc <= -3 || !valid);
+            if ((A.ablate & 8) && lane == 0) atomicAdd(&A.counters[all_dead ? 0 : (all_live ? 1 : 2)], 1ULL);
+            // one recursion step of this lane's chain: spin 0 advances l by 2 (entry 2j+h),
+            // spin 2 advances l by 1 (entry s)
+            auto advance = [&](int e) {
+                const double2 c = cf[e];
+                const double vn = fma(fma(c.x, xx, sgn * c.y), vc, -vp);
+                vp = vc;
+                vc = vn;
+            };
+            auto rescale = [&]() {
+                if (__any(fabs(vc) > SC_BIG)) {
+                    if (fabs(vc) > SC_BIG) {
+                        vc *= SC_SMALL; vp *= SC_SMALL;
+                        sc += 1;
+                        scf = scale_of(sc);
+                    }
+                }
+            };
+            constexpr int NSTEP = SPIN == 0 ? LBLK / 2 : LBLK;
+            if (all_dead) {
+                for (int s = 0; s < NSTEP; ++s) {
+                    advance(SPIN == 0 ? 2 * s + h : s);
+                    rescale();
+                }
+            } else {
+                // row r of tile t, lane c  lives at  ((t*16 + r)*64 + (c ^ swz(r)))
+                if (all_live) {
+#pragma unroll
+                    for (int s = 0; s < NSTEP; ++s) {
+                        const int t = SPIN == 0 ? 0 : ((s + off) & 1), r = SPIN == 0 ? s : (s >> 1);
+                        mytile[(t * 16 + r) * 64 + (lane ^ tile_swz(r))] = vc;
+                        advance(SPIN == 0 ? 2 * s + h : s);
+                    }
+                } else {
+#pragma unroll 4
+                    for (int s = 0; s < NSTEP; ++s) {
+                        const int t = SPIN == 0 ? 0 : ((s + off) & 1), r = SPIN == 0 ? s : (s >> 1);
+                        mytile[(t * 16 + r) * 64 + (lane ^ tile_swz(r))] = vc * scf;
+                        advance(SPIN == 0 ? 2 * s + h : s);
+                        rescale();
+                    }
+                }
+                // the tile is private to the wave: order its LDS writes before the reads
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (!(A.ablate & 1)) {
+                    // A[i][k] = tile value of row i, ring q+8k of half hh:
+                    //   spin 0: hh = parity (tile 0);  spin 2: hh = function, tile = parity
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+#pragma unroll
+                        for (int par = 0; par < 2; ++par)
+#pragma unroll
+                            for (int op = 0; op < NOP; ++op) {
+                                const int t = SPIN == 0 ? 0 : par, hh = SPIN == 0 ? par : op;
+                                const double a = mytile[(t * 16 + ai) * 64 + ((hh * 32 + q + 8 * ak) ^ tile_swz(ai))];
+#pragma unroll
+                                for (int g = 0; g < NG; ++g)
+                                    acc[g][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[g][par][op][q], acc[g][par], 0, 0, 0);
+                            }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // ---- flush: combine the waves' D tiles through LDS (fixed order) --------------------
+        // D layout of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4*reg, col = lane&15
+        if (threadIdx.x < 2 * LBLK) (&coefs[cbuf ^ 1][0].x)[threadIdx.x] = cpre;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int par = 0; par < 2; ++par)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    mytile[(g * 2 + par) * 256 + (ak + 4 * r) * 16 + ai] = acc[g][par][r];
+        __syncthreads();
+        for (int t = threadIdx.x; t < NG * 512; t += NW * 64) {
+            const int g = t >> 9, par = (t >> 8) & 1, r16 = (t >> 4) & 15, col = t & 15;
+            if (g >= A.ng) continue;
+            double s = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) s += (&tiles[ww][0][0][0])[(g * 2 + par) * 256 + r16 * 16 + col];
+            const int l = lb + 2 * r16 + (par ^ off);
+            if (l <= lmax)
+                A.partial[(task.pout - A.row0 + (l - l0)) * (NCOL * A.ng) + g * NCOL + col] = s * alphan[cb + l];
+        }
+        __syncthreads();  // D tiles consumed: the tile buffers may be overwritten by the next block
+    }
+    (void)NCOLS;
+}
+
+// =====================================================================================
+// partial sums -> alm (fixed order over the ring groups of each m)
+// =====================================================================================
+template <int SPIN>
+__global__ __launch_bounds__(256) void k_alm_reduce(PlanDev P, const LegTask *__restrict__ tasks,
+                                                    const MTasks *__restrict__ of_m,
+                                                    const double *__restrict__ partial, long long row0, int m0,
+                                                    int ncomp, int ng, const double *__restrict__ fl, int add,
+                                                    double2 *__restrict__ alm, long long alm_stride)
+{
+    const int m = m0 + blockIdx.x, lmax = P.lmax;
+    const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
+    const MTasks mt = of_m[m];
+    const int nl = lmax - m + 1, nc = 8 * ng, ncol = NCOL * ng;
+    for (int i = threadIdx.x; i < nl * nc; i += blockDim.x) {
+        const int l = m + i / nc, c = i % nc;
+        if (c >= ncomp) continue;
+        double2 v = make_double2(0.0, 0.0);
+        if (l >= l0) {
+            // component c: column group c/8, columns 2(c%8), +1 (spin 2: comp 2f+e of field f)
+            const int col = (c >> 3) * NCOL + 2 * (c & 7);
+            for (int t = 0; t < mt.count; ++t) {
+                const double *p = partial + (tasks[mt.first + t].pout - row0 + (l - l0)) * ncol + col;
+                v.x += p[0];
+                v.y += p[1];
+            }
+            if (fl) { v.x *= fl[l]; v.y *= fl[l]; }
+        }
+        double2 *dst = alm + (long long)c * alm_stride + almidx(lmax, l, m);
+        if (add) { const double2 o = *dst; v.x += o.x; v.y += o.y; }
+        *dst = v;
+    }
+}
+
+// =====================================================================================
+// host side: task list, m-chunking, launch sequence
+// =====================================================================================
+// libsharp's published heuristic for the largest m that contributes on a ring
+// (sharp_get_mlim): rings with m > mlim are skipped.
+static int ring_mlim(int lmax, int spin, double sth, double cth)
+{
+    double ofs = lmax * 0.01;
+    if (ofs < 100.) ofs = 100.;
+    double b = -2 * spin * fabs(cth);
+    double t1 = lmax * sth + ofs;
+    double c = (double)spin * spin - t1 * t1;
+    double discr = b * b - 4 * c;
+    if (discr <= 0) return lmax;
+    double res = (-b + sqrt(discr)) / 2.;
+    if (res > lmax) res = lmax;
+    return (int)(res + 0.5);
+}
+
+int analysis_max_comp(int) { return 8 * NGMAX; }
+
+int build_tasks(hx_plan *pl, int spin)
+{
+    hx_plan::TaskSet &ts = pl->ts[spin ? 1 : 0];
+    if (ts.built) return HX_OK;
+    const int lmax = pl->lmax;
+    const int nw = spin == 0 ? LegCfg<0>::NW : LegCfg<2>::NW;
+    const int nrb = (pl->nrp + RBLK - 1) / RBLK;
+    ts.tasks.clear();
+    ts.of_m.assign(lmax + 1, MTasks{0, 0});
+    ts.rows_before_m.assign(lmax + 2, 0);
+    long long rows = 0;
+    // mlim is monotone in the ring index (pole -> equator): first active ring by bisection
+    std::vector<int> mlim(pl->nrp);
+    for (int rp = 0; rp < pl->nrp; ++rp) mlim[rp] = ring_mlim(lmax, spin, pl->h_sth[rp], pl->h_z[rp]);
+    for (int m = 0; m <= lmax; ++m) {
+        ts.rows_before_m[m] = rows;
+        const int l0 = spin == 0 ? m : std::max(m, 2);
+        ts.of_m[m].first = (int)ts.tasks.size();
+        if (l0 <= lmax) {
+            int first = (int)(std::lower_bound(mlim.begin(), mlim.end(), m) - mlim.begin());
+            if (first >= pl->nrp) first = pl->nrp - 1;
+            for (int rb = first / RBLK; rb < nrb; rb += nw) {
+                LegTask t;
+                t.m = m; t.rb0 = rb; t.nrb = std::min(nw, nrb - rb); t.pad = 0; t.pout = rows;
+                rows += (lmax - l0 + 1);
+                ts.tasks.push_back(t);
+            }
+        }
+        ts.of_m[m].count = (int)ts.tasks.size() - ts.of_m[m].first;
+    }
+    ts.rows_before_m[lmax + 1] = rows;
+    HX_TRY(upload(ts.d_tasks, ts.tasks));
+    HX_TRY(upload(ts.d_of_m, ts.of_m));
+    ts.built = true;
+    return HX_OK;
+}
+
+template <int SPIN>
+static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int nb, int ng, const double *d_rw,
+                        const double *d_fl, int add, double2 *d_alms)
+{
+    hipStream_t st = rt().stream;
+    PlanDev P = pl->dev();
+    const int t0 = ts.of_m[m0].first;
+    const int t1 = ts.of_m[m1 - 1].first + ts.of_m[m1 - 1].count;
+    {
+        ProfScope ps("fourier_combine");
+        dim3 grid(m1 - m0, pl->nrp_pad / 32);
+        hipLaunchKernelGGL(k_fourier_combine<SPIN>, grid, dim3(256), 0, st, P, pl->Y.as<double2>(), nb, ng, m0, d_rw, pl->F.as<double>());
+    }
+    if (t1 > t0) {
+        ProfScope ps("legendre_analysis");
+        ProfScope ps2(SPIN == 0 ? "legendre_analysis_s0" : "legendre_analysis_s2");
+        LegParams A;
+        A.P = P; A.tasks = ts.d_tasks.as<LegTask>() + t0; A.F = pl->F.as<double>(); A.partial = pl->partial.as<double>();
+        A.m0 = m0; A.row0 = ts.rows_before_m[m0]; A.ng = ng;
+        const char *e = getenv("HX_ABLATE");
+        A.ablate = e ? atoi(e) : 0;
+        A.counters = nullptr;
+        if (A.ablate & 8) {
+            HX_TRY(pl->d_dbg.alloc(64));
+            HX_HIP(hipMemsetAsync(pl->d_dbg.p, 0, 64, st));
+            A.counters = pl->d_dbg.as<unsigned long long>();
+        }
+        const double2 *cn = SPIN == 0 ? pl->cn0.as<double2>() : pl->cn2.as<double2>();
+        const double *al = SPIN == 0 ? pl->al0.as<double>() : pl->al2.as<double>();
+        constexpr int NW = LegCfg<SPIN>::NW;
+        if (ng == 1)
+            hipLaunchKernelGGL((k_legendre_analysis<SPIN, 1>), dim3((unsigned)(t1 - t0)), dim3(NW * 64), 0, st, A, cn, al);
+        else
+            hipLaunchKernelGGL((k_legendre_analysis<SPIN, 2>), dim3((unsigned)(t1 - t0)), dim3(NW * 64), 0, st, A, cn, al);
+        if (A.ablate & 8) {
+            unsigned long long hc[4] = {0, 0, 0, 0};
+            HX_HIP(hipStreamSynchronize(st));
+            HX_HIP(hipMemcpy(hc, pl->d_dbg.p, 32, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[hx] spin %d m [%d,%d) legendre wave-blocks: dead %llu live %llu mixed %llu\n", SPIN, m0, m1, hc[0], hc[1], hc[2]);
+        }
+    }
+    {
+        ProfScope ps("alm_reduce");
+        hipLaunchKernelGGL(k_alm_reduce<SPIN>, dim3(m1 - m0), dim3(256), 0, st, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
+                           pl->partial.as<double>(), ts.rows_before_m[m0], m0, nb, ng, d_fl, add, d_alms, pl->nlm);
+    }
+    HX_HIP(hipGetLastError());
+    return HX_OK;
+}
+
+// One analysis pass over a batch of <= 8*NGMAX components (device pointers).  F and the
+// partial sums are produced per m-chunk so that their footprint stays within a budget
+// (HX_SCRATCH_GB, default 40 GB); Y (ring spectra of the batch) persists across chunks.
+int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 *d_alms, const double *d_rw,
+                   const double *d_pw, const double *d_fl, int add)
+{
+    const int sidx = spin ? 1 : 0, nop = spin ? 2 : 1;
+    HX_TRY(build_tasks(pl, spin));
+    if (spin) HX_TRY(ensure_rec2(pl));
+    hx_plan::TaskSet &ts = pl->ts[sidx];
+    const int ng = (nb + 7) / 8;
+    const int ncol = NCOL * ng;
+    HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
+    HX_TRY(launch_ring_subdft_maps(pl, nb, d_maps, d_pw, pl->Y.as<double2>()));
+
+    const char *eb = getenv("HX_SCRATCH_GB");
+    const double budget = (eb ? atof(eb) : 40.0) * 1e9;
+    const double f_per_m = (double)pl->nrp_pad * 2 * nop * ncol * sizeof(double);
+    const int lmax = pl->lmax;
+    std::vector<std::pair<int, int>> chunks;
+    size_t maxF = 16, maxP = 16;
+    for (int m0 = 0; m0 <= lmax;) {
+        int m1 = m0 + 1;
+        while (m1 <= lmax) {
+            const double bytes = f_per_m * (m1 + 1 - m0) +
+                                 (double)(ts.rows_before_m[m1 + 1] - ts.rows_before_m[m0]) * ncol * sizeof(double);
+            if (bytes > budget) break;
+            ++m1;
+        }
+        chunks.emplace_back(m0, m1);
+        maxF = std::max(maxF, (size_t)(f_per_m * (m1 - m0)));
+        maxP = std::max(maxP, (size_t)(ts.rows_before_m[m1] - ts.rows_before_m[m0]) * ncol * sizeof(double));
+        m0 = m1;
+    }
+    HX_TRY(pl->F.alloc(maxF));
+    HX_TRY(pl->partial.alloc(maxP));
+    for (auto &ch : chunks) {
+        if (spin == 0)
+            HX_TRY(launch_chunk<0>(pl, ts, ch.first, ch.second, nb, ng, d_rw, d_fl, add, d_alms));
+        else
+            HX_TRY(launch_chunk<2>(pl, ts, ch.first, ch.second, nb, ng, d_rw, d_fl, add, d_alms));
+    }
+    return HX_OK;
+}
+
+}  // namespace hx

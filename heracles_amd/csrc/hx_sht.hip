@@ -21,72 +21,10 @@
 #include <cmath>
 #include <cstdlib>
 
-#include "hx_common.h"
-#include "hx_fft_core.h"
+#include "hx_sht_common.h"
 
 namespace hx {
 using namespace hxfft;
-
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
-constexpr int LA_WAVES = 8;       // waves (64-ring-pair blocks) per Legendre workgroup
-constexpr int TILE_LD = 64;       // LDS row stride (doubles) of a 16 x 64 lambda tile (XOR-swizzled columns)
-constexpr int LBLK = 32;          // l values per block (16 even-parity + 16 odd-parity rows)
-constexpr int NCOL = 16;          // MFMA N: real columns per batch (8 spin-0 maps / 4 spin-2 fields)
-constexpr double SC_BIG = 0x1p+300, SC_SMALL = 0x1p-300;
-
-struct LegTask {
-    int m;
-    int rb0;          // first 64-ring-pair block
-    int nrb;          // blocks (waves) used, 1..LA_WAVES
-    int pad;
-    long long pout;   // first row of this task in the partial buffer
-};
-
-struct MTasks {
-    int first, count;
-};
-
-// Device-side view of a plan (POD, passed by value to kernels).
-struct PlanDev {
-    int nside, lmax, nrp, nrp_pad, twN;
-    long long npix, ny;
-    const double *z, *omz, *sth, *rwdef;
-    const int *nsub, *shifted;
-    const long long *startN, *startS, *bhat_off;
-    const double2 *tw, *bhat;
-    const double *mfac, *kfac2;
-    const double2 *rec0;
-    const double4 *rec2;
-};
-
-}  // namespace hx
-
-struct hx_plan {
-    int nside = 0, lmax = 0, max_comp = 0;
-    int nrp = 0, nrp_pad = 0, nrb = 0, twN = 1;
-    long long npix = 0, ny = 0, nlm = 0;
-    size_t lds_fft = 0;
-    hx::DevBuf z, omz, sth, rwdef, nsub, shifted, startN, startS, bhat_off, tw, bhat, mfac, kfac2, rec0, rec2, cn0, al0, cn2, al2;
-    std::vector<double> h_sth, h_z;
-    std::vector<int> h_nsub;
-    struct TaskSet {
-        bool built = false;
-        std::vector<hx::LegTask> tasks;
-        std::vector<hx::MTasks> of_m;
-        hx::DevBuf d_tasks, d_of_m;
-        long long rows = 0;
-    } ts[2];
-    hx::DevBuf Y, F, partial, d_rw, stage_maps, stage_alms, resid, Fsyn;
-    hx::PlanDev dev() const;
-};
-
-namespace hx {
-
-__host__ __device__ inline long long almidx(int lmax, int l, int m)
-{
-    return (long long)m * (2 * lmax + 1 - m) / 2 + l;
-}
 
 // =====================================================================================
 // table initialisation kernels
@@ -193,13 +131,6 @@ __global__ void k_init_rec2(int lmax, double4 *__restrict__ rec)
     }
 }
 
-__device__ inline double2 expipi(double x)
-{
-    double s, c;
-    sincospi(x, &s, &c);
-    return make_double2(c, s);
-}
-
 // In-LDS FFT drivers (all threads of the block participate)
 __device__ inline void lds_fft_dif(double2 *buf, int M, const double2 *__restrict__ tw, int twN)
 {
@@ -302,412 +233,6 @@ __global__ __launch_bounds__(512) void k_ring_subdft(PlanDev P, const double *__
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
         double2 cz = expipi(-(double)chirp_num(k, n) / (double)n);
         out[k] = cscale(cmul(buf[k], cz), inv);
-    }
-}
-
-// =====================================================================================
-// 2. combine: Y -> F operands
-// =====================================================================================
-__device__ inline double2 ring_mode(const PlanDev &P, const double2 *__restrict__ Yc, int rp, int n,
-                                    int mm)
-{
-    // Z[mm] with X[4k+r] = Y_r[k]
-    return Yc[P.startN[rp] + (long long)(mm & 3) * n + (mm >> 2)];
-}
-
-// F_N(m), F_S(m) of ring pair rp for component c, including phase and quadrature weight
-__device__ inline void ring_modes_ns(const PlanDev &P, const double2 *__restrict__ Y, int c, int rp,
-                                     int m, double w, double2 &FN, double2 &FS)
-{
-    const int n = P.nsub[rp];
-    const int nphi = 4 * n;
-    const int mm = m % nphi, mc = (nphi - mm) % nphi;
-    const double2 *Yc = Y + (long long)c * P.ny;
-    const double2 a = ring_mode(P, Yc, rp, n, mm), b = cconj(ring_mode(P, Yc, rp, n, mc));
-    double2 xn = cscale(cadd(a, b), 0.5);
-    double2 d = cscale(csub(a, b), 0.5);
-    double2 xs = mul_mi(d);  // (a-b)/(2i)
-    double2 ph = make_double2(w, 0.0);
-    if (P.shifted[rp]) ph = cscale(expipi(-(double)(m % (2 * nphi)) / (double)nphi), w);
-    FN = cmul(xn, ph);
-    FS = P.startS[rp] >= 0 ? cmul(xs, ph) : make_double2(0.0, 0.0);
-}
-
-// grid: x = m, y = tiles of 32 ring pairs; block 256 = 32 ring pairs x 8 slots
-template <int SPIN>
-__global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double2 *__restrict__ Y,
-                                                         int ncomp, const double *__restrict__ rw,
-                                                         double *__restrict__ F)
-{
-    const int m = blockIdx.x;
-    const int rp = blockIdx.y * 32 + (threadIdx.x >> 3);
-    const int slot = threadIdx.x & 7;
-    if (rp >= P.nrp_pad) return;
-    const bool live = rp < P.nrp;
-    const double w = live ? (rw ? rw[rp] : 1.0) * (4.0 * M_PI / (double)P.npix) : 0.0;
-    if (SPIN == 0) {
-        double2 s = make_double2(0.0, 0.0), d = s;
-        if (live && slot < ncomp) {
-            double2 fn, fs;
-            ring_modes_ns(P, Y, slot, rp, m, w, fn, fs);
-            s = cadd(fn, fs);
-            d = csub(fn, fs);
-        }
-        double *base = F + (((long long)m * P.nrp_pad + rp) * 2) * NCOL + 2 * slot;
-        *reinterpret_cast<double2 *>(base) = s;
-        *reinterpret_cast<double2 *>(base + NCOL) = d;
-    } else {
-        const int f = slot >> 1, op = slot & 1;
-        double4 o0 = make_double4(0.0, 0.0, 0.0, 0.0), o1 = o0;
-        if (live && 2 * f + 1 < ncomp) {
-            double2 qn, qs, un, us;
-            ring_modes_ns(P, Y, 2 * f, rp, m, w, qn, qs);
-            ring_modes_ns(P, Y, 2 * f + 1, rp, m, w, un, us);
-            // P+ = -(Q + iU)/2, P- = -(Q - iU)/2
-            double2 ppn = cscale(cadd(qn, mul_pi(un)), -0.5), pmn = cscale(csub(qn, mul_pi(un)), -0.5);
-            double2 pps = cscale(cadd(qs, mul_pi(us)), -0.5), pms = cscale(csub(qs, mul_pi(us)), -0.5);
-            // B+(P) = [Pr, Pi, Pi, -Pr]   (E_re, E_im, B_re, B_im columns, lambda^+ operand)
-            // B-(P) = [Pr, Pi, -Pi, Pr]   (lambda^- operand)
-            double4 x, y;
-            if (op == 0) {
-                x = make_double4(ppn.x, ppn.y, ppn.y, -ppn.x);  // B+(P+_N)
-                y = make_double4(pms.x, pms.y, -pms.y, pms.x);  // B-(P-_S)
-            } else {
-                x = make_double4(pmn.x, pmn.y, -pmn.y, pmn.x);  // B-(P-_N)
-                y = make_double4(pps.x, pps.y, pps.y, -pps.x);  // B+(P+_S)
-            }
-            o0 = make_double4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
-            o1 = make_double4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
-        }
-        double *base = F + ((((long long)m * P.nrp_pad + rp) * 2) * 2 + op) * NCOL + 4 * f;
-        *reinterpret_cast<double4 *>(base) = o0;
-        *reinterpret_cast<double4 *>(base + 2 * NCOL) = o1;
-    }
-}
-
-// =====================================================================================
-// 3. Legendre analysis on FP64 MFMA
-// =====================================================================================
-struct SVal {
-    double v;
-    int e;  // value = v * 2^(300 e)
-};
-
-__device__ inline void snorm_small(SVal &s)
-{
-    if (s.v != 0.0)
-        while (fabs(s.v) < SC_SMALL) {
-            s.v *= SC_BIG;
-            s.e -= 1;
-        }
-}
-
-// x^n for 0 <= x <= 1 with extended exponent
-__device__ inline SVal spow(double x, int n)
-{
-    SVal r = {1.0, 0}, b = {x, 0};
-    while (n) {
-        if (n & 1) {
-            r.v *= b.v;
-            r.e += b.e;
-            snorm_small(r);
-        }
-        n >>= 1;
-        if (n) {
-            b.v *= b.v;
-            b.e *= 2;
-            snorm_small(b);
-        }
-    }
-    return r;
-}
-
-__device__ inline double sval_true(double v, int e)
-{
-    return e == 0 ? v : (e == -1 ? v * SC_SMALL : 0.0);
-}
-
-struct LegParams {
-    PlanDev P;
-    const LegTask *__restrict__ tasks;
-    const double *__restrict__ F;
-    const double2 *__restrict__ rec0;
-    const double4 *__restrict__ rec2;
-    double *__restrict__ partial;
-    int ablate;  // diagnostic only (HX_ABLATE): 1 skip MFMA, 2 skip recursion, 4 skip flush, 8 count paths
-    unsigned long long *counters;  // [dead, live, mixed, wave_off] block counts when ablate & 8
-};
-
-// broadcast lane `src` of a wave-distributed double to all lanes (-> SGPR pair)
-__device__ inline double bcast(double v, int src)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
-
-template <int SPIN>
-__global__ __launch_bounds__(LA_WAVES * 64) void k_legendre_analysis(LegParams A,
-                                                                   const double2 *__restrict__ coefn,
-                                                                   const double *__restrict__ alphan)
-{
-    constexpr int NOP = SPIN == 0 ? 1 : 2;
-    __shared__ double tiles[LA_WAVES][2][16][TILE_LD];  // 128 KiB; after the MFMA phase the first
-                                                        // 4 KiB of each wave's tiles carry its D tiles
-    __shared__ double2 coefs[2][LBLK];                  // recursion coefficients of this / the next block
-    const PlanDev &P = A.P;
-    const LegTask task = A.tasks[blockIdx.x];
-    const int m = task.m, lmax = P.lmax;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool wave_on = w < task.nrb;
-    const int rb = task.rb0 + (wave_on ? w : 0);
-    const int rp = rb * 64 + lane;
-    const bool valid = wave_on && rp < P.nrp;
-    const double x = valid ? P.z[rp] : 0.0;
-    const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
-    const int off = (l0 + m) & 1;
-    const long long cb = almidx(lmax, 0, m);
-
-    // ---- B operands: F[m][rp][par][op][16], lane (k = lane>>4, j = lane&15) ----------
-    double fr[NOP][2][16];
-    {
-        const int j = lane & 15, k = lane >> 4;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const long long row = (long long)m * P.nrp_pad + rb * 64 + q + 16 * k;
-#pragma unroll
-            for (int par = 0; par < 2; ++par)
-#pragma unroll
-                for (int op = 0; op < NOP; ++op)
-                    fr[op][par][q] = wave_on ? A.F[((row * 2 + par) * NOP + op) * NCOL + j] : 0.0;
-        }
-    }
-
-    // ---- seeds ----------------------------------------------------------------------
-    double vc[NOP], vp[NOP];
-    int sc[NOP];
-    if (SPIN == 0) {
-        SVal s = {0.0, 0};
-        if (valid) {
-            s = spow(P.sth[rp], m);
-            s.v *= P.mfac[m];
-        }
-        vc[0] = s.v; vp[0] = 0.0; sc[0] = valid ? s.e : -100;
-    } else {
-        SVal sp = {0.0, -100}, sm = {0.0, -100};
-        if (valid) {
-            const double sth = P.sth[rp], omx = P.omz[rp], opx = 2.0 - omx;
-            const double nrm = sqrt((2.0 * l0 + 1.0) / (4.0 * M_PI));
-            if (m == 0) {
-                double d = 0.61237243569579452455 * sth * sth;  // sqrt(6)/4
-                sp.v = sm.v = nrm * d; sp.e = sm.e = 0;
-            } else if (m == 1) {
-                sp.v = nrm * (-0.5 * omx * sth); sp.e = 0;
-                sm.v = nrm * (0.5 * opx * sth);  sm.e = 0;
-            } else {
-                SVal b = spow(sth, m - 2);
-                b.v *= P.kfac2[m] * nrm * ((m & 1) ? -1.0 : 1.0);
-                sp.v = b.v * (0.25 * omx * omx); sp.e = b.e;
-                sm.v = b.v * (0.25 * opx * opx); sm.e = b.e;
-            }
-            snorm_small(sp);
-            snorm_small(sm);
-        }
-        vc[0] = sp.v; vp[0] = 0.0; sc[0] = sp.e;
-        if (NOP > 1) { vc[NOP - 1] = sm.v; vp[NOP - 1] = 0.0; sc[NOP - 1] = sm.e; }
-    }
-
-    double *mytile = &tiles[w][0][0][0];
-    double *myflush = mytile;
-    const int ai = lane & 15, ak = lane >> 4;
-    // tile element (row r of parity tile p, ring c) lives at ((p*16 + r)*64 + (c ^ r));
-    // MFMA q contracts the rings {q, q+16, q+32, q+48} of this wave (k = lane>>4).
-    auto mfma_block = [&](int op, double4_t (&acc)[2]) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // tile is private to the wave:
-        __builtin_amdgcn_wave_barrier();                        // order LDS writes before reads
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (A.ablate & 1) return;
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-#pragma unroll
-            for (int par = 0; par < 2; ++par) {
-                const double a = mytile[(par * 16 + ai) * TILE_LD + ((q + 16 * ak) ^ ai)];
-                acc[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[op][par][q], acc[par], 0, 0, 0);
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto scale_of = [](int e) { return e == 0 ? 1.0 : (e == -1 ? SC_SMALL : 0.0); };
-
-    // spin 0: the normalised two-step recursion mu_{l+2} = (A' x^2 + B') mu_l - mu_{l-2}
-    // (lambda_l = alpha_l mu_l) gives two independent chains (even / odd l - m) per ring,
-    // each feeding one parity tile; alpha_l is applied to the output rows at the flush.
-    // State of chain p: (wp[p], wc[p]) = mu at l-2, l; alpha_m = alpha_{m+1} = 1.
-    double wc[2] = {0.0, 0.0}, wp[2] = {0.0, 0.0};
-    const double x2 = x * x;
-    if (SPIN == 0) {
-        wc[0] = vc[0];
-        wc[1] = sqrt(2.0 * m + 3.0) * x * vc[0];  // lambda_{m+1,m} = sqrt(2m+3) x lambda_mm
-    }
-    double scf[NOP];
-#pragma unroll
-    for (int op = 0; op < NOP; ++op) scf[op] = scale_of(sc[op]);
-
-    // The coefficients are the same for every wave of the workgroup: each block's 32 entries
-    // are fetched one block ahead by threads 0..127 (one double each) and handed over through
-    // LDS, so the recursion never waits on global / scalar memory.
-    const int coff = SPIN == 0 ? 0 : 1;  // spin-2 coefficients are indexed by the target l
-    double cpre = 0.0;
-    if (threadIdx.x < 2 * LBLK)
-        (&coefs[0][0].x)[threadIdx.x] = reinterpret_cast<const double *>(coefn + cb + l0 + coff)[threadIdx.x];
-    __syncthreads();
-    int cbuf = 0;
-    for (int lb = l0; lb <= lmax; lb += LBLK, cbuf ^= 1) {
-        if (threadIdx.x < 2 * LBLK)
-            cpre = reinterpret_cast<const double *>(coefn + cb + lb + LBLK + coff)[threadIdx.x];
-        const double2 *cf = coefs[cbuf];
-        double4_t acc[2];
-        acc[0] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        acc[1] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        if (wave_on && !(A.ablate & 2)) {
-            if (SPIN == 0) {
-                const bool all_live = __all(sc[0] == 0 || !valid);
-                const bool all_dead = __all(sc[0] <= -3 || !valid);
-                if ((A.ablate & 8) && lane == 0) atomicAdd(&A.counters[all_dead ? 0 : (all_live ? 1 : 2)], 1ULL);
-                auto advance2 = [&](int j) {
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const double2 c = cf[2 * j + p];
-                        const double vn = fma(fma(c.x, x2, c.y), wc[p], -wp[p]);
-                        wp[p] = wc[p];
-                        wc[p] = vn;
-                    }
-                };
-                auto rescale = [&]() {
-                    if (__any(fabs(wc[0]) > SC_BIG || fabs(wc[1]) > SC_BIG)) {
-                        if (fabs(wc[0]) > SC_BIG || fabs(wc[1]) > SC_BIG) {
-                            wc[0] *= SC_SMALL; wp[0] *= SC_SMALL; wc[1] *= SC_SMALL; wp[1] *= SC_SMALL;
-                            sc[0] += 1;
-                            scf[0] = scale_of(sc[0]);
-                        }
-                    }
-                };
-                if (all_dead) {
-                    for (int j = 0; j < LBLK / 2; ++j) { advance2(j); rescale(); }
-                } else {
-                    if (all_live) {
-#pragma unroll
-                        for (int j = 0; j < LBLK / 2; ++j) {
-                            mytile[(0 * 16 + j) * TILE_LD + (lane ^ j)] = wc[0];
-                            mytile[(1 * 16 + j) * TILE_LD + (lane ^ j)] = wc[1];
-                            advance2(j);
-                        }
-                    } else {
-#pragma unroll 4
-                        for (int j = 0; j < LBLK / 2; ++j) {
-                            mytile[(0 * 16 + j) * TILE_LD + (lane ^ j)] = wc[0] * scf[0];
-                            mytile[(1 * 16 + j) * TILE_LD + (lane ^ j)] = wc[1] * scf[0];
-                            advance2(j);
-                            rescale();
-                        }
-                    }
-                    mfma_block(0, acc);
-                }
-            } else {
-#pragma unroll
-                for (int op = 0; op < NOP; ++op) {
-                    const bool all_live = __all(sc[op] == 0 || !valid);
-                    const bool all_dead = __all(sc[op] <= -3 || !valid);
-                    if ((A.ablate & 8) && lane == 0) atomicAdd(&A.counters[all_dead ? 0 : (all_live ? 1 : 2)], 1ULL);
-                    const double sgn = op == 0 ? 1.0 : -1.0;
-                    auto advance = [&](int s) {
-                        const double2 c = cf[s];
-                        const double vn = fma(fma(c.x, x, sgn * c.y), vc[op], -vp[op]);
-                        vp[op] = vc[op];
-                        vc[op] = vn;
-                    };
-                    auto rescale = [&]() {
-                        if (__any(fabs(vc[op]) > SC_BIG)) {
-                            if (fabs(vc[op]) > SC_BIG) {
-                                vc[op] *= SC_SMALL; vp[op] *= SC_SMALL;
-                                sc[op] += 1;
-                                scf[op] = scale_of(sc[op]);
-                            }
-                        }
-                    };
-                    if (all_dead) {
-                        for (int s = 0; s < LBLK; ++s) { advance(s); rescale(); }
-                        continue;
-                    }
-                    if (all_live) {
-#pragma unroll 8
-                        for (int s = 0; s < LBLK; ++s) {
-                            mytile[(((s + off) & 1) * 16 + (s >> 1)) * TILE_LD + (lane ^ (s >> 1))] = vc[op];
-                            advance(s);
-                        }
-                    } else {
-#pragma unroll 4
-                        for (int s = 0; s < LBLK; ++s) {
-                            mytile[(((s + off) & 1) * 16 + (s >> 1)) * TILE_LD + (lane ^ (s >> 1))] = vc[op] * scf[op];
-                            advance(s);
-                            rescale();
-                        }
-                    }
-                    mfma_block(op, acc);
-                }
-            }
-        }
-        // ---- flush: combine the waves' partial tiles through LDS ---------------------
-        // D layout of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4*reg, col = lane&15
-        if (threadIdx.x < 2 * LBLK) (&coefs[cbuf ^ 1][0].x)[threadIdx.x] = cpre;
-#pragma unroll
-        for (int par = 0; par < 2; ++par)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                myflush[par * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[par][r];
-        __syncthreads();
-        for (int t = threadIdx.x; t < 512; t += LA_WAVES * 64) {
-            const int par = t >> 8, r16 = (t >> 4) & 15, col = t & 15;
-            double s = 0.0;
-#pragma unroll
-            for (int ww = 0; ww < LA_WAVES; ++ww) s += (&tiles[ww][0][0][0])[par * 256 + r16 * 16 + col];
-            const int l = lb + 2 * r16 + (par ^ off);
-            if (l <= lmax) A.partial[(task.pout + (l - l0)) * NCOL + col] = s * alphan[cb + l];
-        }
-        __syncthreads();  // D tiles consumed: the tile buffers may be overwritten by the next block
-    }
-}
-
-// =====================================================================================
-// 4. partial sums -> alm
-// =====================================================================================
-template <int SPIN>
-__global__ __launch_bounds__(256) void k_alm_reduce(PlanDev P, const LegTask *__restrict__ tasks,
-                                                    const MTasks *__restrict__ of_m,
-                                                    const double *__restrict__ partial, int ncomp,
-                                                    const double *__restrict__ fl, int add,
-                                                    double2 *__restrict__ alm, long long alm_stride)
-{
-    const int m = blockIdx.x, lmax = P.lmax;
-    const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
-    const MTasks mt = of_m[m];
-    const int nl = lmax - m + 1;
-    for (int i = threadIdx.x; i < nl * 8; i += blockDim.x) {
-        const int l = m + (i >> 3), c = i & 7;
-        if (c >= ncomp) continue;
-        double2 v = make_double2(0.0, 0.0);
-        if (l >= l0) {
-            // spin 0: comp c -> cols 2c,2c+1; spin 2: comp 2f+e -> cols 4f+2e, +1 (== 2c)
-            for (int t = 0; t < mt.count; ++t) {
-                const double *p = partial + (tasks[mt.first + t].pout + (l - l0)) * NCOL + 2 * c;
-                v.x += p[0];
-                v.y += p[1];
-            }
-            if (fl) { v.x *= fl[l]; v.y *= fl[l]; }
-        }
-        double2 *dst = alm + (long long)c * alm_stride + almidx(lmax, l, m);
-        if (add) { double2 o = *dst; v.x += o.x; v.y += o.y; }
-        *dst = v;
     }
 }
 
@@ -921,72 +446,6 @@ PlanDev hx_plan::dev() const
     return P;
 }
 
-template <class T>
-static int upload(DevBuf &b, const std::vector<T> &v)
-{
-    HX_TRY(b.alloc(sizeof(T) * std::max<size_t>(v.size(), 1)));
-    if (!v.empty()) HX_HIP(hipMemcpy(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
-    return HX_OK;
-}
-
-// libsharp's published heuristic for the largest m that contributes on a ring
-// (sharp_get_mlim): rings with m > mlim are skipped.
-static int ring_mlim(int lmax, int spin, double sth, double cth)
-{
-    double ofs = lmax * 0.01;
-    if (ofs < 100.) ofs = 100.;
-    double b = -2 * spin * fabs(cth);
-    double t1 = lmax * sth + ofs;
-    double c = (double)spin * spin - t1 * t1;
-    double discr = b * b - 4 * c;
-    if (discr <= 0) return lmax;
-    double res = (-b + sqrt(discr)) / 2.;
-    if (res > lmax) res = lmax;
-    return (int)(res + 0.5);
-}
-
-static int build_tasks(hx_plan *pl, int spin)
-{
-    hx_plan::TaskSet &ts = pl->ts[spin ? 1 : 0];
-    if (ts.built) return HX_OK;
-    const int lmax = pl->lmax;
-    ts.tasks.clear();
-    ts.of_m.assign(lmax + 1, MTasks{0, 0});
-    std::vector<std::vector<LegTask>> per_m(lmax + 1);
-    for (int m = 0; m <= lmax; ++m) {
-        const int l0 = spin == 0 ? m : std::max(m, 2);
-        if (l0 > lmax) continue;
-        int first = pl->nrp;  // first active ring pair (rings are ordered pole -> equator)
-        for (int rp = 0; rp < pl->nrp; ++rp)
-            if (ring_mlim(lmax, spin, pl->h_sth[rp], pl->h_z[rp]) >= m) { first = rp; break; }
-        if (first >= pl->nrp) first = pl->nrp - 1;
-        int rb = first / 64;
-        while (rb < pl->nrb) {
-            LegTask t;
-            t.m = m; t.rb0 = rb; t.nrb = std::min(LA_WAVES, pl->nrb - rb); t.pad = 0; t.pout = 0;
-            per_m[m].push_back(t);
-            rb += t.nrb;
-        }
-    }
-    // partial-buffer rows and per-m index (tasks of one m stay contiguous)
-    long long rows = 0;
-    for (int m = 0; m <= lmax; ++m) {
-        const int l0 = spin == 0 ? m : std::max(m, 2);
-        ts.of_m[m].first = (int)ts.tasks.size();
-        ts.of_m[m].count = (int)per_m[m].size();
-        for (auto &t : per_m[m]) {
-            t.pout = rows;
-            rows += (lmax - l0 + 1);
-            ts.tasks.push_back(t);
-        }
-    }
-    ts.rows = rows;
-    HX_TRY(upload(ts.d_tasks, ts.tasks));
-    HX_TRY(upload(ts.d_of_m, ts.of_m));
-    ts.built = true;
-    return HX_OK;
-}
-
 extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
 {
     if (ensure_ready() != HX_OK) return nullptr;
@@ -999,7 +458,6 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
     pl->npix = 12LL * nside * nside;
     pl->nrp = 2 * nside;
     pl->nrp_pad = (pl->nrp + 63) / 64 * 64;
-    pl->nrb = pl->nrp_pad / 64;
     pl->nlm = (long long)(lmax + 1) * (lmax + 2) / 2;
     const long long ns = nside, ncap = 2 * ns * (ns - 1);
     std::vector<double> z(pl->nrp), omz(pl->nrp), sth(pl->nrp), rw(pl->nrp, 1.0);
@@ -1116,10 +574,11 @@ extern "C" int64_t hx_plan_scratch_bytes(const hx_plan *pl)
 {
     if (!pl) return 0;
     return (int64_t)(pl->Y.bytes + pl->F.bytes + pl->partial.bytes + pl->rec0.bytes + pl->rec2.bytes + pl->cn0.bytes + pl->al0.bytes + pl->cn2.bytes + pl->al2.bytes +
-                     pl->bhat.bytes + pl->stage_maps.bytes + pl->stage_alms.bytes + pl->resid.bytes + pl->Fsyn.bytes);
+                     pl->bhat.bytes + pl->resid.bytes + pl->Fsyn.bytes);
 }
 
-static int ensure_rec2(hx_plan *pl)
+namespace hx {
+int ensure_rec2(hx_plan *pl)
 {
     if (pl->rec2.p) return HX_OK;
     HX_TRY(pl->rec2.alloc(sizeof(double4) * (pl->nlm + 128)));
@@ -1134,72 +593,15 @@ static int ensure_rec2(hx_plan *pl)
     return HX_OK;
 }
 
-// ---- one analysis pass over a batch of <= 8 components (device pointers) -------------
-static int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 *d_alms,
-                          const double *d_rw, const double *d_pw, const double *d_fl, int add)
+int launch_ring_subdft_maps(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, double2 *Y)
 {
-    hipStream_t st = rt().stream;
-    const int sidx = spin ? 1 : 0, nop = spin ? 2 : 1;
-    HX_TRY(build_tasks(pl, spin));
-    if (spin) HX_TRY(ensure_rec2(pl));
-    hx_plan::TaskSet &ts = pl->ts[sidx];
-    HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * 8));
-    HX_TRY(pl->F.alloc(sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * 2 * 2 * NCOL));
-    HX_TRY(pl->partial.alloc(sizeof(double) * (size_t)std::max<long long>(pl->ts[0].rows, pl->ts[1].rows) * NCOL));
-    PlanDev P = pl->dev();
-    {
-        ProfScope ps("ring_fft");
-        hipLaunchKernelGGL(k_ring_subdft<0>, dim3(pl->nrp, 4, nb), dim3(512), pl->lds_fft, st, P, d_maps, d_pw,
-                           (const double2 *)nullptr, pl->Y.as<double2>());
-    }
-    {
-        ProfScope ps("fourier_combine");
-        dim3 grid(pl->lmax + 1, pl->nrp_pad / 32);
-        if (spin == 0)
-            hipLaunchKernelGGL(k_fourier_combine<0>, grid, dim3(256), 0, st, P, pl->Y.as<double2>(), nb, d_rw, pl->F.as<double>());
-        else
-            hipLaunchKernelGGL(k_fourier_combine<2>, grid, dim3(256), 0, st, P, pl->Y.as<double2>(), nb, d_rw, pl->F.as<double>());
-    }
-    {
-        ProfScope ps("legendre_analysis");
-        ProfScope ps2(spin == 0 ? "legendre_analysis_s0" : "legendre_analysis_s2");
-        LegParams A;
-        A.P = P; A.tasks = ts.d_tasks.as<LegTask>(); A.F = pl->F.as<double>(); A.partial = pl->partial.as<double>();
-        A.rec0 = pl->rec0.as<double2>(); A.rec2 = pl->rec2.as<double4>();
-        {
-            const char *e = getenv("HX_ABLATE");
-            A.ablate = e ? atoi(e) : 0;
-            A.counters = nullptr;
-            if (A.ablate & 8) {
-                HX_TRY(pl->d_rw.alloc(64));
-                HX_HIP(hipMemsetAsync(pl->d_rw.p, 0, 64, st));
-                A.counters = pl->d_rw.as<unsigned long long>();
-            }
-        }
-        if (spin == 0)
-            hipLaunchKernelGGL(k_legendre_analysis<0>, dim3((unsigned)ts.tasks.size()), dim3(LA_WAVES * 64), 0, st, A, (const double2 *)pl->cn0.as<double2>(), (const double *)pl->al0.as<double>());
-        else
-            hipLaunchKernelGGL(k_legendre_analysis<2>, dim3((unsigned)ts.tasks.size()), dim3(LA_WAVES * 64), 0, st, A, (const double2 *)pl->cn2.as<double2>(), (const double *)pl->al2.as<double>());
-    }
-    if (pl->d_rw.p && getenv("HX_ABLATE") && (atoi(getenv("HX_ABLATE")) & 8)) {
-        unsigned long long h[4] = {0, 0, 0, 0};
-        HX_HIP(hipStreamSynchronize(st));
-        HX_HIP(hipMemcpy(h, pl->d_rw.p, 32, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[hx] spin %d legendre wave-blocks: dead %llu live %llu mixed %llu\n", spin, h[0], h[1], h[2]);
-    }
-    {
-        ProfScope ps("alm_reduce");
-        if (spin == 0)
-            hipLaunchKernelGGL(k_alm_reduce<0>, dim3(pl->lmax + 1), dim3(256), 0, st, P, ts.d_tasks.as<LegTask>(),
-                               ts.d_of_m.as<MTasks>(), pl->partial.as<double>(), nb, d_fl, add, d_alms, pl->nlm);
-        else
-            hipLaunchKernelGGL(k_alm_reduce<2>, dim3(pl->lmax + 1), dim3(256), 0, st, P, ts.d_tasks.as<LegTask>(),
-                               ts.d_of_m.as<MTasks>(), pl->partial.as<double>(), nb, d_fl, add, d_alms, pl->nlm);
-    }
-    (void)nop;
+    ProfScope ps("ring_fft");
+    hipLaunchKernelGGL(k_ring_subdft<0>, dim3(pl->nrp, 4, nb), dim3(512), pl->lds_fft, rt().stream, pl->dev(), d_maps, d_pw,
+                       (const double2 *)nullptr, Y);
     HX_HIP(hipGetLastError());
     return HX_OK;
 }
+}  // namespace hx
 
 // ---- one synthesis pass over a batch (device pointers).  If d_ref != NULL the output is
 // the residual ref - synth (Jacobi iteration). -------------------------------------------
@@ -1219,7 +621,7 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
     fr.assign(pl->lmax + 1, MTasks{0, 0});
     for (int m = 0; m <= pl->lmax; ++m) {
         int first = 0;
-        if (ts.of_m[m].count > 0) first = ts.tasks[ts.of_m[m].first].rb0 * 64;
+        if (ts.of_m[m].count > 0) first = ts.tasks[ts.of_m[m].first].rb0 * RBLK;
         fr[m].first = first;
     }
     DevBuf d_fr;
@@ -1287,8 +689,11 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
     HX_TRY(valms.bind(alms, sizeof(double2) * (size_t)ncomp * pl->nlm));
     DevBuf resid;
     if (niter > 0) HX_TRY(resid.alloc(sizeof(double) * (size_t)8 * pl->npix));
-    for (int c0 = 0; c0 < ncomp; c0 += 8) {
-        const int nb = std::min(8, ncomp - c0);
+    // without iterations a launch takes 8*NGMAX components; the synthesis of the Jacobi
+    // iterations works on 8 at a time
+    const int bs = niter > 0 ? 8 : analysis_max_comp(spin);
+    for (int c0 = 0; c0 < ncomp; c0 += bs) {
+        const int nb = std::min(bs, ncomp - c0);
         const double *dm = vmaps.as<double>() + (size_t)c0 * pl->npix;
         double2 *da = valms.as<double2>() + (size_t)c0 * pl->nlm;
         // the filter fl is applied once, after the last iteration

@@ -1,0 +1,157 @@
+// hx_sht_common.h -- plan structure, device-side plan view and scaled-arithmetic helpers
+// shared by hx_sht.hip (plan, ring Fourier stage, synthesis, C ABI) and hx_analysis.hip
+// (Legendre analysis on FP64 MFMA).
+#pragma once
+#include <vector>
+
+#include "hx_common.h"
+#include "hx_fft_core.h"
+
+namespace hx {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int LBLK = 32;   // l values per block (16 even-parity + 16 odd-parity rows)
+constexpr int NCOL = 16;   // MFMA N: real columns per group (8 spin-0 maps / 4 spin-2 fields)
+constexpr int NGMAX = 2;   // column groups per analysis launch
+constexpr int RBLK = 32;   // ring pairs per wave of the Legendre analysis kernel
+constexpr double SC_BIG = 0x1p+300, SC_SMALL = 0x1p-300;
+
+struct LegTask {
+    int m;
+    int rb0;          // first 32-ring-pair block
+    int nrb;          // blocks (waves) used
+    int pad;
+    long long pout;   // first row of this task in the partial buffer
+};
+
+struct MTasks {
+    int first, count;
+};
+
+// Device-side view of a plan (POD, passed by value to kernels).
+struct PlanDev {
+    int nside, lmax, nrp, nrp_pad, twN;
+    long long npix, ny;
+    const double *z, *omz, *sth, *rwdef;
+    const int *nsub, *shifted;
+    const long long *startN, *startS, *bhat_off;
+    const double2 *tw, *bhat;
+    const double *mfac, *kfac2;
+    const double2 *rec0;
+    const double4 *rec2;
+};
+
+__host__ __device__ inline long long almidx(int lmax, int l, int m)
+{
+    return (long long)m * (2 * lmax + 1 - m) / 2 + l;
+}
+
+__device__ inline double2 expipi(double x)
+{
+    double s, c;
+    sincospi(x, &s, &c);
+    return make_double2(c, s);
+}
+
+// value = v * 2^(300 e): lambda_mm ~ (sin theta)^m underflows f64 for m ~ 10^3..10^4
+struct SVal {
+    double v;
+    int e;
+};
+
+__device__ inline void snorm_small(SVal &s)
+{
+    if (s.v != 0.0)
+        while (fabs(s.v) < SC_SMALL) {
+            s.v *= SC_BIG;
+            s.e -= 1;
+        }
+}
+
+// x^n for 0 <= x <= 1 with extended exponent
+__device__ inline SVal spow(double x, int n)
+{
+    SVal r = {1.0, 0}, b = {x, 0};
+    while (n) {
+        if (n & 1) {
+            r.v *= b.v;
+            r.e += b.e;
+            snorm_small(r);
+        }
+        n >>= 1;
+        if (n) {
+            b.v *= b.v;
+            b.e *= 2;
+            snorm_small(b);
+        }
+    }
+    return r;
+}
+
+__device__ inline double sval_true(double v, int e)
+{
+    return e == 0 ? v : (e == -1 ? v * SC_SMALL : 0.0);
+}
+
+// seeds of the spin-2 recursions at l0 = max(m,2): sqrt((2 l0+1)/4pi) d^{l0}_{m,-2} and d^{l0}_{m,+2}
+__device__ inline void spin2_seeds(int m, double sth, double omx, double kfac2m, SVal &sp, SVal &sm)
+{
+    const int l0 = m > 2 ? m : 2;
+    const double opx = 2.0 - omx;
+    const double nrm = sqrt((2.0 * l0 + 1.0) / (4.0 * M_PI));
+    if (m == 0) {
+        const double d = 0.61237243569579452455 * sth * sth;  // sqrt(6)/4 sin^2
+        sp.v = sm.v = nrm * d; sp.e = sm.e = 0;
+    } else if (m == 1) {
+        sp.v = nrm * (-0.5 * omx * sth); sp.e = 0;
+        sm.v = nrm * (0.5 * opx * sth);  sm.e = 0;
+    } else {
+        SVal b = spow(sth, m - 2);
+        b.v *= kfac2m * nrm * ((m & 1) ? -1.0 : 1.0);
+        sp.v = b.v * (0.25 * omx * omx); sp.e = b.e;
+        sm.v = b.v * (0.25 * opx * opx); sm.e = b.e;
+    }
+    snorm_small(sp);
+    snorm_small(sm);
+}
+
+template <class T>
+inline int upload(DevBuf &b, const std::vector<T> &v)
+{
+    HX_TRY(b.alloc(sizeof(T) * (v.size() > 0 ? v.size() : 1)));
+    if (!v.empty()) HX_HIP(hipMemcpy(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    return HX_OK;
+}
+
+}  // namespace hx
+
+struct hx_plan {
+    int nside = 0, lmax = 0, max_comp = 0;
+    int nrp = 0, nrp_pad = 0, twN = 1;
+    long long npix = 0, ny = 0, nlm = 0;
+    size_t lds_fft = 0;
+    hx::DevBuf z, omz, sth, rwdef, nsub, shifted, startN, startS, bhat_off, tw, bhat, mfac, kfac2, rec0, rec2, cn0, al0, cn2, al2;
+    std::vector<double> h_sth, h_z;
+    std::vector<int> h_nsub;
+    struct TaskSet {
+        bool built = false;
+        std::vector<hx::LegTask> tasks;       // ordered by m; tasks of one m contiguous
+        std::vector<hx::MTasks> of_m;
+        std::vector<long long> rows_before_m; // partial rows of all tasks with smaller m (size lmax+2)
+        hx::DevBuf d_tasks, d_of_m;
+    } ts[2];
+    hx::DevBuf Y, F, partial, d_dbg, resid, Fsyn;
+    hx::PlanDev dev() const;
+};
+
+namespace hx {
+// hx_sht.hip
+int ensure_rec2(hx_plan *pl);
+int launch_ring_subdft_maps(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, double2 *Y);
+// hx_analysis.hip
+int build_tasks(hx_plan *pl, int spin);
+int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 *d_alms, const double *d_rw,
+                   const double *d_pw, const double *d_fl, int add);
+int analysis_max_comp(int spin);
+}  // namespace hx
