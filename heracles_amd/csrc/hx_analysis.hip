@@ -144,6 +144,7 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
     constexpr int NW = C::NW, NT = C::NT, NOP = C::NOP, NCOLS = NCOL * NG;
     __shared__ double tiles[NW][NT][16][64];  // 128 KiB; after the MFMA phase each wave's tiles carry its D tiles
     __shared__ double2 coefs[2][LBLK];        // recursion coefficients of this / the next block
+    __shared__ double alphas[2][LBLK];        // output scalings alpha_l of this / the next block
     const PlanDev &P = A.P;
     const LegTask task = A.tasks[blockIdx.x];
     const int m = task.m, lmax = P.lmax;
@@ -204,14 +205,24 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
     // The coefficients are the same for every wave: each block's 32 entries are fetched one
     // block ahead by threads 0..63 (one double each) and handed over through LDS.
     const int coff = SPIN == 0 ? 0 : 1;  // spin-2 coefficients are indexed by the target l
-    double cpre = 0.0;
+    // Work-group barrier that waits for this wave's LDS traffic only: global stores / loads in
+    // flight (partial sums, prefetches) must not hold every wave at the barrier.
+    auto lds_barrier = []() {
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+    };
+    double cpre = 0.0, apre = 0.0;
     if (threadIdx.x < 2 * LBLK)
         (&coefs[0][0].x)[threadIdx.x] = reinterpret_cast<const double *>(coefn + cb + l0 + coff)[threadIdx.x];
+    else if (threadIdx.x < 3 * LBLK)
+        alphas[0][threadIdx.x - 2 * LBLK] = alphan[cb + l0 + (threadIdx.x - 2 * LBLK)];
     __syncthreads();
     int cbuf = 0;
     for (int lb = l0; lb <= lmax; lb += LBLK, cbuf ^= 1) {
         if (threadIdx.x < 2 * LBLK)
             cpre = reinterpret_cast<const double *>(coefn + cb + lb + LBLK + coff)[threadIdx.x];
+        else if (threadIdx.x < 3 * LBLK)
+            apre = alphan[cb + lb + LBLK + (threadIdx.x - 2 * LBLK)];
         const double2 *cf = coefs[cbuf];
         double4_t acc[NG][2];
 #pragma unroll
@@ -290,7 +301,10 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
         }
         // ---- flush: combine the waves' D tiles through LDS (fixed order) --------------------
         // D layout of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4*reg, col = lane&15
-        if (threadIdx.x < 2 * LBLK) (&coefs[cbuf ^ 1][0].x)[threadIdx.x] = cpre;
+        if (threadIdx.x < 2 * LBLK)
+            (&coefs[cbuf ^ 1][0].x)[threadIdx.x] = cpre;
+        else if (threadIdx.x < 3 * LBLK)
+            alphas[cbuf ^ 1][threadIdx.x - 2 * LBLK] = apre;
 #pragma unroll
         for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     mytile[(g * 2 + par) * 256 + (ak + 4 * r) * 16 + ai] = acc[g][par][r];
-        __syncthreads();
+        lds_barrier();
         for (int t = threadIdx.x; t < NG * 512; t += NW * 64) {
             const int g = t >> 9, par = (t >> 8) & 1, r16 = (t >> 4) & 15, col = t & 15;
             if (g >= A.ng) continue;
@@ -307,9 +321,9 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
             for (int ww = 0; ww < NW; ++ww) s += (&tiles[ww][0][0][0])[(g * 2 + par) * 256 + r16 * 16 + col];
             const int l = lb + 2 * r16 + (par ^ off);
             if (l <= lmax)
-                A.partial[(task.pout - A.row0 + (l - l0)) * (NCOL * A.ng) + g * NCOL + col] = s * alphan[cb + l];
+                A.partial[(task.pout - A.row0 + (l - l0)) * (NCOL * A.ng) + g * NCOL + col] = s * alphas[cbuf][l - lb];
         }
-        __syncthreads();  // D tiles consumed: the tile buffers may be overwritten by the next block
+        lds_barrier();  // D tiles consumed: the tile buffers may be overwritten by the next block
     }
     (void)NCOLS;
 }
@@ -367,7 +381,9 @@ static int ring_mlim(int lmax, int spin, double sth, double cth)
     return (int)(res + 0.5);
 }
 
-int analysis_max_comp(int) { return 8 * NGMAX; }
+// spin 0: one column group per launch (a second group does not fit 128 VGPRs at 4 waves/SIMD);
+// spin 2: two groups (8 fields) share one recursion pass.
+int analysis_max_comp(int spin) { return spin == 0 ? 8 : 8 * NGMAX; }
 
 int build_tasks(hx_plan *pl, int spin)
 {
