@@ -131,17 +131,30 @@ __global__ void k_init_rec2(int lmax, double4 *__restrict__ rec)
     }
 }
 
-// In-LDS FFT drivers (all threads of the block participate)
+// In-LDS FFT drivers (all threads of the block participate): fused radix-4 stages, plus one
+// radix-2 stage when log2(M) is odd.  Same data layout / bit-reversed order as pure radix-2
+// (tests/csrc/test_fft_core.cpp runs this exact schedule on the host).
 __device__ inline void lds_fft_dif(double2 *buf, int M, const double2 *__restrict__ tw, int twN)
 {
-    for (int h = M >> 1; h >= 1; h >>= 1) {
+    int h = M >> 1;
+    if (ilog2(M) & 1) {
         for (int i = threadIdx.x; i < (M >> 1); i += blockDim.x) dif_butterfly(buf, i, h, tw, twN);
+        __syncthreads();
+        h >>= 1;
+    }
+    for (h >>= 1; h >= 1; h >>= 2) {
+        for (int i = threadIdx.x; i < (M >> 2); i += blockDim.x) dif4_butterfly(buf, i, h, tw, twN);
         __syncthreads();
     }
 }
 __device__ inline void lds_fft_dit_inv(double2 *buf, int M, const double2 *__restrict__ tw, int twN)
 {
-    for (int h = 1; h <= (M >> 1); h <<= 1) {
+    int h = 1;
+    for (; 4 * h <= M; h <<= 2) {
+        for (int i = threadIdx.x; i < (M >> 2); i += blockDim.x) dit4_inv_butterfly(buf, i, h, tw, twN);
+        __syncthreads();
+    }
+    if (2 * h <= M) {
         for (int i = threadIdx.x; i < (M >> 1); i += blockDim.x) dit_inv_butterfly(buf, i, h, tw, twN);
         __syncthreads();
     }
@@ -175,14 +188,15 @@ __global__ __launch_bounds__(512) void k_init_bhat(PlanDev P, const int *__restr
 // MODE 0: input = real maps (N ring -> real part, S ring -> imaginary part)
 // MODE 1: input = complex spectrum Zc[c][ny-layout natural order] (synthesis: conj trick)
 template <int MODE>
-__global__ __launch_bounds__(512) void k_ring_subdft(PlanDev P, const double *__restrict__ maps,
-                                                     const double *__restrict__ pixw,
-                                                     const double2 *__restrict__ zin,
-                                                     double2 *__restrict__ Y)
+__global__ __launch_bounds__(1024) void k_ring_subdft(PlanDev P, const int *__restrict__ rp_list,
+                                                      const double *__restrict__ maps,
+                                                      const double *__restrict__ pixw,
+                                                      const double2 *__restrict__ zin,
+                                                      double2 *__restrict__ Y)
 {
     extern __shared__ double2 buf[];
-    const int rp = P.nrp - 1 - (int)blockIdx.x;  // long (equatorial) rings first
-    const int r = blockIdx.y, c = blockIdx.z;
+    const int rp = rp_list[blockIdx.y];          // ring pairs of one FFT-size class
+    const int r = blockIdx.x, c = blockIdx.z;    // r fastest: the 4 sub-DFTs of a ring pair share its pixels in L2
     const int n = P.nsub[rp];
     const long long sN = P.startN[rp], sS = P.startS[rp];
     const int M = fft_size_for(n);
@@ -486,6 +500,19 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
         delete pl;
         return nullptr;
     }
+    {
+        // FFT-size classes: ring pairs grouped by in-LDS FFT length, longest rings first
+        std::map<int, std::vector<int>> byM;
+        for (int rp = pl->nrp - 1; rp >= 0; --rp) byM[fft_size_for(nsub[rp])].push_back(rp);
+        std::vector<int> list;
+        for (auto it = byM.rbegin(); it != byM.rend(); ++it) {
+            hx_plan::FftClass c;
+            c.M = it->first; c.first = (int)list.size(); c.count = (int)it->second.size();
+            list.insert(list.end(), it->second.begin(), it->second.end());
+            pl->fft_classes.push_back(c);
+        }
+        if (upload(pl->fft_rp_list, list) != HX_OK) { delete pl; return nullptr; }
+    }
     pl->twN = std::max(maxM, 2);
     pl->lds_fft = (size_t)maxM * sizeof(double2);
     pl->h_sth = sth; pl->h_z = z; pl->h_nsub = nsub;
@@ -593,13 +620,24 @@ int ensure_rec2(hx_plan *pl)
     return HX_OK;
 }
 
+// One launch per FFT-size class, so that every class gets the LDS it needs and no more
+// (a 4096-point ring must not reserve the 128 KiB of an 8192-point Bluestein ring).
+template <int MODE>
+static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, const double2 *zin, double2 *Y)
+{
+    for (const auto &c : pl->fft_classes) {
+        const int threads = c.M >= 8192 ? 1024 : (c.M >= 1024 ? 512 : 256);
+        hipLaunchKernelGGL(k_ring_subdft<MODE>, dim3(4, c.count, nb), dim3(threads), (size_t)c.M * sizeof(double2), rt().stream,
+                           pl->dev(), pl->fft_rp_list.as<int>() + c.first, d_maps, d_pw, zin, Y);
+    }
+    HX_HIP(hipGetLastError());
+    return HX_OK;
+}
+
 int launch_ring_subdft_maps(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, double2 *Y)
 {
     ProfScope ps("ring_fft");
-    hipLaunchKernelGGL(k_ring_subdft<0>, dim3(pl->nrp, 4, nb), dim3(512), pl->lds_fft, rt().stream, pl->dev(), d_maps, d_pw,
-                       (const double2 *)nullptr, Y);
-    HX_HIP(hipGetLastError());
-    return HX_OK;
+    return launch_subdft_classes<0>(pl, nb, d_maps, d_pw, nullptr, Y);
 }
 }  // namespace hx
 
@@ -637,8 +675,7 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
     {
         ProfScope ps("ring_fft");
         hipLaunchKernelGGL(k_synth_spectrum, dim3(pl->nrp, nb), dim3(256), 0, st, P, pl->Fsyn.as<double>(), pl->lmax, pl->resid.as<double2>());
-        hipLaunchKernelGGL(k_ring_subdft<1>, dim3(pl->nrp, 4, nb), dim3(512), pl->lds_fft, st, P, (const double *)nullptr,
-                           (const double *)nullptr, pl->resid.as<double2>(), pl->Y.as<double2>());
+        HX_TRY(launch_subdft_classes<1>(pl, nb, nullptr, nullptr, pl->resid.as<double2>(), pl->Y.as<double2>()));
         hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, nb), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps, d_ref ? 1 : 0, d_ref);
     }
     HX_HIP(hipGetLastError());

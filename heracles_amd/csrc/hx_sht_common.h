@@ -2,6 +2,7 @@
 // shared by hx_sht.hip (plan, ring Fourier stage, synthesis, C ABI) and hx_analysis.hip
 // (Legendre analysis on FP64 MFMA).
 #pragma once
+#include <map>
 #include <vector>
 
 #include "hx_common.h"
@@ -141,6 +142,9 @@ struct hx_plan {
         std::vector<long long> rows_before_m; // partial rows of all tasks with smaller m (size lmax+2)
         hx::DevBuf d_tasks, d_of_m;
     } ts[2];
+    struct FftClass { int M, first, count; };
+    std::vector<FftClass> fft_classes;   // ring pairs grouped by in-LDS FFT length
+    hx::DevBuf fft_rp_list;
     hx::DevBuf Y, F, partial, d_dbg, resid, Fsyn;
     hx::PlanDev dev() const;
 };

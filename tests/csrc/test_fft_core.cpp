@@ -21,14 +21,24 @@ static std::vector<double2> make_tw(int twN)
 }
 static double2 expipi(double x) /* exp(i pi x) */ { return mk(cos(M_PI * x), sin(M_PI * x)); }
 
+// same stage schedule as lds_fft_dif / lds_fft_dit_inv in hx_sht.hip: fused radix-4 stages,
+// plus one radix-2 stage when log2(M) is odd
 static void fft_dif(std::vector<double2> &b, int M, const std::vector<double2> &tw, int twN)
 {
-    for (int h = M / 2; h >= 1; h >>= 1)
+    int h = M / 2;
+    if (ilog2(M) & 1) {
         for (int i = 0; i < M / 2; ++i) dif_butterfly(b.data(), i, h, tw.data(), twN);
+        h >>= 1;
+    }
+    for (h >>= 1; h >= 1; h >>= 2)
+        for (int i = 0; i < M / 4; ++i) dif4_butterfly(b.data(), i, h, tw.data(), twN);
 }
 static void fft_dit_inv(std::vector<double2> &b, int M, const std::vector<double2> &tw, int twN)
 {
-    for (int h = 1; h <= M / 2; h <<= 1)
+    int h = 1;
+    for (; 4 * h <= M; h <<= 2)
+        for (int i = 0; i < M / 4; ++i) dit4_inv_butterfly(b.data(), i, h, tw.data(), twN);
+    if (2 * h <= M)
         for (int i = 0; i < M / 2; ++i) dit_inv_butterfly(b.data(), i, h, tw.data(), twN);
 }
 
@@ -71,7 +81,7 @@ int main()
     const int twN = 8192;
     auto tw = make_tw(twN);
     double worst = 0;
-    int sizes[] = {1, 2, 3, 4, 5, 7, 8, 12, 16, 31, 32, 33, 100, 127, 128, 255, 257, 1000};
+    int sizes[] = {1, 2, 3, 4, 5, 7, 8, 12, 16, 31, 32, 33, 64, 100, 127, 128, 255, 256, 257, 512, 1000};
     for (int n : sizes) {
         int N = 4 * n;
         std::vector<double2> z(N);
