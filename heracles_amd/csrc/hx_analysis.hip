@@ -135,13 +135,21 @@ __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double
 // XOR swizzle of the tile column by the row: bits {4,2,1,0} of the column index
 __device__ __host__ inline int tile_swz(int r) { return (r & 7) | ((r & 8) << 1); }
 
-template <int SPIN, int NG>
+// NGQ > 0: NGQ groups of 16 columns on v_mfma_f64_16x16x4_f64.
+// NGQ < 0: -NGQ blocks of 4 columns on v_mfma_f64_4x4x4_4b_f64 (small batches: the four 4x4x4
+//          blocks take the four 4-row groups of the same [16 l x 4 rings] A operand, so the A
+//          layout -- row = lane&15, k = lane>>4 -- is unchanged; B lane (k, b, j) = F[ring k][col j],
+//          D lane (i, b, j) = row 4b+i, col j; measured 16 cycles / instruction).
+template <int SPIN, int NGQ>
 __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(LegParams A,
                                                                            const double2 *__restrict__ coefn,
                                                                            const double *__restrict__ alphan)
 {
     using C = LegCfg<SPIN>;
-    constexpr int NW = C::NW, NT = C::NT, NOP = C::NOP, NCOLS = NCOL * NG;
+    constexpr int NW = C::NW, NT = C::NT, NOP = C::NOP;
+    constexpr bool QUAD = NGQ < 0;            // 4-column MFMA path
+    constexpr int NG = QUAD ? 1 : NGQ;        // 16-column groups held in the partial rows
+    constexpr int NB = QUAD ? -NGQ : NGQ;     // B-operand register sets per (par, op, q)
     __shared__ double tiles[NW][NT][16][64];  // 128 KiB; after the MFMA phase each wave's tiles carry its D tiles
     __shared__ double2 coefs[2][LBLK];        // recursion coefficients of this / the next block
     __shared__ double alphas[2][LBLK];        // output scalings alpha_l of this / the next block
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
     const int ai = lane & 15, ak = lane >> 4;
 
     // ---- B operands: F[m - m0][rp][par][op][g*16 + j], lane (k = lane>>4, j = lane&15) ----
-    double fr[NG][2][NOP][8];
+    double fr[NB][2][NOP][8];
     {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -172,10 +180,13 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
 #pragma unroll
                 for (int op = 0; op < NOP; ++op)
 #pragma unroll
-                    for (int g = 0; g < NG; ++g)
-                        fr[g][par][op][q] = (wave_on && g < A.ng)
-                                                ? A.F[((row * 2 + par) * NOP + op) * (NCOL * A.ng) + g * NCOL + ai]
+                    for (int g = 0; g < NB; ++g) {
+                        // 16-col path: group g, column lane&15;  4-col path: block g, column lane&3
+                        const int col = QUAD ? 4 * g + (lane & 3) : g * NCOL + ai;
+                        fr[g][par][op][q] = (wave_on && (QUAD || g < A.ng))
+                                                ? A.F[((row * 2 + par) * NOP + op) * (NCOL * A.ng) + col]
                                                 : 0.0;
+                    }
         }
     }
 
@@ -225,11 +236,14 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
             apre = alphan[cb + lb + LBLK + (threadIdx.x - 2 * LBLK)];
         const double2 *cf = coefs[cbuf];
         double4_t acc[NG][2];
+        double accq[NB][2];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             acc[g][0] = (double4_t){0.0, 0.0, 0.0, 0.0};
             acc[g][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
         }
+#pragma unroll
+        for (int g = 0; g < NB; ++g) accq[g][0] = accq[g][1] = 0.0;
         if (wave_on && !(A.ablate & 2)) {
             const bool all_live = __all(sc == 0 || !valid);
             const bool all_dead = __all(sc <= -3 || !valid);
@@ -291,8 +305,12 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
                                 const int t = SPIN == 0 ? 0 : par, hh = SPIN == 0 ? par : op;
                                 const double a = mytile[(t * 16 + ai) * 64 + ((hh * 32 + q + 8 * ak) ^ tile_swz(ai))];
 #pragma unroll
-                                for (int g = 0; g < NG; ++g)
-                                    acc[g][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[g][par][op][q], acc[g][par], 0, 0, 0);
+                                for (int g = 0; g < NB; ++g) {
+                                    if (QUAD)
+                                        accq[g][par] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, fr[g][par][op][q], accq[g][par], 0, 0, 0);
+                                    else
+                                        acc[g][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[g][par][op][q], acc[g][par], 0, 0, 0);
+                                }
                             }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -305,17 +323,26 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
             (&coefs[cbuf ^ 1][0].x)[threadIdx.x] = cpre;
         else if (threadIdx.x < 3 * LBLK)
             alphas[cbuf ^ 1][threadIdx.x - 2 * LBLK] = apre;
+        if (QUAD) {
+            // D lane (i = lane>>4, b = (lane>>2)&3, j = lane&3): row 4b+i, column 4g+j
 #pragma unroll
-        for (int g = 0; g < NG; ++g)
+            for (int g = 0; g < NB; ++g)
 #pragma unroll
-            for (int par = 0; par < 2; ++par)
+                for (int par = 0; par < 2; ++par)
+                    mytile[par * 256 + (4 * ((lane >> 2) & 3) + ak) * 16 + 4 * g + (lane & 3)] = accq[g][par];
+        } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    mytile[(g * 2 + par) * 256 + (ak + 4 * r) * 16 + ai] = acc[g][par][r];
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int par = 0; par < 2; ++par)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        mytile[(g * 2 + par) * 256 + (ak + 4 * r) * 16 + ai] = acc[g][par][r];
+        }
         lds_barrier();
         for (int t = threadIdx.x; t < NG * 512; t += NW * 64) {
             const int g = t >> 9, par = (t >> 8) & 1, r16 = (t >> 4) & 15, col = t & 15;
-            if (g >= A.ng) continue;
+            if (g >= A.ng || (QUAD && col >= 4 * NB)) continue;
             double s = 0.0;
 #pragma unroll
             for (int ww = 0; ww < NW; ++ww) s += (&tiles[ww][0][0][0])[(g * 2 + par) * 256 + r16 * 16 + col];
@@ -325,7 +352,6 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
         }
         lds_barrier();  // D tiles consumed: the tile buffers may be overwritten by the next block
     }
-    (void)NCOLS;
 }
 
 // =====================================================================================
@@ -452,10 +478,19 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         const double2 *cn = SPIN == 0 ? pl->cn0.as<double2>() : pl->cn2.as<double2>();
         const double *al = SPIN == 0 ? pl->al0.as<double>() : pl->al2.as<double>();
         constexpr int NW = LegCfg<SPIN>::NW;
-        if (ng == 1)
-            hipLaunchKernelGGL((k_legendre_analysis<SPIN, 1>), dim3((unsigned)(t1 - t0)), dim3(NW * 64), 0, st, A, cn, al);
+        // real columns in use: 2 per spin-0 component, 4 per spin-2 field
+        const int ncols_used = SPIN == 0 ? 2 * nb : 2 * nb;
+        const char *eq = getenv("HX_NO_QUAD");
+        const bool quad_ok = !(eq && atoi(eq));
+        dim3 grid((unsigned)(t1 - t0)), block(NW * 64);
+        if (quad_ok && ncols_used <= 4)
+            hipLaunchKernelGGL((k_legendre_analysis<SPIN, -1>), grid, block, 0, st, A, cn, al);
+        else if (quad_ok && ncols_used <= 8)
+            hipLaunchKernelGGL((k_legendre_analysis<SPIN, -2>), grid, block, 0, st, A, cn, al);
+        else if (ng == 1)
+            hipLaunchKernelGGL((k_legendre_analysis<SPIN, 1>), grid, block, 0, st, A, cn, al);
         else
-            hipLaunchKernelGGL((k_legendre_analysis<SPIN, 2>), dim3((unsigned)(t1 - t0)), dim3(NW * 64), 0, st, A, cn, al);
+            hipLaunchKernelGGL((k_legendre_analysis<SPIN, 2>), grid, block, 0, st, A, cn, al);
         if (A.ablate & 8) {
             unsigned long long hc[4] = {0, 0, 0, 0};
             HX_HIP(hipStreamSynchronize(st));

@@ -35,8 +35,11 @@ def test_map2alm_random_maps(oracle, nside, lmax, spin):
     plan.close()
 
 
-@pytest.mark.parametrize("spin,ncomp", [(0, 1), (0, 8), (0, 9), (0, 19), (2, 2), (2, 8), (2, 10)])
+@pytest.mark.parametrize("spin,ncomp", [(0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 8), (0, 9), (0, 19),
+                                        (2, 2), (2, 4), (2, 6), (2, 8), (2, 10), (2, 16), (2, 18), (2, 22)])
 def test_map2alm_batching(oracle, spin, ncomp):
+    """Launch shapes: 4-column MFMA path (<= 2 maps / 1 field), 8-column path, one and two
+    16-column groups, and several launches per call."""
     import heracles_amd as hx
 
     rng = np.random.default_rng(7 + ncomp)
