@@ -29,26 +29,6 @@ using namespace hxfft;
 // =====================================================================================
 // table initialisation kernels
 // =====================================================================================
-__global__ void k_init_rec0(int lmax, double2 *__restrict__ rec)
-{
-    const int m = blockIdx.x;
-    for (int l = m + threadIdx.x; l <= lmax; l += blockDim.x) {
-        double2 r = make_double2(0.0, 0.0);
-        if (l > m) {
-            double dl = l, dm = m;
-            double a = sqrt((4.0 * dl * dl - 1.0) / (dl * dl - dm * dm));
-            double b = 0.0;
-            if (l > m + 1) {
-                double d1 = l - 1.0;
-                double ap = sqrt((4.0 * d1 * d1 - 1.0) / (d1 * d1 - dm * dm));
-                b = a / ap;
-            }
-            r = make_double2(a, b);
-        }
-        rec[almidx(lmax, l, m)] = r;
-    }
-}
-
 // Normalised recursions used by the analysis kernel (two FMAs per new value, after the
 // scheme of libsharp/ducc's Ylmgen): with lambda_l = alpha_l mu_l,
 //   spin 0 (two-step):  mu_{l+2} = (A' x^2 + B') mu_l - mu_{l-2}
@@ -107,27 +87,6 @@ __global__ void k_init_norm2(int lmax, double2 *__restrict__ coef, double *__res
         coef[almidx(lmax, l + 1, m)] = make_double2(p * a0 / a1, q * a0 / a1);
         am1 = a0;
         a0 = a1;
-    }
-}
-
-// rec2[idx(l,m)] = (c1x, c1c(n=-2), c2, 0): g_l = (c1x x + c1c) g_{l-1} - c2 g_{l-2};
-// for n=+2 the sign of c1c flips.  g_l = sqrt((2l+1)/4pi) d^l_{m,n}.
-__global__ void k_init_rec2(int lmax, double4 *__restrict__ rec)
-{
-    const int m = blockIdx.x;
-    const int l0 = m > 2 ? m : 2;
-    for (int l = m + threadIdx.x; l <= lmax; l += blockDim.x) {
-        double4 r = make_double4(0.0, 0.0, 0.0, 0.0);
-        if (l > l0) {
-            double k = l - 1.0, lp = l, dm = m, dn = -2.0;
-            double den = k * sqrt((lp * lp - dm * dm) * (lp * lp - dn * dn));
-            double r1 = sqrt((2.0 * k + 3.0) / (2.0 * k + 1.0));
-            r.x = r1 * (2.0 * k + 1.0) * k * lp / den;
-            r.y = -r1 * (2.0 * k + 1.0) * dm * dn / den;
-            double r2 = sqrt((2.0 * k + 3.0) / (2.0 * k - 1.0));
-            r.z = r2 * lp * sqrt((k * k - dm * dm) * (k * k - dn * dn)) / den;
-        }
-        rec[almidx(lmax, l, m)] = r;
     }
 }
 
@@ -251,132 +210,8 @@ __global__ __launch_bounds__(1024) void k_ring_subdft(PlanDev P, const int *__re
 }
 
 // =====================================================================================
-// Legendre synthesis (VALU, lanes = ring pairs): F_m(r) = sum_l a_lm lambda_lm(r)
+// synthesis: Fsyn -> ring spectra -> pixels (the Legendre part lives in hx_analysis.hip)
 // =====================================================================================
-// alm operands staged per m as AL[m-offset ...]: we read alm directly: for each l the
-// 2*ncomp reals of (c, re/im) are wave-uniform scalar loads.
-// Output: Fsyn[m][rp][ns][16]: ns = 0 north, 1 south; columns = 2c+{re,im} of F_m.
-// spin 2: columns 4f + {Qre,Qim,Ure,Uim}.
-template <int SPIN>
-__global__ __launch_bounds__(256) void k_legendre_synthesis(PlanDev P, const double2 *__restrict__ alm,
-                                                            long long alm_stride, int ncomp,
-                                                            const MTasks *__restrict__ first_rp,
-                                                            double *__restrict__ Fsyn)
-{
-    constexpr int NOP = SPIN == 0 ? 1 : 2;
-    const int m = blockIdx.x, lmax = P.lmax;
-    const int rp = blockIdx.y * 256 + threadIdx.x;
-    const bool valid = rp < P.nrp;
-    const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
-    const long long cb = almidx(lmax, 0, m);
-    // whole block below the first active ring pair: write zeros
-    const bool block_dead = (int)(blockIdx.y * 256 + 255) < first_rp[m].first;
-    double ev[NCOL], od[NCOL];
-#pragma unroll
-    for (int i = 0; i < NCOL; ++i) ev[i] = od[i] = 0.0;
-    if (!block_dead && l0 <= lmax) {
-        const double x = valid ? P.z[rp] : 0.0;
-        double vc[NOP], vp[NOP];
-        int sc[NOP];
-        if (SPIN == 0) {
-            SVal s = {0.0, -100};
-            if (valid) {
-                s = spow(P.sth[rp], m);
-                s.v *= P.mfac[m];
-            }
-            vc[0] = s.v; vp[0] = 0.0; sc[0] = s.e;
-        } else {
-            SVal sp = {0.0, -100}, sm = {0.0, -100};
-            if (valid) {
-                const double sth = P.sth[rp], omx = P.omz[rp], opx = 2.0 - omx;
-                const double nrm = sqrt((2.0 * l0 + 1.0) / (4.0 * M_PI));
-                if (m == 0) {
-                    double d = 0.61237243569579452455 * sth * sth;
-                    sp.v = sm.v = nrm * d; sp.e = sm.e = 0;
-                } else if (m == 1) {
-                    sp.v = nrm * (-0.5 * omx * sth); sp.e = 0;
-                    sm.v = nrm * (0.5 * opx * sth);  sm.e = 0;
-                } else {
-                    SVal b = spow(sth, m - 2);
-                    b.v *= P.kfac2[m] * nrm * ((m & 1) ? -1.0 : 1.0);
-                    sp.v = b.v * (0.25 * omx * omx); sp.e = b.e;
-                    sm.v = b.v * (0.25 * opx * opx); sm.e = b.e;
-                }
-                snorm_small(sp);
-                snorm_small(sm);
-            }
-            vc[0] = sp.v; vp[0] = 0.0; sc[0] = sp.e;
-            if (NOP > 1) { vc[NOP - 1] = sm.v; vp[NOP - 1] = 0.0; sc[NOP - 1] = sm.e; }
-        }
-        for (int l = l0; l <= lmax; ++l) {
-            const bool odd = (l + m) & 1;
-            double lam[NOP];
-#pragma unroll
-            for (int op = 0; op < NOP; ++op) lam[op] = sval_true(vc[op], sc[op]);
-            if (SPIN == 0) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    if (c < ncomp) {
-                        const double2 a = alm[(long long)c * alm_stride + cb + l];
-                        if (odd) { od[2 * c] = fma(lam[0], a.x, od[2 * c]); od[2 * c + 1] = fma(lam[0], a.y, od[2 * c + 1]); }
-                        else     { ev[2 * c] = fma(lam[0], a.x, ev[2 * c]); ev[2 * c + 1] = fma(lam[0], a.y, ev[2 * c + 1]); }
-                    }
-                }
-            } else {
-                // Q_m = -sum (E F1 + i B F2), U_m = -sum (B F1 - i E F2)
-                // F1 = (lam+ + lam-)/2, F2 = (lam+ - lam-)/2.  South: F1 -> p F1, F2 -> -p F2.
-                // ev/od hold the F1 parts in [4f..4f+3] of ev/od and the F2 parts in evod2
-                const double f1 = 0.5 * (lam[0] + lam[NOP - 1]), f2 = 0.5 * (lam[0] - lam[NOP - 1]);
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    if (2 * f + 1 < ncomp) {
-                        const double2 E = alm[(long long)(2 * f) * alm_stride + cb + l];
-                        const double2 B = alm[(long long)(2 * f + 1) * alm_stride + cb + l];
-                        // north contribution n = -(E f1 + i B f2) etc.; south uses s1 = p f1, s2 = -p f2
-                        // accumulate A = f1-part, C = f2-part separately by parity:
-                        //   parity even: north A + C, south A - C ; parity odd: north A + C, south -A + C
-                        const double qa_r = -f1 * E.x, qa_i = -f1 * E.y;   // -(E f1)
-                        const double qc_r = f2 * B.y, qc_i = -f2 * B.x;    // -(i B f2)
-                        const double ua_r = -f1 * B.x, ua_i = -f1 * B.y;   // -(B f1)
-                        const double uc_r = -f2 * E.y, uc_i = f2 * E.x;    // +(i E f2)
-                        // ev := quantity that is the same north and south; od := flips sign
-                        if (!odd) {
-                            ev[4 * f] += qa_r; ev[4 * f + 1] += qa_i; ev[4 * f + 2] += ua_r; ev[4 * f + 3] += ua_i;
-                            od[4 * f] += qc_r; od[4 * f + 1] += qc_i; od[4 * f + 2] += uc_r; od[4 * f + 3] += uc_i;
-                        } else {
-                            od[4 * f] += qa_r; od[4 * f + 1] += qa_i; od[4 * f + 2] += ua_r; od[4 * f + 3] += ua_i;
-                            ev[4 * f] += qc_r; ev[4 * f + 1] += qc_i; ev[4 * f + 2] += uc_r; ev[4 * f + 3] += uc_i;
-                        }
-                    }
-                }
-            }
-            // advance
-#pragma unroll
-            for (int op = 0; op < NOP; ++op) {
-                double vn;
-                if (SPIN == 0) {
-                    const double2 c = P.rec0[cb + l + 1];
-                    vn = fma(c.x * x, vc[op], -c.y * vp[op]);
-                } else {
-                    const double4 c = P.rec2[cb + l + 1];
-                    const double cc = op == 0 ? c.y : -c.y;
-                    vn = fma(fma(c.x, x, cc), vc[op], -c.z * vp[op]);
-                }
-                vp[op] = vc[op]; vc[op] = vn;
-                if (fabs(vc[op]) > SC_BIG) { vc[op] *= SC_SMALL; vp[op] *= SC_SMALL; sc[op] += 1; }
-            }
-        }
-    }
-    if (rp < P.nrp_pad) {
-        double *base = Fsyn + (((long long)m * P.nrp_pad + rp) * 2) * NCOL;
-#pragma unroll
-        for (int i = 0; i < NCOL; ++i) {
-            base[i] = ev[i] + od[i];          // north
-            base[NCOL + i] = ev[i] - od[i];   // south
-        }
-    }
-}
-
 // Fsyn -> conj(Z) spectra of the packed ring pair z = f_N + i f_S.
 // X[k] = sum_{m == k mod nphi} (c_m/2) Ft_m + sum_{m == -k} (c_m/2) conj(Ft_m), Ft = F e^{i m phi0}
 // grid: x = ring pair, y = comp; block loops over k.  Output Zc[c][startN + k] = conj(X_N + i X_S)
@@ -456,7 +291,7 @@ PlanDev hx_plan::dev() const
     P.startN = startN.as<long long>(); P.startS = startS.as<long long>(); P.bhat_off = bhat_off.as<long long>();
     P.tw = tw.as<double2>(); P.bhat = bhat.as<double2>();
     P.mfac = mfac.as<double>(); P.kfac2 = kfac2.as<double>();
-    P.rec0 = rec0.as<double2>(); P.rec2 = rec2.as<double4>();
+    P.rec0 = nullptr; P.rec2 = nullptr;
     return P;
 }
 
@@ -560,11 +395,8 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
     chk(upload(pl->startN, sN)); chk(upload(pl->startS, sS)); chk(upload(pl->bhat_off, boff));
     chk(upload(pl->tw, tw)); chk(upload(pl->mfac, mfac)); chk(upload(pl->kfac2, kfac2));
     chk(pl->bhat.alloc(sizeof(double2) * std::max<long long>(btot, 1)));
-    chk(pl->rec0.alloc(sizeof(double2) * (pl->nlm + 128)));
     if (rc != HX_OK) { delete pl; return nullptr; }
     hipStream_t st = rt().stream;
-    (void)hipMemsetAsync(pl->rec0.p, 0, sizeof(double2) * (pl->nlm + 128), st);
-    hipLaunchKernelGGL(k_init_rec0, dim3(lmax + 1), dim3(256), 0, st, lmax, pl->rec0.as<double2>());
     if (pl->cn0.alloc(sizeof(double2) * (pl->nlm + 128)) != HX_OK || pl->al0.alloc(sizeof(double) * (pl->nlm + 128)) != HX_OK) {
         delete pl;
         return nullptr;
@@ -607,10 +439,7 @@ extern "C" int64_t hx_plan_scratch_bytes(const hx_plan *pl)
 namespace hx {
 int ensure_rec2(hx_plan *pl)
 {
-    if (pl->rec2.p) return HX_OK;
-    HX_TRY(pl->rec2.alloc(sizeof(double4) * (pl->nlm + 128)));
-    HX_HIP(hipMemsetAsync(pl->rec2.p, 0, sizeof(double4) * (pl->nlm + 128), rt().stream));
-    hipLaunchKernelGGL(k_init_rec2, dim3(pl->lmax + 1), dim3(256), 0, rt().stream, pl->lmax, pl->rec2.as<double4>());
+    if (pl->cn2.p) return HX_OK;
     HX_TRY(pl->cn2.alloc(sizeof(double2) * (pl->nlm + 128)));
     HX_TRY(pl->al2.alloc(sizeof(double) * (pl->nlm + 128)));
     HX_HIP(hipMemsetAsync(pl->cn2.p, 0, sizeof(double2) * (pl->nlm + 128), rt().stream));
@@ -649,29 +478,11 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
     hipStream_t st = rt().stream;
     HX_TRY(build_tasks(pl, spin));
     if (spin) HX_TRY(ensure_rec2(pl));
-    hx_plan::TaskSet &ts = pl->ts[spin ? 1 : 0];
     HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * 8));
     HX_TRY(pl->resid.alloc(sizeof(double2) * (size_t)pl->ny * 8));  // conj(Z) spectra
     HX_TRY(pl->Fsyn.alloc(sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * 2 * NCOL));
     PlanDev P = pl->dev();
-    // first active ring pair per m (reuse MTasks.first as "first ring pair")
-    static thread_local std::vector<MTasks> fr;
-    fr.assign(pl->lmax + 1, MTasks{0, 0});
-    for (int m = 0; m <= pl->lmax; ++m) {
-        int first = 0;
-        if (ts.of_m[m].count > 0) first = ts.tasks[ts.of_m[m].first].rb0 * RBLK;
-        fr[m].first = first;
-    }
-    DevBuf d_fr;
-    HX_TRY(upload(d_fr, fr));
-    {
-        ProfScope ps("legendre_synthesis");
-        dim3 grid(pl->lmax + 1, (pl->nrp_pad + 255) / 256);
-        if (spin == 0)
-            hipLaunchKernelGGL(k_legendre_synthesis<0>, grid, dim3(256), 0, st, P, d_alms, pl->nlm, nb, d_fr.as<MTasks>(), pl->Fsyn.as<double>());
-        else
-            hipLaunchKernelGGL(k_legendre_synthesis<2>, grid, dim3(256), 0, st, P, d_alms, pl->nlm, nb, d_fr.as<MTasks>(), pl->Fsyn.as<double>());
-    }
+    HX_TRY(legendre_synthesis(pl, spin, nb, d_alms, pl->Fsyn.as<double>()));
     {
         ProfScope ps("ring_fft");
         hipLaunchKernelGGL(k_synth_spectrum, dim3(pl->nrp, nb), dim3(256), 0, st, P, pl->Fsyn.as<double>(), pl->lmax, pl->resid.as<double2>());
@@ -679,7 +490,6 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
         hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, nb), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps, d_ref ? 1 : 0, d_ref);
     }
     HX_HIP(hipGetLastError());
-    HX_HIP(hipStreamSynchronize(st));  // d_fr is freed on return
     return HX_OK;
 }
 
