@@ -343,9 +343,11 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
         for (int t = threadIdx.x; t < NG * 512; t += NW * 64) {
             const int g = t >> 9, par = (t >> 8) & 1, r16 = (t >> 4) & 15, col = t & 15;
             if (g >= A.ng || (QUAD && col >= 4 * NB)) continue;
-            double s = 0.0;
+            // fixed association (bit-reproducible), four independent chains for latency
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int ww = 0; ww < NW; ++ww) s += (&tiles[ww][0][0][0])[(g * 2 + par) * 256 + r16 * 16 + col];
+            for (int ww = 0; ww < NW; ++ww) s4[ww & 3] += (&tiles[ww][0][0][0])[(g * 2 + par) * 256 + r16 * 16 + col];
+            const double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
             const int l = lb + 2 * r16 + (par ^ off);
             if (l <= lmax)
                 A.partial[(task.pout - A.row0 + (l - l0)) * (NCOL * A.ng) + g * NCOL + col] = s * alphas[cbuf][l - lb];
