@@ -14,7 +14,7 @@
 //                Every lane runs ONE normalised recursion chain (2 FMAs per value).
 //   tile       = 16 rows (l) x 64 lanes in LDS, XOR-swizzled so that the row-wise stores and
 //                the [16 l x 4 rings] A-operand reads are both bank-conflict free.
-//   MFMA q     contracts rings {q, q+8, q+16, q+24} of the wave; its B operand (F of 8 maps =
+//   MFMA q     contracts rings {2q, 2q+1, 2q+16, 2q+17} of the wave; its B operand (F of 8 maps =
 //                16 real columns, x NG column groups) stays in registers for the whole l sweep.
 //   flush      per 32-l block the waves' D tiles are summed through LDS in fixed order
 //                (bit-reproducible) and scaled by alpha_l into `partial`.
@@ -132,8 +132,13 @@ __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double
 // =====================================================================================
 // Legendre analysis
 // =====================================================================================
-// XOR swizzle of the tile column by the row: bits {4,2,1,0} of the column index
-__device__ __host__ inline int tile_swz(int r) { return (r & 7) | ((r & 8) << 1); }
+// Tile addressing of the analysis kernel.  Element (row r, lane c) lives at column c ^ r
+// (r < 16): row-wise stores stay contiguous per 16-lane group.  MFMA q contracts the rings
+// ringsel(q, k), k = 0..3, chosen so that the [16 rows x 4 rings] operand read hits 32
+// distinct 8-byte slots per 32-lane half (ds_read_b64) AND 16 distinct slots per 16-lane
+// group (ds_read2_b64, which hipcc forms for the two parity halves).
+__device__ __host__ inline int tile_swz(int r) { return r & 15; }
+__device__ __host__ inline int ringsel(int q, int k) { return (k & 1) * 16 + 2 * q + (k >> 1); }
 
 // NGQ > 0: NGQ groups of 16 columns on v_mfma_f64_16x16x4_f64.
 // NGQ < 0: -NGQ blocks of 4 columns on v_mfma_f64_4x4x4_4b_f64 (small batches: the four 4x4x4
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
     {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const long long row = (long long)(m - A.m0) * P.nrp_pad + rb * RBLK + q + 8 * ak;
+            const long long row = (long long)(m - A.m0) * P.nrp_pad + rb * RBLK + ringsel(q, ak);
 #pragma unroll
             for (int par = 0; par < 2; ++par)
 #pragma unroll
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
 #pragma unroll
                             for (int op = 0; op < NOP; ++op) {
                                 const int t = SPIN == 0 ? 0 : par, hh = SPIN == 0 ? par : op;
-                                const double a = mytile[(t * 16 + ai) * 64 + ((hh * 32 + q + 8 * ak) ^ tile_swz(ai))];
+                                const double a = mytile[(t * 16 + ai) * 64 + ((hh * 32 + ringsel(q, ak)) ^ tile_swz(ai))];
 #pragma unroll
                                 for (int g = 0; g < NB; ++g) {
                                     if (QUAD)
@@ -440,7 +445,8 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_synthesis(Sy
     constexpr int NW = C::NW, NT = C::NT, NOP = C::NOP;
     __shared__ double tiles[NW][NT][16][64];
     __shared__ double2 coefs[2][LBLK];
-    __shared__ double bs[2][NOP][LBLK][NCOL];  // alpha_l a_lm of this / the next block
+    constexpr int BLD = NCOL + 8;             // row stride 24: rows two apart fall into different bank halves
+    __shared__ double bs[2][NOP][LBLK][BLD];  // alpha_l a_lm of this / the next block
     const PlanDev &P = A.P;
     const LegTask task = A.tasks[blockIdx.x];
     const int m = task.m, lmax = P.lmax;
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_synthesis(Sy
 #pragma unroll
         for (int u = 0; u < BPT; ++u) {
             const int t = threadIdx.x + u * NW * 64;
-            if (t < NBV) (&bs[buf][0][0][0])[t] = bpre[u];
+            if (t < NBV) bs[buf][t / (LBLK * NCOL)][(t / NCOL) % LBLK][t % NCOL] = bpre[u];
         }
     };
     fetch(l0);

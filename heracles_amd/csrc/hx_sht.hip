@@ -534,7 +534,8 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
     HX_TRY(vpw.bind(pix_weights, sizeof(double) * (size_t)pl->npix));
     HX_TRY(vfl.bind(fl, sizeof(double) * (pl->lmax + 1)));
     HX_TRY(valms.bind(alms, sizeof(double2) * (size_t)ncomp * pl->nlm));
-    DevBuf resid;
+    // residual maps of the Jacobi iterations: plan-owned scratch (no per-call hipMalloc)
+    DevBuf &resid = pl->resid_maps;
     if (niter > 0) HX_TRY(resid.alloc(sizeof(double) * (size_t)8 * pl->npix));
     // without iterations a launch takes 8*NGMAX components; the synthesis of the Jacobi
     // iterations works on 8 at a time

@@ -145,7 +145,7 @@ struct hx_plan {
     struct FftClass { int M, first, count; };
     std::vector<FftClass> fft_classes;   // ring pairs grouped by in-LDS FFT length
     hx::DevBuf fft_rp_list;
-    hx::DevBuf Y, F, partial, d_dbg, resid, Fsyn;
+    hx::DevBuf Y, F, partial, d_dbg, resid, resid_maps, Fsyn;
     hx::PlanDev dev() const;
 };
 
