@@ -210,7 +210,7 @@ def main():
             mix = {"L": L, "seconds": mix_s, "gemm_ms": gms, "gemm_tflops_algorithmic": gflop / (gms * 1e-3) / 1e12 if gms else None,
                    "checksum": float(np.abs(mm[2] - (mm[0] - mm[1])).max())}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N = 1 only
             cpu = cpu_baseline(nside, lmax, nbins)
         out = {
             "metric": "map->Cl pairs/sec + mixing-matrix build sec, nside=%d lmax=%d" % (nside, lmax),

@@ -27,7 +27,7 @@ SYMBOLS = (
     "hx_profile_enable", "hx_profile_reset", "hx_profile_get", "hx_plan_create",
     "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_map2alm", "hx_alm2map",
     "hx_alm2cl_pairs", "hx_gauss_legendre", "hx_wigner_d_table", "hx_mixmat",
-    "hx_mixmat_eb", "hx_cl2corr", "hx_corr2cl",
+    "hx_mixmat_eb", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values",
 )
 
 
@@ -55,6 +55,13 @@ def load():
                 f"{_LIBNAME} not found: build it with `make -C heracles_amd/csrc` "
                 "(hipcc, gfx950).  heracles_amd has no CPU fallback.",
             )
+        try:
+            # one HIP runtime per process: torch bundles its own libamdhip64 under the same
+            # soname, so it has to be the copy already resident when libhxsht.so is loaded
+            # (loading the system runtime first leaves torch without a visible device)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_LIBNAME)
         vp, i, dp = C.c_void_p, C.c_int, C.c_void_p
         L.hx_version.restype = C.c_char_p
@@ -76,6 +83,8 @@ def load():
         L.hx_mixmat_eb.argtypes = [dp, i, i, i, i, dp]
         L.hx_cl2corr.argtypes = [i, i, dp, dp]
         L.hx_corr2cl.argtypes = [i, i, dp, dp]
+        L.hx_ang2pix_ring.argtypes = [i, C.c_int64, dp, dp, dp]
+        L.hx_map_values.argtypes = [i, C.c_int64, dp, dp, i, dp, dp, i]
         L.hx_timer_stop.argtypes = [C.POINTER(C.c_float)]
         L.hx_profile_get.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         _lib = L
@@ -100,6 +109,12 @@ def ptr(obj):
     if hasattr(obj, "data_ptr"):  # torch tensor
         if not obj.is_contiguous():
             raise ValueError("tensor must be contiguous")
+        if getattr(obj, "is_cuda", False):
+            # libhxsht launches on its own stream: whatever torch queued on this tensor
+            # (fills, copies, collectives) has to be complete before the library touches it
+            import torch
+
+            torch.cuda.current_stream(obj.device).synchronize()
         return C.c_void_p(obj.data_ptr())
     raise TypeError(f"cannot take the address of {type(obj)!r}")
 

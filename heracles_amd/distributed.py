@@ -71,6 +71,9 @@ class PairWork:
             self._gather_buf = torch.empty((self.world * 3 * nb, nlm), dtype=local.dtype, device=local.device)
         # complex dtypes are gathered through their real view (same bytes)
         dist.all_gather_into_tensor(torch.view_as_real(self._gather_buf), torch.view_as_real(local), group=self.group)
+        if local.is_cuda:
+            # libhxsht launches on its own stream: the gathered shards must have landed first
+            torch.cuda.current_stream(local.device).synchronize()
         flat = self._gather_buf
         return [flat[k] for k in range(flat.shape[0])]
 
@@ -93,6 +96,8 @@ class PairWork:
             send[: mine.shape[0]] = torch.from_numpy(mine).to(dev)
         recv = torch.empty((self.world * nmax, self.lmax + 1), dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(recv, send, group=self.group)
+        if recv.is_cuda:
+            torch.cuda.current_stream(recv.device).synchronize()
         recv = recv.reshape(self.world, nmax, self.lmax + 1)
         if self.rank != 0:
             return None

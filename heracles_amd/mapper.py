@@ -48,47 +48,72 @@ def _native(arr):
     return arr
 
 
-def ang2pix_ring(nside, lon, lat):
-    """RING pixel index of (lon, lat) in degrees -- the HEALPix ang2pix definition
-    (Gorski et al. 2005), the function ``hp.ang2pix(nside, lon, lat, lonlat=True)``
-    provides at heracles/healpy.py:157.  Host-side numpy; a HIP version is the first
-    "next" row of SURVEY.md section 8f."""
-    lon = np.asarray(lon, dtype=np.float64)
-    lat = np.asarray(lat, dtype=np.float64)
-    theta = np.radians(90.0 - lat)
-    z = np.cos(theta)
-    za = np.abs(z)
-    tt = np.mod(np.radians(lon), 2 * np.pi) * (2.0 / np.pi)  # in [0,4)
-    tt = np.where(tt >= 4.0, tt - 4.0, tt)
-    nl4 = 4 * nside
-    npix = 12 * nside * nside
-    ncap = 2 * nside * (nside - 1)
-    out = np.empty(z.shape, dtype=np.int64)
-    eq = za <= 2.0 / 3.0
-    # equatorial region
-    temp1 = nside * (0.5 + tt)
-    temp2 = nside * z * 0.75
-    jp = np.floor(temp1 - temp2).astype(np.int64)
-    jm = np.floor(temp1 + temp2).astype(np.int64)
-    ir = nside + 1 + jp - jm
-    kshift = 1 - (ir & 1)
-    ip = (jp + jm - nside + kshift + 1) // 2
-    ip = np.mod(ip, nl4)
-    pe = ncap + (ir - 1) * nl4 + ip
-    # polar caps
-    tp = tt - np.floor(tt)
-    sth = np.sin(theta)
-    big = za >= 0.99
-    tmp = np.where(big, nside * sth / np.sqrt((1.0 + za) / 3.0), nside * np.sqrt(3.0 * (1.0 - za)))
-    jp2 = np.floor(tp * tmp).astype(np.int64)
-    jm2 = np.floor((1.0 - tp) * tmp).astype(np.int64)
-    ir2 = jp2 + jm2 + 1
-    ip2 = np.floor(tt * ir2).astype(np.int64)
-    ip2 = np.mod(ip2, 4 * ir2)
-    pn = 2 * ir2 * (ir2 - 1) + ip2
-    ps = npix - 2 * ir2 * (ir2 + 1) + ip2
-    out = np.where(eq, pe, np.where(z > 0, pn, ps))
+def ang2pix_ring(nside, lon, lat, out=None):
+    """RING pixel index of (lon, lat) in degrees on the GPU: ``hp.ang2pix(nside, lon, lat,
+    lonlat=True)`` of heracles/healpy.py:157.  numpy arrays or device tensors."""
+    from . import _lib
+
+    _lib.ensure_init()
+    if hasattr(lon, "data_ptr"):
+        import torch
+
+        lon, lat = lon.to(torch.float64).contiguous(), lat.to(torch.float64).contiguous()
+        if out is None:
+            out = torch.empty(lon.shape, dtype=torch.int64, device=lon.device)
+        n = lon.numel()
+    else:
+        lon = np.ascontiguousarray(_native(lon), dtype=np.float64)
+        lat = np.ascontiguousarray(_native(lat), dtype=np.float64)
+        if out is None:
+            out = np.empty(lon.shape, dtype=np.int64)
+        n = lon.size
+    if lon.shape != lat.shape:
+        raise ValueError("lon and lat must have the same shape")
+    _lib.check(_lib.load().hx_ang2pix_ring(int(nside), n, _lib.ptr(lon), _lib.ptr(lat), _lib.ptr(out)))
     return out
+
+
+def map_values(nside, lon, lat, data, values, *, ordered=True):
+    """``data[..., ipix[j]] += values[..., j]`` in catalogue order (heracles/healpy.py:58-66,
+    :144-160) on the GPU; ``data`` is a numpy array (round trip through HBM) or a device
+    tensor (updated in place, the path to use when looping over catalogue pages)."""
+    from . import _lib
+
+    _lib.ensure_init()
+    npix = 12 * nside * nside
+    if data.shape[-1] != npix:
+        raise ValueError(f"maps have {data.shape[-1]} pixels, NSIDE={nside} needs {npix}")
+    on_dev = hasattr(data, "data_ptr")
+    if on_dev:
+        import torch
+
+        if data.dtype != torch.float64 or not data.is_contiguous():
+            raise TypeError("device maps must be contiguous float64")
+        maps = data
+        conv = lambda a: (a if hasattr(a, "data_ptr") else torch.as_tensor(np.ascontiguousarray(_native(a), dtype=np.float64))
+                          ).to(torch.float64).contiguous()
+        lon, lat, values = conv(lon), conv(lat), conv(values)
+        n = lon.numel()
+    else:
+        lon = np.ascontiguousarray(_native(lon), dtype=np.float64)
+        lat = np.ascontiguousarray(_native(lat), dtype=np.float64)
+        values = np.ascontiguousarray(_native(values), dtype=np.float64)
+        n = lon.size
+        maps = data if (data.dtype == np.float64 and data.flags.c_contiguous and data.dtype.isnative) \
+            else np.ascontiguousarray(data, dtype=np.float64)
+    if tuple(lat.shape) != tuple(lon.shape) or values.shape[-1] != n:
+        raise ValueError("lon, lat and the last axis of values must have the same length")
+    nval = 1
+    for d in data.shape[:-1]:
+        nval *= d
+    if tuple(values.shape[:-1]) != tuple(data.shape[:-1]):
+        # the compiled reference loop broadcasts values[..., j] into maps[..., i]
+        values = (np.broadcast_to(values, (*data.shape[:-1], n)).copy() if not on_dev
+                  else values.expand(*data.shape[:-1], n).contiguous())
+    _lib.check(_lib.load().hx_map_values(int(nside), n, _lib.ptr(lon), _lib.ptr(lat), nval, _lib.ptr(values),
+                                         _lib.ptr(maps), 0 if ordered else 1))
+    if maps is not data:
+        data[...] = maps
 
 
 class HipHealpixMapper:
@@ -137,13 +162,9 @@ class HipHealpixMapper:
         return m
 
     def map_values(self, lon, lat, data, values, spin=0):
-        """Add values to the pixels containing (lon, lat) [degrees]; heracles/healpy.py:144-160."""
-        ipix = ang2pix_ring(self.__nside, _native(lon), _native(lat))
-        values = _native(values)
-        flat = data.reshape(-1, data.shape[-1])
-        vals = np.asarray(values).reshape(-1, np.shape(values)[-1])
-        for row in range(flat.shape[0]):
-            np.add.at(flat[row], ipix, vals[row])
+        """Add values to the pixels containing (lon, lat) [degrees]; heracles/healpy.py:144-160.
+        ang2pix, the stable sort by pixel and the ordered per-pixel sums run on the GPU."""
+        map_values(self.__nside, lon, lat, data, values)
 
     def _fl(self, spin):
         if not self.__deconv:

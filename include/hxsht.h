@@ -102,6 +102,19 @@ int hx_mixmat_eb(const double *cl, int ncl, int l1max, int l2max, int l3max, dou
 int hx_cl2corr(int lmax, int nspec, const double *cls, double *corrs);
 int hx_corr2cl(int lmax, int nspec, const double *corrs, double *cls);
 
+/* ---- catalogue -> map accumulation (first "next" row of SURVEY.md 8f) ---------------
+ * hx_ang2pix_ring replaces hp.ang2pix(nside, lon, lat, lonlat=True) at
+ * heracles/healpy.py:157 (RING scheme, lon/lat in degrees, n points).
+ * hx_map_values replaces HealpixMapper.map_values (heracles/healpy.py:144-160) with the
+ * compiled loop _map (heracles/healpy.py:58-66): maps[v][ipix[j]] += values[v][j] for
+ * j = 0..n-1 IN THAT ORDER per pixel (bit-identical sums; flags = 0).  values: [nval][n],
+ * maps: [nval][12 nside^2], read-modify-write, host or device.  HX_MAP_ATOMIC gives up the
+ * ordering guarantee for one pass of hardware f64 atomics.                             */
+#define HX_MAP_ATOMIC 1
+int hx_ang2pix_ring(int nside, int64_t n, const double *lon, const double *lat, int64_t *ipix);
+int hx_map_values(int nside, int64_t n, const double *lon, const double *lat, int nval,
+                  const double *values, double *maps, int flags);
+
 #ifdef __cplusplus
 }
 #endif

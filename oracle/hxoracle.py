@@ -239,3 +239,61 @@ def mixmat_eb(cl, l1max=None, l2max=None, l3max=None, spin=(2, 2)):
     out = np.empty((3, l1max + 1, l2max + 1))
     lib().hxo_mixmat_eb(_p(cl), C.c_int(l1max), C.c_int(l2max), C.c_int(l3max), _p(out))
     return out
+
+
+# ---- catalogue -> map accumulation (numpy restatement) -------------------------------
+def ang2pix_ring(nside, lon, lat):
+    """hp.ang2pix(nside, lon, lat, lonlat=True) as called at heracles/healpy.py:157.
+    healpy (1.16) is not vendored in /root/reference; this restates its published code
+    path: healpy lonlat2thetaphi (theta = pi/2 - radians(lat), phi = radians(lon)), then
+    healpix_cxx T_Healpix_Base::ang2pix -> loc2pix, RING branch (Gorski et al. 2005).
+    Parity with healpy itself is unpinned; pinned here on the pix2ang round trip."""
+    lon = np.asarray(lon, dtype=np.float64)
+    lat = np.asarray(lat, dtype=np.float64)
+    nside = int(nside)
+    theta = np.pi / 2.0 - np.radians(lat)
+    phi = np.radians(lon)
+    z = np.cos(theta)
+    have_sth = (theta < 0.01) | (theta > 3.14159 - 0.01)
+    sth = np.where(have_sth, np.sin(theta), 0.0)
+    za = np.abs(z)
+    v = phi * 0.6366197723675813430755350534900574
+    with np.errstate(invalid="ignore"):
+        neg = np.fmod(v, 4.0) + 4.0
+        tt = np.where(v >= 0, np.where(v < 4.0, v, np.fmod(v, 4.0)), np.where(neg == 4.0, 0.0, neg))
+    nl4 = 4 * nside
+    npix = 12 * nside * nside
+    ncap = 2 * nside * (nside - 1)
+    # equatorial belt
+    temp1 = nside * (0.5 + tt)
+    temp2 = nside * z * 0.75
+    jp = (temp1 - temp2).astype(np.int64)
+    jm = (temp1 + temp2).astype(np.int64)
+    ir = nside + 1 + jp - jm
+    kshift = 1 - (ir & 1)
+    t1 = jp + jm - nside + kshift + 1 + nl4 + nl4
+    ip = (t1 >> 1) % nl4
+    pe = ncap + (ir - 1) * nl4 + ip
+    # polar caps
+    tp = tt - tt.astype(np.int64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        tmp = np.where((za < 0.99) | ~have_sth, nside * np.sqrt(3.0 * (1.0 - za)), nside * sth / np.sqrt((1.0 + za) / 3.0))
+    jp2 = (tp * tmp).astype(np.int64)
+    jm2 = ((1.0 - tp) * tmp).astype(np.int64)
+    ir2 = jp2 + jm2 + 1
+    ip2 = np.minimum((tt * ir2).astype(np.int64), 4 * ir2 - 1)
+    pn = 2 * ir2 * (ir2 - 1) + ip2
+    ps = npix - 2 * ir2 * (ir2 + 1) + ip2
+    return np.where(za <= 2.0 / 3.0, pe, np.where(z > 0, pn, ps))
+
+
+def map_values(nside, lon, lat, data, values):
+    """HealpixMapper.map_values (heracles/healpy.py:144-160): the sequential loop of
+    heracles/healpy.py:58-66, maps[..., i] += values[..., j] in catalogue order.
+    np.add.at is that same unbuffered in-order accumulation (the reference's own test
+    uses it as the expectation, tests/test_healpy.py:57-77)."""
+    ipix = ang2pix_ring(nside, lon, lat)
+    flat = data.reshape(-1, data.shape[-1])
+    vals = np.broadcast_to(np.asarray(values, dtype=np.float64), (*data.shape[:-1], ipix.size)).reshape(-1, ipix.size)
+    for row in range(flat.shape[0]):
+        np.add.at(flat[row], ipix, vals[row])

@@ -131,3 +131,112 @@ def test_angular_power_spectra_golden(golden):
     assert [key_str(k) for k in cls] == list(golden["aps/plain/keys"])
     for k, v in cls.items():
         np.testing.assert_allclose(np.asarray(v.array), golden[f"aps/plain/cl/{key_str(k)}"], rtol=1e-12, atol=1e-14)
+
+
+# ---- catalogue -> map accumulation (hx_ang2pix_ring / hx_map_values) ---------------------
+@pytest.mark.parametrize("nside", [1, 2, 3, 16, 64, 4096])
+def test_ang2pix_matches_oracle(oracle, nside):
+    from heracles_amd.mapper import ang2pix_ring
+
+    rng = np.random.default_rng(nside)
+    n = 200_000
+    lon = rng.uniform(-360, 720, n)
+    lat = np.degrees(np.arcsin(rng.uniform(-1, 1, n)))
+    lon[:6] = [0.0, 90.0, 359.999, 360.0, -0.0, 720.0]
+    lat[:6] = [90.0, 90.0, -90.0, 0.0, 0.0, 41.8103148957786]
+    lat[6:2000] = rng.uniform(89.0, 90.0, 1994) * rng.choice([-1, 1], 1994)  # sin(theta) branch near the poles
+    got = ang2pix_ring(nside, lon, lat)
+    assert got.dtype == np.int64
+    np.testing.assert_array_equal(got, oracle.ang2pix_ring(nside, lon, lat))
+    if nside <= 64:
+        theta, phi = oracle.pix2ang(nside)
+        np.testing.assert_array_equal(ang2pix_ring(nside, np.degrees(phi), 90.0 - np.degrees(theta)),
+                                      np.arange(12 * nside**2))
+
+
+def test_map_values_reference_case():
+    """tests/test_healpy.py:44-77 with the GPU mapper: order-exact sums."""
+    from heracles_amd import HipHealpixMapper
+    from heracles_amd.mapper import ang2pix_ring
+
+    nside = 32
+    npix = 12 * nside**2
+    rng = np.random.default_rng(50)
+    mapper = HipHealpixMapper(nside)
+    size = 1000
+    lon = rng.uniform(0, 360, size=size)
+    lat = np.degrees(np.arcsin(rng.uniform(-1, 1, size=size)))
+    x, y = rng.standard_normal(size), rng.standard_normal(size)
+    ipix = ang2pix_ring(nside, lon, lat)
+    m = mapper.create()
+    mapper.map_values(lon, lat, m, x)
+    expected = np.zeros(npix)
+    np.add.at(expected, ipix, x)
+    np.testing.assert_array_equal(m, expected)
+    m = mapper.create(2)
+    mapper.map_values(lon, lat, m, np.stack([x, y]))
+    expected = np.zeros((2, npix))
+    np.add.at(expected[0], ipix, x)
+    np.add.at(expected[1], ipix, y)
+    np.testing.assert_array_equal(m, expected)
+    # accumulates on top of what is there; big-endian inputs are byteswapped (heracles/healpy.py:43-55)
+    mapper.map_values(lon.astype(">f8"), lat.astype(">f8"), m, np.stack([x, y]).astype(">f8"))
+    np.add.at(expected[0], ipix, x)
+    np.add.at(expected[1], ipix, y)
+    np.testing.assert_array_equal(m, expected)
+    mapper.map_values(lon[:0], lat[:0], m, np.stack([x, y])[:, :0])  # empty page
+    np.testing.assert_array_equal(m, expected)
+
+
+def test_map_values_crowded_pixels_ordered_and_atomic(oracle):
+    """Many points per pixel, values of very different magnitude: the ordered path is
+    bit-identical to the sequential loop, the atomic path only to rounding."""
+    import torch
+    from heracles_amd.mapper import map_values
+
+    nside = 8
+    npix = 12 * nside**2
+    rng = np.random.default_rng(3)
+    n = 300_000
+    lon = rng.uniform(0, 360, n)
+    lat = np.degrees(np.arcsin(rng.uniform(-1, 1, n)))
+    lon[: n // 3] = 12.5
+    lat[: n // 3] = -33.0  # a third of the catalogue in one pixel
+    vals = rng.standard_normal((3, n)) * 10.0 ** rng.integers(-8, 8, (3, n))
+    exp = rng.standard_normal((3, npix))
+    got = exp.copy()
+    oracle.map_values(nside, lon, lat, exp, vals)
+    map_values(nside, lon, lat, got, vals)
+    np.testing.assert_array_equal(got, exp)
+    dev = torch.zeros((3, npix), dtype=torch.float64, device="cuda")
+    map_values(nside, torch.as_tensor(lon).cuda(), torch.as_tensor(lat).cuda(), dev, torch.as_tensor(vals).cuda())
+    ref = np.zeros((3, npix))
+    oracle.map_values(nside, lon, lat, ref, vals)
+    np.testing.assert_array_equal(dev.cpu().numpy(), ref)
+    dev.zero_()
+    map_values(nside, lon, lat, dev, vals, ordered=False)
+    scale = np.zeros((3, npix))
+    oracle.map_values(nside, lon, lat, scale, np.abs(vals))
+    assert np.all(np.abs(dev.cpu().numpy() - ref) <= 1e-12 * scale + 1e-300)
+
+
+def test_map_values_full_size_checksum():
+    """nside=4096: sum over pixels == sum over the catalogue (exact for integer-valued
+    weights), hit counts == np.bincount of the indices."""
+    import torch
+    from heracles_amd.mapper import ang2pix_ring, map_values
+
+    nside = 4096
+    npix = 12 * nside**2
+    g = torch.Generator(device="cuda").manual_seed(11)
+    n = 20_000_000
+    lon = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 360.0
+    lat = torch.rad2deg(torch.asin(torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 2 - 1))
+    w = torch.randint(-1000, 1000, (2, n), device="cuda", generator=g).to(torch.float64)
+    w[0] = 1.0
+    maps = torch.zeros((2, npix), dtype=torch.float64, device="cuda")
+    map_values(nside, lon, lat, maps, w)
+    assert float(maps[0].sum()) == n and float(maps[1].sum()) == float(w[1].sum())
+    ipix = ang2pix_ring(nside, lon, lat)
+    assert int(ipix.min()) >= 0 and int(ipix.max()) < npix
+    assert torch.equal(maps[0], torch.bincount(ipix, minlength=npix).to(torch.float64))

@@ -201,32 +201,38 @@ def test_mapper_interface_and_metadata():
         mapper.transform(mapper.create(), spin=1)
 
 
-def test_ang2pix_and_map_values(oracle):
-    from heracles_amd import HipHealpixMapper
-    from heracles_amd.mapper import ang2pix_ring
-
-    for nside in (1, 2, 4, 16, 32):
+def test_oracle_ang2pix_and_map_values(oracle):
+    """The numpy restatement of ang2pix / map_values that the GPU path is checked against:
+    pix2ang round trip of every pixel centre (any NSIDE, not only powers of two), range,
+    locality, the pole / wrap-around cases and the reference's own map_values expectation
+    (tests/test_healpy.py:57-77)."""
+    for nside in (1, 2, 3, 4, 5, 16, 32):
         theta, phi = oracle.pix2ang(nside)
-        ipix = ang2pix_ring(nside, np.degrees(phi), 90.0 - np.degrees(theta))
+        ipix = oracle.ang2pix_ring(nside, np.degrees(phi), 90.0 - np.degrees(theta))
         np.testing.assert_array_equal(ipix, np.arange(12 * nside**2))
     rng = np.random.default_rng(7)
     nside = 16
     lon = rng.uniform(-360, 720, 5000)
     lat = np.degrees(np.arcsin(rng.uniform(-1, 1, 5000)))
-    ipix = ang2pix_ring(nside, lon, lat)
+    ipix = oracle.ang2pix_ring(nside, lon, lat)
     assert ipix.min() >= 0 and ipix.max() < 12 * nside**2
-    # every point is nearer to its own pixel centre than to any ring-neighbour centre
+    np.testing.assert_array_equal(ipix, oracle.ang2pix_ring(nside, np.mod(lon, 360.0), lat))
     theta, phi = oracle.pix2ang(nside)
     vec = np.stack([np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)], 1)
     t, p = np.radians(90 - lat), np.radians(lon)
     v = np.stack([np.sin(t) * np.cos(p), np.sin(t) * np.sin(p), np.cos(t)], 1)
     d_own = np.arccos(np.clip((v * vec[ipix]).sum(1), -1, 1))
     assert d_own.max() < 1.5 * np.sqrt(4 * np.pi / (12 * nside**2))
-    mapper = HipHealpixMapper(nside, deconvolve=False)
+    # poles and the lon = 0 / 360 seam
+    assert oracle.ang2pix_ring(nside, [0.0, 90.0, 359.999], [90.0, 90.0, 90.0]).tolist() == [0, 1, 3]
+    npix = 12 * nside**2
+    assert oracle.ang2pix_ring(nside, [0.0, 359.999], [-90.0, -90.0]).tolist() == [npix - 4, npix - 1]
+    assert oracle.ang2pix_ring(nside, [360.0], [0.0])[0] == oracle.ang2pix_ring(nside, [0.0], [0.0])[0]
     x, y = rng.standard_normal(5000), rng.standard_normal(5000)
-    m = mapper.create(2)
-    mapper.map_values(lon, lat, m, np.stack([x, y]))
-    exp = np.zeros((2, 12 * nside**2))
-    np.add.at(exp[0], ipix, x)
-    np.add.at(exp[1], ipix, y)
+    m = np.zeros((2, npix))
+    oracle.map_values(nside, lon, lat, m, np.stack([x, y]))
+    exp = np.zeros((2, npix))
+    for j, i in enumerate(ipix):  # the loop of heracles/healpy.py:58-66
+        exp[0, i] += x[j]
+        exp[1, i] += y[j]
     np.testing.assert_array_equal(m, exp)
