@@ -13,7 +13,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBNAME = os.path.join(_HERE, "libhxsht.so")
+# HX_LIBRARY selects another build of the same library (kernel timing experiments)
+_LIBNAME = os.environ.get("HX_LIBRARY") or os.path.join(_HERE, "libhxsht.so")
 _lock = threading.Lock()
 _lib = None
 

@@ -213,8 +213,6 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
         }
     }
     const double sgn = (SPIN == 2 && h) ? -1.0 : 1.0;  // q' enters with opposite sign for d_{m,+2}
-    auto scale_of = [](int e) { return e == 0 ? 1.0 : (e == -1 ? SC_SMALL : 0.0); };
-    double scf = scale_of(sc);
 
     double *mytile = &tiles[w][0][0][0];
 
@@ -250,31 +248,40 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
 #pragma unroll
         for (int g = 0; g < NB; ++g) accq[g][0] = accq[g][1] = 0.0;
         if (wave_on && !(A.ablate & 2)) {
+            // A chain is LIVE when its scale exponent is 0: its true value is >= 2^-300 and from
+            // there on a plain double.  Below that it contributes nothing at double precision
+            // and the tile gets an exact zero; such a chain is only stepped and, every 4 steps,
+            // promoted once it has grown past 1 (value *= 2^-300, exponent += 1).
             const bool all_live = __all(sc == 0 || !valid);
-            const bool all_dead = __all(sc <= -3 || !valid);
+            const bool all_dead = __all(sc < 0 || !valid);
             if ((A.ablate & 8) && lane == 0) atomicAdd(&A.counters[all_dead ? 0 : (all_live ? 1 : 2)], 1ULL);
             // one recursion step of this lane's chain: spin 0 advances l by 2 (entry 2j+h),
             // spin 2 advances l by 1 (entry s)
             auto advance = [&](int e) {
+#ifdef HX_FAKECOEF
+                const double2 c = make_double2(1.0e-3 * e, 0.5);  // timing experiment only
+#else
                 const double2 c = cf[e];
+#endif
                 const double vn = fma(fma(c.x, xx, sgn * c.y), vc, -vp);
                 vp = vc;
                 vc = vn;
             };
-            auto rescale = [&]() {
-                if (__any(fabs(vc) > SC_BIG)) {
-                    if (fabs(vc) > SC_BIG) {
+            auto promote = [&]() {
+                const bool up = sc < 0 && fabs(vc) > 1.0;
+                if (__any(up)) {
+                    if (up) {
                         vc *= SC_SMALL; vp *= SC_SMALL;
                         sc += 1;
-                        scf = scale_of(sc);
                     }
                 }
             };
             constexpr int NSTEP = SPIN == 0 ? LBLK / 2 : LBLK;
             if (all_dead) {
+#pragma unroll 4
                 for (int s = 0; s < NSTEP; ++s) {
                     advance(SPIN == 0 ? 2 * s + h : s);
-                    rescale();
+                    if ((s & 3) == 3) promote();
                 }
             } else {
                 // row r of tile t, lane c  lives at  ((t*16 + r)*64 + (c ^ swz(r)))
@@ -286,12 +293,12 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
                         advance(SPIN == 0 ? 2 * s + h : s);
                     }
                 } else {
-#pragma unroll 4
+#pragma unroll
                     for (int s = 0; s < NSTEP; ++s) {
                         const int t = SPIN == 0 ? 0 : ((s + off) & 1), r = SPIN == 0 ? s : (s >> 1);
-                        mytile[(t * 16 + r) * 64 + (lane ^ tile_swz(r))] = vc * scf;
+                        mytile[(t * 16 + r) * 64 + (lane ^ tile_swz(r))] = sc == 0 ? vc : 0.0;
                         advance(SPIN == 0 ? 2 * s + h : s);
-                        rescale();
+                        if ((s & 3) == 3) promote();
                     }
                 }
                 // the tile is private to the wave: order its LDS writes before the reads
@@ -480,8 +487,6 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_synthesis(Sy
         }
     }
     const double sgn = (SPIN == 2 && h) ? -1.0 : 1.0;
-    auto scale_of = [](int e) { return e == 0 ? 1.0 : (e == -1 ? SC_SMALL : 0.0); };
-    double scf = scale_of(sc);
     double *mytile = &tiles[w][0][0][0];
     // synthesis reads A[ring i][l-row k]: rows k, k+1 of one instruction must fall into different
     // halves of the banks -> swizzle the column by (row & 1) << 4
@@ -534,28 +539,30 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_synthesis(Sy
         fetch(lb + LBLK);
         const double2 *cf = coefs[cbuf];
         if (wave_on) {
+            // live / dead chains: see k_legendre_analysis
             const bool all_live = __all(sc == 0 || !valid);
-            const bool all_dead = __all(sc <= -3 || !valid);
+            const bool all_dead = __all(sc < 0 || !valid);
             auto advance = [&](int e) {
                 const double2 c = cf[e];
                 const double vn = fma(fma(c.x, xx, sgn * c.y), vc, -vp);
                 vp = vc;
                 vc = vn;
             };
-            auto rescale = [&]() {
-                if (__any(fabs(vc) > SC_BIG)) {
-                    if (fabs(vc) > SC_BIG) {
+            auto promote = [&]() {
+                const bool up = sc < 0 && fabs(vc) > 1.0;
+                if (__any(up)) {
+                    if (up) {
                         vc *= SC_SMALL; vp *= SC_SMALL;
                         sc += 1;
-                        scf = scale_of(sc);
                     }
                 }
             };
             constexpr int NSTEP = SPIN == 0 ? LBLK / 2 : LBLK;
             if (all_dead) {
+#pragma unroll 4
                 for (int s = 0; s < NSTEP; ++s) {
                     advance(SPIN == 0 ? 2 * s + h : s);
-                    rescale();
+                    if ((s & 3) == 3) promote();
                 }
             } else {
                 if (all_live) {
@@ -566,12 +573,12 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_synthesis(Sy
                         advance(SPIN == 0 ? 2 * s + h : s);
                     }
                 } else {
-#pragma unroll 4
+#pragma unroll
                     for (int s = 0; s < NSTEP; ++s) {
                         const int t = SPIN == 0 ? 0 : ((s + off) & 1), r = SPIN == 0 ? s : (s >> 1);
-                        mytile[(t * 16 + r) * 64 + (lane ^ swz(r))] = vc * scf;
+                        mytile[(t * 16 + r) * 64 + (lane ^ swz(r))] = sc == 0 ? vc : 0.0;
                         advance(SPIN == 0 ? 2 * s + h : s);
-                        rescale();
+                        if ((s & 3) == 3) promote();
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

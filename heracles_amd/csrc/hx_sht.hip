@@ -22,6 +22,9 @@
 #include <cstdlib>
 
 #include "hx_sht_common.h"
+#ifndef HX_FFT_ABL
+#define HX_FFT_ABL 0  // timing experiments only (tools/fft_ablate.sh)
+#endif
 
 namespace hx {
 using namespace hxfft;
@@ -172,6 +175,9 @@ __global__ __launch_bounds__(1024) void k_ring_subdft(PlanDev P, const int *__re
             for (int q = 0; q < 4; ++q) {
                 if (MODE == 0) {
                     long long iN = sN + j + (long long)q * n;
+#if HX_FFT_ABL & 16
+                    zq[q] = make_double2(1.0 + j, 2.0 + q); continue;
+#endif
                     double fn = mp[iN];
                     if (pixw) fn *= pixw[iN];
                     double fs = 0.0;
@@ -187,24 +193,40 @@ __global__ __launch_bounds__(1024) void k_ring_subdft(PlanDev P, const int *__re
             }
             double2 t = dif4_combine(zq[0], zq[1], zq[2], zq[3], r);
             unsigned qn = load_phase_num(j, r, n, blu);
+#if HX_FFT_ABL & 1
+            val = cmul(t, make_double2(0.5, (double)qn));
+#else
             val = qn ? cmul(t, expipi(-(double)qn / (2.0 * n))) : t;
+#endif
         }
         buf[j] = val;
     }
     __syncthreads();
+#if !(HX_FFT_ABL & 2)
     lds_fft_dif(buf, M, P.tw, P.twN);
+#endif
     double2 *out = Y + (long long)c * P.ny + sN + (long long)r * n;
     if (!blu) {
         for (int k = threadIdx.x; k < n; k += blockDim.x) out[k] = buf[bitrev(k, p)];
         return;
     }
     const double2 *bh = P.bhat + P.bhat_off[rp];
+#if HX_FFT_ABL & 4
+    for (int j = threadIdx.x; j < M; j += blockDim.x) buf[j] = cmul(buf[j], make_double2(0.5, (double)j));
+#else
     for (int j = threadIdx.x; j < M; j += blockDim.x) buf[j] = cmul(buf[j], bh[j]);
+#endif
     __syncthreads();
+#if !(HX_FFT_ABL & 8)
     lds_fft_dit_inv(buf, M, P.tw, P.twN);
+#endif
     const double inv = 1.0 / M;
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
+#if HX_FFT_ABL & 1
+        double2 cz = make_double2(0.5, (double)chirp_num(k, n));
+#else
         double2 cz = expipi(-(double)chirp_num(k, n) / (double)n);
+#endif
         out[k] = cscale(cmul(buf[k], cz), inv);
     }
 }

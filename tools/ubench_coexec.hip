@@ -27,12 +27,49 @@ __global__ void k(int mode, int iters, double* out, unsigned long long* cyc, int
   double ma = 1e-3 + threadIdx.x * 1e-6, mb = 1.0;
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   if (role == 0) {
+#ifdef PRIO
+    __builtin_amdgcn_s_setprio(3);  // does the arbiter let the VALU chain in ahead of the MFMA stream?
+#endif
+#ifdef NCHAIN
+    // NCHAIN independent dependency chains per lane: latency- or throughput-starved beside MFMA?
+    double ch[NCHAIN];
+#pragma unroll
+    for (int u = 0; u < NCHAIN; ++u) ch[u] = a0 + u;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < NCHAIN; ++u) ch[u] = __builtin_fma(ch[u], x, y);
+    }
+#pragma unroll
+    for (int u = 0; u < NCHAIN; ++u) a1 += ch[u];
+#else
     for (int i = 0; i < iters; ++i) { a0 = __builtin_fma(a0, x, y); a1 = __builtin_fma(a1, x, y); }
+#endif
   } else if (role == 1) {
+#ifdef QUAD
+    // same flops per iteration as two 16x16x4: eight 4x4x4_4b on independent accumulators
+    double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(ma, mb, q[u], 0, 0, 0);
+    }
+    c0[0] = q[0] + q[1] + q[2] + q[3]; c1[1] = q[4] + q[5] + q[6] + q[7];
+#elif defined(NACC)
+    // NACC independent 16x16x4 accumulators per wave, 2 MFMAs per accumulator per iteration / NACC
+    double4_t cc[NACC];
+#pragma unroll
+    for (int u = 0; u < NACC; ++u) cc[u] = c0;
+    for (int i = 0; i < iters; i += NACC / 2) {
+#pragma unroll
+      for (int u = 0; u < NACC; ++u) cc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ma, mb, cc[u], 0,0,0);
+    }
+#pragma unroll
+    for (int u = 0; u < NACC; ++u) c0 += cc[u];
+#else
     for (int i = 0; i < iters; ++i) {
       c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ma, mb, c0, 0,0,0);
       c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ma, mb, c1, 0,0,0);
     }
+#endif
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + c0[0] + c1[1];
