@@ -41,7 +41,8 @@ struct LegParams {
     double *__restrict__ partial;      // [row - row0][16*NG]
     int m0;                            // first m of the chunk held in F
     long long row0;                    // first partial row of the chunk
-    int ng;                            // active column groups (<= NG)
+    int ng;                            // active column groups (<= NG, + 1 if there are extra 4-column blocks)
+    int ncol;                          // doubles per F / partial row: 16 per full group + 4 per extra block
     int ablate;                        // diagnostic only (HX_ABLATE): 1 skip MFMA, 2 skip recursion, 8 count paths
     unsigned long long *counters;
 };
@@ -75,7 +76,7 @@ __device__ inline void ring_modes_ns(const PlanDev &P, const double2 *__restrict
 // Component c lives in column group c/8, slot c%8 (spin 2: field f = c/2 in group f/4).
 template <int SPIN>
 __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double2 *__restrict__ Y, int ncomp, int ng,
-                                                         int m0, const double *__restrict__ rw,
+                                                         int ncol, int m0, const double *__restrict__ rw,
                                                          double *__restrict__ F)
 {
     constexpr int NOP = LegCfg<SPIN>::NOP;
@@ -85,11 +86,11 @@ __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double
     if (rp >= P.nrp_pad) return;
     const bool live = rp < P.nrp;
     const double w = live ? (rw ? rw[rp] : 1.0) * (4.0 * M_PI / (double)P.npix) : 0.0;
-    const int ncol = NCOL * ng;
     double *row = F + (((long long)blockIdx.x * P.nrp_pad + rp) * 2) * NOP * ncol;
     for (int g = 0; g < ng; ++g) {
         if (SPIN == 0) {
             const int c = g * 8 + slot;
+            if (g * NCOL + 2 * slot >= ncol) continue;  // beyond the last (4-column) block of the row
             double2 s = make_double2(0.0, 0.0), d = s;
             if (live && c < ncomp) {
                 double2 fn, fs;
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double
             *reinterpret_cast<double2 *>(row + ncol + g * NCOL + 2 * slot) = d;
         } else {
             const int f = g * 4 + (slot >> 1), op = slot & 1;
+            if (g * NCOL + 4 * (slot >> 1) >= ncol) continue;  // beyond the last field of the row
             double4 o0 = make_double4(0.0, 0.0, 0.0, 0.0), o1 = o0;
             if (live && 2 * f + 1 < ncomp) {
                 double2 qn, qs, un, us;
@@ -138,14 +140,13 @@ __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double
 // distinct 8-byte slots per 32-lane half (ds_read_b64) AND 16 distinct slots per 16-lane
 // group (ds_read2_b64, which hipcc forms for the two parity halves).
 __device__ __host__ inline int tile_swz(int r) { return r & 15; }
-__device__ __host__ inline int ringsel(int q, int k) { return (k & 1) * 16 + 2 * q + (k >> 1); }
 
 // NGQ > 0: NGQ groups of 16 columns on v_mfma_f64_16x16x4_f64.
 // NGQ < 0: -NGQ blocks of 4 columns on v_mfma_f64_4x4x4_4b_f64 (small batches: the four 4x4x4
 //          blocks take the four 4-row groups of the same [16 l x 4 rings] A operand, so the A
 //          layout -- row = lane&15, k = lane>>4 -- is unchanged; B lane (k, b, j) = F[ring k][col j],
 //          D lane (i, b, j) = row 4b+i, col j; measured 16 cycles / instruction).
-template <int SPIN, int NGQ>
+template <int SPIN, int NGQ, int NBX = 0>
 __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(LegParams A,
                                                                            const double2 *__restrict__ coefn,
                                                                            const double *__restrict__ alphan)
@@ -155,6 +156,12 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
     constexpr bool QUAD = NGQ < 0;            // 4-column MFMA path
     constexpr int NG = QUAD ? 1 : NGQ;        // 16-column groups held in the partial rows
     constexpr int NB = QUAD ? -NGQ : NGQ;     // B-operand register sets per (par, op, q)
+    // NBX > 0 (hybrid): after the NG full groups, NBX more blocks of 4 columns on the 4x4x4 MFMA --
+    // they share the recursion, the tiles and the flush of the full groups (e.g. 10 spin-0 maps =
+    // one 16-column group + one 4-column block in ONE sweep instead of two launches)
+    constexpr int NGT = NG + (NBX > 0 ? 1 : 0);
+    static_assert(!(QUAD && NBX > 0), "extra blocks only next to full groups");
+    static_assert(NGT * 512 <= LegCfg<SPIN>::NT * 1024, "D tiles must fit the wave's tile");
     __shared__ double tiles[NW][NT][16][64];  // 128 KiB; after the MFMA phase each wave's tiles carry its D tiles
     __shared__ double2 coefs[2][LBLK];        // recursion coefficients of this / the next block
     __shared__ double alphas[2][LBLK];        // output scalings alpha_l of this / the next block
@@ -188,10 +195,24 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
                     for (int g = 0; g < NB; ++g) {
                         // 16-col path: group g, column lane&15;  4-col path: block g, column lane&3
                         const int col = QUAD ? 4 * g + (lane & 3) : g * NCOL + ai;
-                        fr[g][par][op][q] = (wave_on && (QUAD || g < A.ng))
-                                                ? A.F[((row * 2 + par) * NOP + op) * (NCOL * A.ng) + col]
+                        fr[g][par][op][q] = (wave_on && (QUAD || (g < A.ng && col < A.ncol)))
+                                                ? A.F[((row * 2 + par) * NOP + op) * A.ncol + col]
                                                 : 0.0;
                     }
+        }
+    }
+    double frx[NBX > 0 ? NBX : 1][2][NOP][8];
+    if (NBX > 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const long long row = (long long)(m - A.m0) * P.nrp_pad + rb * RBLK + ringsel(q, ak);
+#pragma unroll
+            for (int par = 0; par < 2; ++par)
+#pragma unroll
+                for (int op = 0; op < NOP; ++op)
+#pragma unroll
+                    for (int g = 0; g < NBX; ++g)
+                        frx[g][par][op][q] = wave_on ? A.F[((row * 2 + par) * NOP + op) * A.ncol + NG * NCOL + 4 * g + (lane & 3)] : 0.0;
         }
     }
 
@@ -247,6 +268,9 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
         }
 #pragma unroll
         for (int g = 0; g < NB; ++g) accq[g][0] = accq[g][1] = 0.0;
+        double accx[NBX > 0 ? NBX : 1][2];
+#pragma unroll
+        for (int g = 0; g < (NBX > 0 ? NBX : 1); ++g) accx[g][0] = accx[g][1] = 0.0;
         if (wave_on && !(A.ablate & 2)) {
             // A chain is LIVE when its scale exponent is 0: its true value is >= 2^-300 and from
             // there on a plain double.  Below that it contributes nothing at double precision
@@ -323,6 +347,9 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
                                     else
                                         acc[g][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[g][par][op][q], acc[g][par], 0, 0, 0);
                                 }
+#pragma unroll
+                                for (int g = 0; g < NBX; ++g)
+                                    accx[g][par] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[g][par][op][q], accx[g][par], 0, 0, 0);
                             }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -350,11 +377,16 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         mytile[(g * 2 + par) * 256 + (ak + 4 * r) * 16 + ai] = acc[g][par][r];
+#pragma unroll
+            for (int g = 0; g < NBX; ++g)
+#pragma unroll
+                for (int par = 0; par < 2; ++par)
+                    mytile[(NG * 2 + par) * 256 + (4 * ((lane >> 2) & 3) + ak) * 16 + 4 * g + (lane & 3)] = accx[g][par];
         }
         lds_barrier();
-        for (int t = threadIdx.x; t < NG * 512; t += NW * 64) {
+        for (int t = threadIdx.x; t < NGT * 512; t += NW * 64) {
             const int g = t >> 9, par = (t >> 8) & 1, r16 = (t >> 4) & 15, col = t & 15;
-            if (g >= A.ng || (QUAD && col >= 4 * NB)) continue;
+            if (g >= A.ng || g * NCOL + col >= A.ncol || (QUAD && col >= 4 * NB)) continue;
             // fixed association (bit-reproducible), four independent chains for latency
             double s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -362,7 +394,7 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
             const double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
             const int l = lb + 2 * r16 + (par ^ off);
             if (l <= lmax)
-                A.partial[(task.pout - A.row0 + (l - l0)) * (NCOL * A.ng) + g * NCOL + col] = s * alphas[cbuf][l - lb];
+                A.partial[(task.pout - A.row0 + (l - l0)) * A.ncol + g * NCOL + col] = s * alphas[cbuf][l - lb];
         }
         lds_barrier();  // D tiles consumed: the tile buffers may be overwritten by the next block
     }
@@ -375,13 +407,13 @@ template <int SPIN>
 __global__ __launch_bounds__(256) void k_alm_reduce(PlanDev P, const LegTask *__restrict__ tasks,
                                                     const MTasks *__restrict__ of_m,
                                                     const double *__restrict__ partial, long long row0, int m0,
-                                                    int ncomp, int ng, const double *__restrict__ fl, int add,
+                                                    int ncomp, int ng, int ncol, const double *__restrict__ fl, int add,
                                                     double2 *__restrict__ alm, long long alm_stride)
 {
     const int m = m0 + blockIdx.x, lmax = P.lmax;
     const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
     const MTasks mt = of_m[m];
-    const int nl = lmax - m + 1, nc = 8 * ng, ncol = NCOL * ng;
+    const int nl = lmax - m + 1, nc = 8 * ng;
     for (int i = threadIdx.x; i < nl * nc; i += blockDim.x) {
         const int l = m + i / nc, c = i % nc;
         if (c >= ncomp) continue;
@@ -685,7 +717,9 @@ static int ring_mlim(int lmax, int spin, double sth, double cth)
 
 // spin 0: one column group per launch (a second group does not fit 128 VGPRs at 4 waves/SIMD);
 // spin 2: two groups (8 fields) share one recursion pass.
-int analysis_max_comp(int spin) { return spin == 0 ? 8 : 8 * NGMAX; }
+// spin 0: 8 components in a full group + 4 in two 4-column blocks.  spin 2: two full groups; a
+// third (<2,3>) needs 144 more VGPRs than the wave has and was measured 1.6x slower from spills.
+int analysis_max_comp(int spin) { return spin == 0 ? 12 : 8 * NGMAX; }  // spin 0: 8 in a full group + 4 in two 4-column blocks
 
 int build_tasks(hx_plan *pl, int spin)
 {
@@ -725,7 +759,7 @@ int build_tasks(hx_plan *pl, int spin)
 }
 
 template <int SPIN>
-static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int nb, int ng, const double *d_rw,
+static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int nb, int ng, int ncol, const double *d_rw,
                         const double *d_fl, int add, double2 *d_alms)
 {
     hipStream_t st = rt().stream;
@@ -735,14 +769,14 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
     {
         ProfScope ps("fourier_combine");
         dim3 grid(m1 - m0, pl->nrp_pad / 32);
-        hipLaunchKernelGGL(k_fourier_combine<SPIN>, grid, dim3(256), 0, st, P, pl->Y.as<double2>(), nb, ng, m0, d_rw, pl->F.as<double>());
+        hipLaunchKernelGGL(k_fourier_combine<SPIN>, grid, dim3(256), 0, st, P, pl->Y.as<double2>(), nb, ng, ncol, m0, d_rw, pl->F.as<double>());
     }
     if (t1 > t0) {
         ProfScope ps("legendre_analysis");
         ProfScope ps2(SPIN == 0 ? "legendre_analysis_s0" : "legendre_analysis_s2");
         LegParams A;
         A.P = P; A.tasks = ts.d_tasks.as<LegTask>() + t0; A.F = pl->F.as<double>(); A.partial = pl->partial.as<double>();
-        A.m0 = m0; A.row0 = ts.rows_before_m[m0]; A.ng = ng;
+        A.m0 = m0; A.row0 = ts.rows_before_m[m0]; A.ng = ng; A.ncol = ncol;
         const char *e = getenv("HX_ABLATE");
         A.ablate = e ? atoi(e) : 0;
         A.counters = nullptr;
@@ -763,6 +797,10 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
             hipLaunchKernelGGL((k_legendre_analysis<SPIN, -1>), grid, block, 0, st, A, cn, al);
         else if (quad_ok && ncols_used <= 8)
             hipLaunchKernelGGL((k_legendre_analysis<SPIN, -2>), grid, block, 0, st, A, cn, al);
+        else if (SPIN == 0 && ncol == NCOL + 4)
+            hipLaunchKernelGGL((k_legendre_analysis<0, 1, 1>), grid, block, 0, st, A, cn, al);
+        else if (SPIN == 0 && ncol == NCOL + 8)
+            hipLaunchKernelGGL((k_legendre_analysis<0, 1, 2>), grid, block, 0, st, A, cn, al);
         else if (ng == 1)
             hipLaunchKernelGGL((k_legendre_analysis<SPIN, 1>), grid, block, 0, st, A, cn, al);
         else
@@ -777,7 +815,7 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
     {
         ProfScope ps("alm_reduce");
         hipLaunchKernelGGL(k_alm_reduce<SPIN>, dim3(m1 - m0), dim3(256), 0, st, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
-                           pl->partial.as<double>(), ts.rows_before_m[m0], m0, nb, ng, d_fl, add, d_alms, pl->nlm);
+                           pl->partial.as<double>(), ts.rows_before_m[m0], m0, nb, ng, ncol, d_fl, add, d_alms, pl->nlm);
     }
     HX_HIP(hipGetLastError());
     return HX_OK;
@@ -794,7 +832,8 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     if (spin) HX_TRY(ensure_rec2(pl));
     hx_plan::TaskSet &ts = pl->ts[sidx];
     const int ng = (nb + 7) / 8;
-    const int ncol = NCOL * ng;
+    // spin 0 beyond 8 components: one full group + (nb - 8 + 1) / 2 blocks of 4 columns
+    const int ncol = (spin == 0 && nb > 8) ? NCOL + 4 * ((nb - 8 + 1) / 2) : NCOL * ng;
     HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
     HX_TRY(launch_ring_subdft_maps(pl, nb, d_maps, d_pw, pl->Y.as<double2>()));
 
@@ -821,9 +860,9 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     HX_TRY(pl->partial.alloc(maxP));
     for (auto &ch : chunks) {
         if (spin == 0)
-            HX_TRY(launch_chunk<0>(pl, ts, ch.first, ch.second, nb, ng, d_rw, d_fl, add, d_alms));
+            HX_TRY(launch_chunk<0>(pl, ts, ch.first, ch.second, nb, ng, ncol, d_rw, d_fl, add, d_alms));
         else
-            HX_TRY(launch_chunk<2>(pl, ts, ch.first, ch.second, nb, ng, d_rw, d_fl, add, d_alms));
+            HX_TRY(launch_chunk<2>(pl, ts, ch.first, ch.second, nb, ng, ncol, d_rw, d_fl, add, d_alms));
     }
     return HX_OK;
 }
