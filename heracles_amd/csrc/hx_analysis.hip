@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double
 // distinct 8-byte slots per 32-lane half (ds_read_b64) AND 16 distinct slots per 16-lane
 // group (ds_read2_b64, which hipcc forms for the two parity halves).
 __device__ __host__ inline int tile_swz(int r) { return r & 15; }
+__device__ __host__ inline int ringsel(int q, int k) { return (k & 1) * 16 + 2 * q + (k >> 1); }
 
 // NGQ > 0: NGQ groups of 16 columns on v_mfma_f64_16x16x4_f64.
 // NGQ < 0: -NGQ blocks of 4 columns on v_mfma_f64_4x4x4_4b_f64 (small batches: the four 4x4x4
