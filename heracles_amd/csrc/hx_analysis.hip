@@ -180,6 +180,7 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
     const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
     const int off = (l0 + m) & 1;
     const long long cb = almidx(lmax, 0, m);
+    const long long cbs = __builtin_amdgcn_readfirstlane((int)cb);  // nlm < 2^31 for every supported lmax
     const int ai = lane & 15, ak = lane >> 4;
 
     // ---- B operands: F[m - m0][rp][par][op][g*16 + j], lane (k = lane>>4, j = lane&15) ----
@@ -286,7 +287,11 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
 #ifdef HX_FAKECOEF
                 const double2 c = make_double2(1.0e-3 * e, 0.5);  // timing experiment only
 #else
-                const double2 c = cf[e];
+                // spin 2: the entry is the same for every lane -> scalar loads (s_load_dwordx16, four
+                // steps each) through the constant cache instead of 64-lane LDS broadcasts, which
+                // cost the LDS pipe as much as the tile stores (measured -10 % kernel time).
+                // spin 0: entry 2j+h differs between the lane halves and stays in LDS.
+                const double2 c = SPIN == 2 ? coefn[cbs + lb + coff + e] : cf[e];
 #endif
                 const double vn = fma(fma(c.x, xx, sgn * c.y), vc, -vp);
                 vp = vc;
@@ -501,6 +506,7 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_synthesis(Sy
     const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
     const int off = (l0 + m) & 1;
     const long long cb = almidx(lmax, 0, m);
+    const long long cbs = __builtin_amdgcn_readfirstlane((int)cb);
     const int ai = lane & 15, ak = lane >> 4;
 
     double vc = 0.0, vp = 0.0;
@@ -576,7 +582,7 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_synthesis(Sy
             const bool all_live = __all(sc == 0 || !valid);
             const bool all_dead = __all(sc < 0 || !valid);
             auto advance = [&](int e) {
-                const double2 c = cf[e];
+                const double2 c = SPIN == 2 ? coefn[cbs + lb + coff + e] : cf[e];  // see k_legendre_analysis
                 const double vn = fma(fma(c.x, xx, sgn * c.y), vc, -vp);
                 vp = vc;
                 vc = vn;
