@@ -840,7 +840,11 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     hx_plan::TaskSet &ts = pl->ts[sidx];
     const int ng = (nb + 7) / 8;
     // spin 0 beyond 8 components: one full group + (nb - 8 + 1) / 2 blocks of 4 columns
-    const int ncol = (spin == 0 && nb > 8) ? NCOL + 4 * ((nb - 8 + 1) / 2) : NCOL * ng;
+    // doubles per F / partial row: only the columns in use are stored -- 4-column granularity on the
+    // 4x4x4 path (<= 8 columns), 16 per full group, + 4 per extra block of the spin-0 hybrid
+    const char *eq = getenv("HX_NO_QUAD");
+    const bool quad = !(eq && atoi(eq)) && 2 * nb <= 8;
+    const int ncol = quad ? 4 * ((2 * nb + 3) / 4) : (spin == 0 && nb > 8) ? NCOL + 4 * ((nb - 8 + 1) / 2) : NCOL * ng;
     HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
     HX_TRY(launch_ring_subdft_maps(pl, nb, d_maps, d_pw, pl->Y.as<double2>()));
 
