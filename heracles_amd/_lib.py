@@ -28,7 +28,7 @@ SYMBOLS = (
     "hx_profile_enable", "hx_profile_reset", "hx_profile_get", "hx_plan_create",
     "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_map2alm", "hx_alm2map",
     "hx_alm2cl_pairs", "hx_gauss_legendre", "hx_wigner_d_table", "hx_mixmat",
-    "hx_mixmat_eb", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values",
+    "hx_mixmat_eb", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade",
 )
 
 
@@ -86,6 +86,7 @@ def load():
         L.hx_corr2cl.argtypes = [i, i, dp, dp]
         L.hx_ang2pix_ring.argtypes = [i, C.c_int64, dp, dp, dp]
         L.hx_map_values.argtypes = [i, C.c_int64, dp, dp, i, dp, dp, i]
+        L.hx_ud_grade.argtypes = [i, i, i, dp, dp]
         L.hx_timer_stop.argtypes = [C.POINTER(C.c_float)]
         L.hx_profile_get.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         _lib = L

@@ -107,7 +107,139 @@ __global__ __launch_bounds__(256) void k_scatter_atomic(long long n, const long 
         unsafeAtomicAdd(&maps[(long long)v * npix + p], values[(long long)v * vstride + j]);
 }
 
+// ---- RING <-> NEST (healpix_cxx ring2xyf / xyf2nest / nest2xyf / xyf2ring), nside = 2^order ----
+__constant__ int c_jrll[12] = {2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4};
+__constant__ int c_jpll[12] = {1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7};
+
+__device__ inline long long spread_bits(long long v)  // bit b -> bit 2b (v < 2^16)
+{
+    v = (v | (v << 8)) & 0x00ff00ffll;
+    v = (v | (v << 4)) & 0x0f0f0f0fll;
+    v = (v | (v << 2)) & 0x33333333ll;
+    v = (v | (v << 1)) & 0x55555555ll;
+    return v;
+}
+__device__ inline long long compress_bits(long long v)  // bit 2b -> bit b
+{
+    v &= 0x55555555ll;
+    v = (v | (v >> 1)) & 0x33333333ll;
+    v = (v | (v >> 2)) & 0x0f0f0f0fll;
+    v = (v | (v >> 4)) & 0x00ff00ffll;
+    v = (v | (v >> 8)) & 0x0000ffffll;
+    return v;
+}
+__device__ inline long long isqrt_ll(long long v) { return (long long)sqrt((double)v + 0.5); }
+
+__device__ inline long long nest2ring_dev(int order, long long pnest)
+{
+    const long long nside = 1ll << order, npface = nside * nside, npix = 12 * npface;
+    const long long ncap = 2 * nside * (nside - 1), nl4 = 4 * nside;
+    const int face = (int)(pnest >> (2 * order));
+    const long long pf = pnest & (npface - 1);
+    const long long ix = compress_bits(pf), iy = compress_bits(pf >> 1);
+    const long long jr = ((long long)c_jrll[face] << order) - ix - iy - 1;
+    long long nr, n_before, kshift;
+    if (jr < nside) { nr = jr; n_before = 2 * nr * (nr - 1); kshift = 0; }
+    else if (jr > 3 * nside) { nr = nl4 - jr; n_before = npix - 2 * (nr + 1) * nr; kshift = 0; }
+    else { nr = nside; n_before = ncap + (jr - nside) * nl4; kshift = (jr - nside) & 1; }
+    long long jp = (c_jpll[face] * nr + ix - iy + 1 + kshift) / 2;
+    if (jp > nl4) jp -= nl4;
+    else if (jp < 1) jp += nl4;
+    return n_before + jp - 1;
+}
+
+__device__ inline long long ring2nest_dev(int order, long long pring)
+{
+    const long long nside = 1ll << order, npface = nside * nside, npix = 12 * npface;
+    const long long ncap = 2 * nside * (nside - 1), nl4 = 4 * nside;
+    long long iring, iphi, kshift, nr;
+    int face;
+    if (pring < ncap) {
+        iring = (1 + isqrt_ll(1 + 2 * pring)) >> 1;
+        iphi = (pring + 1) - 2 * iring * (iring - 1);
+        kshift = 0; nr = iring;
+        face = (int)((iphi - 1) / nr);
+    } else if (pring < npix - ncap) {
+        const long long ip = pring - ncap, tmp = ip >> (order + 2);
+        iring = tmp + nside;
+        iphi = ip - tmp * nl4 + 1;
+        kshift = (iring + nside) & 1; nr = nside;
+        const long long ire = tmp + 1, irm = 2 * nside + 1 - tmp;
+        const long long ifm = (iphi - ire / 2 + nside - 1) >> order, ifp = (iphi - irm / 2 + nside - 1) >> order;
+        face = (int)((ifp == ifm) ? (ifp | 4) : ((ifp < ifm) ? ifp : (ifm + 8)));
+    } else {
+        const long long ip = npix - pring;
+        const long long ir = (1 + isqrt_ll(2 * ip - 1)) >> 1;
+        iphi = 4 * ir + 1 - (ip - 2 * ir * (ir - 1));
+        kshift = 0; nr = ir;
+        iring = nl4 - ir;
+        face = (int)(8 + (iphi - 1) / nr);
+    }
+    const long long irt = iring - c_jrll[face] * nside + 1;
+    long long ipt = 2 * iphi - c_jpll[face] * nr - kshift - 1;
+    if (ipt >= 2 * nside) ipt -= 8 * nside;
+    const long long ix = (ipt - irt) >> 1, iy = (-ipt - irt) >> 1;
+    return face * npface + spread_bits(ix) + (spread_bits(iy) << 1);
+}
+
+// numpy's pairwise summation (the arithmetic behind healpy's np.sum(axis=1) in _ud_grade_core):
+// n < 8 sequential from 0; n <= 128 eight strided accumulators; else split at n/2 rounded to 8.
+template <class Load>
+__device__ double numpy_pairwise_sum(long long i0, long long n, Load load)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (long long i = 0; i < n; ++i) res += load(i0 + i);
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = load(i0 + k);
+        long long i = 8;
+        for (; i < n - (n % 8); i += 8)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] += load(i0 + i + k);
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += load(i0 + i);
+        return res;
+    }
+    long long n2 = n / 2;
+    n2 -= n2 % 8;
+    return numpy_pairwise_sum(i0, n2, load) + numpy_pairwise_sum(i0 + n2, n - n2, load);
+}
+
+constexpr double kUnseen = -1.6375e30;
+
+// healpy.ud_grade, RING -> RING, pess=False, power=None.  One thread per output pixel.
+__global__ __launch_bounds__(256) void k_ud_grade(int order_in, int order_out, const double *__restrict__ in,
+                                                  double *__restrict__ out)
+{
+    const long long npix_out = 12ll << (2 * order_out), npix_in = 12ll << (2 * order_in);
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix_out) return;
+    const double *src = in + (long long)blockIdx.y * npix_in;
+    double *dst = out + (long long)blockIdx.y * npix_out;
+    const long long q = ring2nest_dev(order_out, p);
+    if (order_out >= order_in) {
+        dst[p] = src[nest2ring_dev(order_in, q >> (2 * (order_out - order_in)))];
+        return;
+    }
+    const long long rat2 = 1ll << (2 * (order_in - order_out));
+    long long nhit = 0;
+    // mask_bad(rtol=1e-5, atol=1e-15) | ~isfinite; a masked value enters the sum as value * 0
+    auto load = [&](long long c) {
+        const double v = src[nest2ring_dev(order_in, q * rat2 + c)];
+        const bool good = !(fabs(v - kUnseen) <= 1e-15 + 1e-5 * fabs(kUnseen)) && isfinite(v);
+        nhit += good;
+        return good ? v : v * 0.0;
+    };
+    const double s = numpy_pairwise_sum(0, rat2, load);
+    dst[p] = nhit ? s / (double)nhit : kUnseen;
+}
+
 bool nside_ok(int nside) { return nside >= 1 && nside <= (1 << 24); }
+bool nside_pow2(int nside) { return nside >= 1 && nside <= 8192 && (nside & (nside - 1)) == 0; }
 
 int launch_ang2pix(int nside, long long n, const double *lon, const double *lat, long long *ipix, unsigned *order)
 {
@@ -209,4 +341,29 @@ extern "C" int hx_map_values(int nside, int64_t n, const double *lon, const doub
     // temporaries die with this scope: the stream must have drained them
     HX_HIP(hipStreamSynchronize(st));
     return HX_OK;
+}
+
+extern "C" int hx_ud_grade(int nside_in, int nside_out, int nmaps, const double *in, double *out)
+{
+    HX_TRY(ensure_ready());
+    if (!nside_pow2(nside_in) || !nside_pow2(nside_out))
+        return fail(HX_ERR_ARG, "hx_ud_grade: %d -> %d: nside must be a power of 2 (<= 8192)", nside_in, nside_out);
+    if (nmaps < 0 || (nmaps > 0 && (!in || !out))) return fail(HX_ERR_ARG, "hx_ud_grade: bad arguments");
+    if (nmaps == 0) return HX_OK;
+    const long long npix_in = 12ll * nside_in * nside_in, npix_out = 12ll * nside_out * nside_out;
+    InView vin;
+    OutView vout;
+    HX_TRY(vin.bind(in, sizeof(double) * npix_in * nmaps));
+    HX_TRY(vout.bind(out, sizeof(double) * npix_out * nmaps));
+    int oi = 0, oo = 0;
+    while ((1 << oi) < nside_in) ++oi;
+    while ((1 << oo) < nside_out) ++oo;
+    {
+        ProfScope ps("ud_grade");
+        hipLaunchKernelGGL(k_ud_grade, dim3((unsigned)((npix_out + 255) / 256), nmaps), dim3(256), 0, rt().stream, oi, oo,
+                           vin.as<double>(), vout.as<double>());
+        HX_HIP(hipGetLastError());
+    }
+    HX_TRY(vout.finish());
+    return finish_call();
 }

@@ -116,6 +116,38 @@ def map_values(nside, lon, lat, data, values, *, ordered=True):
         data[...] = maps
 
 
+def ud_grade(data, nside_out, dtype=np.float64):
+    """``hp.ud_grade(data, nside_out, dtype=dtype)`` for RING maps (pess=False, power=None):
+    mean of the unmasked children / replication, on the GPU.  numpy in -> numpy out,
+    device tensor in -> device tensor out."""
+    from . import _lib
+
+    _lib.ensure_init()
+    npix_in = data.shape[-1]
+    nside_in = int(round((npix_in / 12) ** 0.5))
+    if 12 * nside_in * nside_in != npix_in:
+        raise ValueError("Wrong pixel number (it is not 12*nside**2)")
+    for ns in (nside_in, nside_out):
+        if ns < 1 or ns & (ns - 1):
+            raise ValueError(f"{ns} is not a valid nside parameter (must be a power of 2, less than 2**30)")
+    npix_out = 12 * nside_out * nside_out
+    nmaps = 1
+    for d in data.shape[:-1]:
+        nmaps *= d
+    if hasattr(data, "data_ptr"):
+        import torch
+
+        src = data.to(torch.float64).contiguous()
+        out = torch.empty((*data.shape[:-1], npix_out), dtype=torch.float64, device=data.device)
+    else:
+        src = np.ascontiguousarray(_native(data), dtype=np.float64)
+        out = np.empty((*data.shape[:-1], npix_out), dtype=np.float64)
+    _lib.check(_lib.load().hx_ud_grade(nside_in, int(nside_out), nmaps, _lib.ptr(src), _lib.ptr(out)))
+    if not hasattr(out, "data_ptr") and np.dtype(dtype) != np.float64:
+        out = out.astype(dtype)
+    return out
+
+
 class HipHealpixMapper:
     """Mapper for HEALPix maps whose ``transform`` runs on MI355X."""
 
@@ -214,8 +246,5 @@ class HipHealpixMapper:
         return out
 
     def resample(self, data):
-        """Change resolution (hp.ud_grade, heracles/healpy.py:205-209).  Only the identity
-        case is provided here; NSIDE changes are a "next" row."""
-        if data.shape[-1] == 12 * self.__nside**2:
-            return np.array(data, dtype=self.__dtype)
-        raise NotImplementedError("ud_grade between different NSIDE is not part of the hot path")
+        """Change resolution of HEALPix maps (hp.ud_grade, heracles/healpy.py:205-209) on the GPU."""
+        return ud_grade(data, self.__nside, dtype=self.__dtype)

@@ -115,6 +115,13 @@ int hx_ang2pix_ring(int nside, int64_t n, const double *lon, const double *lat, 
 int hx_map_values(int nside, int64_t n, const double *lon, const double *lat, int nval,
                   const double *values, double *maps, int flags);
 
+/* Replaces hp.ud_grade(data, nside, dtype=float64) of HealpixMapper.resample
+ * (heracles/healpy.py:205-209): RING in, RING out, pess=False, power=None -- degrade = mean of
+ * the unmasked children (UNSEEN if none), summed in numpy's pairwise order over the NEST
+ * children; upgrade = replication.  in: [nmaps][12 nside_in^2], out: [nmaps][12 nside_out^2].
+ * Both nside must be powers of two (healpy raises ValueError otherwise; here HX_ERR_ARG).   */
+int hx_ud_grade(int nside_in, int nside_out, int nmaps, const double *in, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -297,3 +297,116 @@ def map_values(nside, lon, lat, data, values):
     vals = np.broadcast_to(np.asarray(values, dtype=np.float64), (*data.shape[:-1], ipix.size)).reshape(-1, ipix.size)
     for row in range(flat.shape[0]):
         np.add.at(flat[row], ipix, vals[row])
+
+
+# ---- resolution change (numpy restatement of healpy.ud_grade) ------------------------
+_JRLL = np.array([2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4], dtype=np.int64)
+_JPLL = np.array([1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7], dtype=np.int64)
+UNSEEN = -1.6375e30
+
+
+def _spread(v):
+    v = np.asarray(v, dtype=np.int64)
+    out = np.zeros_like(v)
+    for b in range(16):
+        out |= ((v >> b) & 1) << (2 * b)
+    return out
+
+
+def _compress(v):
+    v = np.asarray(v, dtype=np.int64)
+    out = np.zeros_like(v)
+    for b in range(16):
+        out |= ((v >> (2 * b)) & 1) << b
+    return out
+
+
+def _isqrt(v):
+    return np.floor(np.sqrt(np.asarray(v, dtype=np.float64) + 0.5)).astype(np.int64)
+
+
+def nest2ring(nside, pnest):
+    """healpix_cxx T_Healpix_Base::nest2ring (nest2xyf + xyf2ring); nside a power of two."""
+    pnest = np.asarray(pnest, dtype=np.int64)
+    order = int(nside).bit_length() - 1
+    npface, npix, ncap, nl4 = nside * nside, 12 * nside * nside, 2 * nside * (nside - 1), 4 * nside
+    face = pnest >> (2 * order)
+    pf = pnest & (npface - 1)
+    ix, iy = _compress(pf), _compress(pf >> 1)
+    jr = (_JRLL[face] << order) - ix - iy - 1
+    north, south = jr < nside, jr > 3 * nside
+    nr = np.where(north, jr, np.where(south, nl4 - jr, nside))
+    n_before = np.where(north, 2 * nr * (nr - 1), np.where(south, npix - 2 * (nr + 1) * nr, ncap + (jr - nside) * nl4))
+    kshift = np.where(north | south, 0, (jr - nside) & 1)
+    jp = (_JPLL[face] * nr + ix - iy + 1 + kshift) // 2
+    jp = np.where(jp > nl4, jp - nl4, np.where(jp < 1, jp + nl4, jp))
+    return n_before + jp - 1
+
+
+def ring2nest(nside, pring):
+    """healpix_cxx T_Healpix_Base::ring2nest (ring2xyf + xyf2nest); nside a power of two."""
+    pring = np.asarray(pring, dtype=np.int64)
+    order = int(nside).bit_length() - 1
+    npface, npix, ncap, nl4 = nside * nside, 12 * nside * nside, 2 * nside * (nside - 1), 4 * nside
+    # north cap
+    irn = (1 + _isqrt(1 + 2 * pring)) >> 1
+    ipn = (pring + 1) - 2 * irn * (irn - 1)
+    fn = (ipn - 1) // np.maximum(irn, 1)
+    # equatorial belt
+    ip = pring - ncap
+    tmp = ip >> (order + 2)
+    ire_ring = tmp + nside
+    ipe = ip - tmp * nl4 + 1
+    kse = (ire_ring + nside) & 1
+    ire, irm = tmp + 1, 2 * nside + 1 - tmp
+    ifm = (ipe - ire // 2 + nside - 1) >> order
+    ifp = (ipe - irm // 2 + nside - 1) >> order
+    fe = np.where(ifp == ifm, ifp | 4, np.where(ifp < ifm, ifp, ifm + 8))
+    # south cap
+    ips = npix - pring
+    irs = (1 + _isqrt(np.maximum(2 * ips - 1, 0))) >> 1
+    iphs = 4 * irs + 1 - (ips - 2 * irs * (irs - 1))
+    fs = 8 + (iphs - 1) // np.maximum(irs, 1)
+    north, south = pring < ncap, pring >= npix - ncap
+    iring = np.where(north, irn, np.where(south, nl4 - irs, ire_ring))
+    iphi = np.where(north, ipn, np.where(south, iphs, ipe))
+    kshift = np.where(north | south, 0, kse)
+    nr = np.where(north, irn, np.where(south, irs, nside))
+    face = np.where(north, fn, np.where(south, fs, fe))
+    irt = iring - _JRLL[face] * nside + 1
+    ipt = 2 * iphi - _JPLL[face] * nr - kshift - 1
+    ipt = np.where(ipt >= 2 * nside, ipt - 8 * nside, ipt)
+    ix, iy = (ipt - irt) >> 1, (-ipt - irt) >> 1
+    return face * npface + _spread(ix) + (_spread(iy) << 1)
+
+
+def ud_grade(m, nside_out):
+    """hp.ud_grade(m, nside_out, dtype=float64) as called at heracles/healpy.py:205-209
+    (RING in, RING out, pess=False, power=None): healpy.pixelfunc.ud_grade = reorder to
+    NEST, _ud_grade_core, reorder back.  np.sum(axis=1) below IS the arithmetic healpy
+    runs (pairwise summation of each parent's children in NEST order)."""
+    m = np.asarray(m, dtype=np.float64)
+    if m.ndim > 1:
+        return np.stack([ud_grade(x, nside_out) for x in m])
+    npix_in = m.shape[-1]
+    nside_in = int(round(np.sqrt(npix_in / 12)))
+    for ns in (nside_in, nside_out):
+        if ns < 1 or ns & (ns - 1):
+            raise ValueError(f"{ns} is not a valid nside parameter (must be a power of 2)")
+    npix_out = 12 * nside_out * nside_out
+    m_nest = m[nest2ring(nside_in, np.arange(npix_in))]
+    if nside_out > nside_in:
+        rat2 = npix_out // npix_in
+        out_nest = np.outer(m_nest, np.ones(rat2)).reshape(npix_out)
+    elif nside_out < nside_in:
+        rat2 = npix_in // npix_out
+        mr = m_nest.reshape(npix_out, rat2)
+        with np.errstate(invalid="ignore"):
+            goods = ~((np.absolute(mr - UNSEEN) <= 1e-15 + 1e-5 * np.absolute(UNSEEN)) | (~np.isfinite(mr)))
+            out_nest = np.sum(mr * goods, axis=1)
+        nhit = goods.sum(axis=1)
+        out_nest[nhit != 0] = out_nest[nhit != 0] / nhit[nhit != 0]
+        out_nest[nhit == 0] = UNSEEN
+    else:
+        out_nest = m_nest
+    return out_nest[ring2nest(nside_out, np.arange(npix_out))]

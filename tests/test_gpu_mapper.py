@@ -240,3 +240,52 @@ def test_map_values_full_size_checksum():
     ipix = ang2pix_ring(nside, lon, lat)
     assert int(ipix.min()) >= 0 and int(ipix.max()) < npix
     assert torch.equal(maps[0], torch.bincount(ipix, minlength=npix).to(torch.float64))
+
+
+# ---- resample / ud_grade (hx_ud_grade) ---------------------------------------------------
+@pytest.mark.parametrize("nside_in,nside_out", [(16, 8), (16, 4), (32, 2), (64, 1), (8, 8), (4, 16), (1, 8), (128, 16)])
+def test_ud_grade_matches_oracle(oracle, nside_in, nside_out):
+    """Bit-identical to healpy's arithmetic (numpy pairwise sums over the NEST children)."""
+    from heracles_amd.mapper import ud_grade
+
+    rng = np.random.default_rng(nside_in * 100 + nside_out)
+    m = rng.standard_normal((3, 12 * nside_in**2)) * 10.0 ** rng.integers(-5, 5, (3, 12 * nside_in**2))
+    m[1, rng.integers(0, m.shape[1], m.shape[1] // 3)] = oracle.UNSEEN   # masked pixels
+    m[2, :7] = [np.nan, np.inf, -np.inf, oracle.UNSEEN, 0.0, -0.0, 1e300]
+    got = ud_grade(m, nside_out)
+    exp = oracle.ud_grade(m, nside_out)
+    assert got.shape == exp.shape == (3, 12 * nside_out**2)
+    np.testing.assert_array_equal(got, exp)
+    np.testing.assert_array_equal(ud_grade(m[0], nside_out), exp[0])
+
+
+def test_mapper_resample_and_errors(oracle):
+    import torch
+    from heracles_amd import HipHealpixMapper
+    from heracles_amd.mapper import ud_grade
+
+    rng = np.random.default_rng(5)
+    m = rng.standard_normal(12 * 64**2)
+    mapper = HipHealpixMapper(16, dtype=np.float32)
+    out = mapper.resample(m)
+    assert out.dtype == np.float32 and out.shape == (12 * 16**2,)
+    np.testing.assert_array_equal(out, oracle.ud_grade(m, 16).astype(np.float32))
+    dev = ud_grade(torch.as_tensor(m).cuda(), 256)
+    assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), oracle.ud_grade(m, 256))
+    with pytest.raises(ValueError, match="power of 2"):
+        ud_grade(m, 12)
+    with pytest.raises(ValueError, match="12\\*nside"):
+        ud_grade(m[:-1], 16)
+
+
+def test_ud_grade_full_size_properties():
+    """nside 4096 -> 1024 -> 4096 on the device: the mean is conserved, replication is exact."""
+    import torch
+    from heracles_amd.mapper import ud_grade
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    m = torch.randint(-2**20, 2**20, (12 * 4096**2,), device="cuda", generator=g).to(torch.float64)
+    d = ud_grade(m, 1024)
+    assert float(d.sum()) * 16 == float(m.sum())        # integer-valued pixels: every sum is exact
+    u = ud_grade(d, 4096)
+    assert torch.equal(ud_grade(u, 1024), d)

@@ -236,3 +236,34 @@ def test_oracle_ang2pix_and_map_values(oracle):
         exp[0, i] += x[j]
         exp[1, i] += y[j]
     np.testing.assert_array_equal(m, exp)
+
+
+def test_oracle_ring_nest_and_ud_grade(oracle):
+    """RING<->NEST restatement: bijection, consistency with ang2pix across resolutions (a NEST
+    parent is index >> 2), and ud_grade against its definition."""
+    for ns in (1, 2, 4, 8, 32):
+        p = np.arange(12 * ns * ns)
+        q = oracle.ring2nest(ns, p)
+        assert np.array_equal(np.sort(q), p)
+        assert np.array_equal(oracle.nest2ring(ns, q), p)
+    rng = np.random.default_rng(11)
+    lon = rng.uniform(0, 360, 50000)
+    lat = np.degrees(np.arcsin(rng.uniform(-1, 1, 50000)))
+    for ns in (2, 16, 256):
+        fine, coarse = oracle.ang2pix_ring(ns, lon, lat), oracle.ang2pix_ring(ns // 2, lon, lat)
+        assert np.array_equal(oracle.nest2ring(ns // 2, oracle.ring2nest(ns, fine) >> 2), coarse)
+    m = rng.standard_normal(12 * 16 * 16)
+    d = oracle.ud_grade(m, 8)
+    kids = oracle.nest2ring(16, 4 * oracle.ring2nest(8, np.arange(12 * 64))[:, None] + np.arange(4))
+    np.testing.assert_allclose(d, m[kids].mean(axis=1), rtol=1e-15, atol=1e-16)
+    u = oracle.ud_grade(m, 64)
+    assert np.array_equal(oracle.ud_grade(u, 16), m)           # replicate, then average equal values
+    assert np.array_equal(oracle.ud_grade(m, 16), m)
+    m2 = m.copy()
+    m2[kids[5]] = oracle.UNSEEN                                  # a fully masked parent
+    m2[kids[7, :2]] = oracle.UNSEEN                              # a half masked parent
+    d2 = oracle.ud_grade(m2, 8)
+    assert d2[5] == oracle.UNSEEN
+    assert d2[7] == (m[kids[7, 2]] + m[kids[7, 3]]) / 2          # masked children enter the sum as zeros
+    with pytest.raises(ValueError):
+        oracle.ud_grade(m, 12)
