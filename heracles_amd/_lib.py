@@ -26,7 +26,7 @@ SYMBOLS = (
     "hx_version", "hx_last_error", "hx_device_count", "hx_init", "hx_set_stream",
     "hx_get_stream", "hx_set_async", "hx_synchronize", "hx_timer_start", "hx_timer_stop",
     "hx_profile_enable", "hx_profile_reset", "hx_profile_get", "hx_plan_create",
-    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_map2alm", "hx_alm2map",
+    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_plan_mfma_flops", "hx_map2alm", "hx_alm2map",
     "hx_alm2cl_pairs", "hx_gauss_legendre", "hx_wigner_d_table", "hx_mixmat",
     "hx_mixmat_eb", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade",
 )
@@ -75,6 +75,7 @@ def load():
         L.hx_plan_destroy.restype = None
         L.hx_plan_scratch_bytes.argtypes = [vp]
         L.hx_plan_scratch_bytes.restype = C.c_int64
+        L.hx_plan_mfma_flops.argtypes = [vp, i, i, C.POINTER(C.c_double)]
         L.hx_map2alm.argtypes = [vp, i, i, dp, dp, dp, dp, dp, i]
         L.hx_alm2map.argtypes = [vp, i, i, dp, dp]
         L.hx_alm2cl_pairs.argtypes = [i, vp, vp, i, i, vp, vp, dp]

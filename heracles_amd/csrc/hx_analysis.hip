@@ -888,3 +888,37 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
 }
 
 }  // namespace hx
+
+// Executed matrix-instruction flops of one hx_map2alm(niter = 0) call with ncomp components:
+// every wave-block of the task list issues 8 (ring quads) x 2 (parities) x NOP MFMAs per full
+// 16-column group (2048 flop each) and per 4-column block (512 flop each).  Blocks whose rings
+// are all still below 2^-300 skip their MFMAs, so this is an upper bound (by < 10 %).
+extern "C" int hx_plan_mfma_flops(hx_plan *pl, int spin, int ncomp, double *flops)
+{
+    using namespace hx;
+    if (!pl || !flops || ncomp < 1 || (spin != 0 && spin != 2)) return fail(HX_ERR_ARG, "hx_plan_mfma_flops: bad arguments");
+    HX_TRY(ensure_ready());
+    HX_TRY(build_tasks(pl, spin));
+    const hx_plan::TaskSet &ts = pl->ts[spin ? 1 : 0];
+    const int nop = spin ? 2 : 1, l0min = spin ? 2 : 0;
+    double wave_blocks = 0.0;
+    for (const LegTask &t : ts.tasks) {
+        const int l0 = std::max(t.m, l0min);
+        wave_blocks += (double)t.nrb * ((pl->lmax - l0) / LBLK + 1);
+    }
+    const char *eq = getenv("HX_NO_QUAD");
+    const bool quad_ok = !(eq && atoi(eq));
+    double per_wave_block = 0.0;
+    const int bs = analysis_max_comp(spin);
+    for (int c0 = 0; c0 < ncomp; c0 += bs) {
+        const int nb = std::min(bs, ncomp - c0), cols = 2 * nb;
+        double full = 0, quad = 0;
+        if (quad_ok && cols <= 8) quad = (cols + 3) / 4;
+        else if (spin == 0 && nb > 8) { full = 1; quad = (nb - 8 + 1) / 2; }
+        else full = (nb + 7) / 8;
+        per_wave_block += 16.0 * nop * (full * 2048.0 + quad * 512.0);
+    }
+    *flops = wave_blocks * per_wave_block;
+    return HX_OK;
+}
+

@@ -48,6 +48,14 @@ class Plan:
     def scratch_bytes(self) -> int:
         return int(_lib.load().hx_plan_scratch_bytes(self._h))
 
+    def mfma_flops(self, spin, ncomp):
+        """Matrix-instruction flops one map2alm(niter=0) of ncomp components executes."""
+        import ctypes
+
+        out = ctypes.c_double(0.0)
+        _lib.check(_lib.load().hx_plan_mfma_flops(self._h, int(spin), int(ncomp), ctypes.byref(out)))
+        return out.value
+
     # -- helpers ------------------------------------------------------------------
     def _out_like(self, ref, shape, complex_):
         if _is_tensor(ref):

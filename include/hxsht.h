@@ -61,6 +61,10 @@ int hx_profile_get(const char *name, int *launches, double *total_ms);
 hx_plan *hx_plan_create(int nside, int lmax, int max_comp);
 void hx_plan_destroy(hx_plan *plan);
 int64_t hx_plan_scratch_bytes(const hx_plan *plan);
+/* Measurement aid (bench.py's roofline): matrix-instruction flops one hx_map2alm(niter = 0) of
+ * ncomp components EXECUTES (task list x MFMAs per wave-block), as opposed to the algorithmic
+ * 8 * 2 nside * nlm per component the roofline is quoted on.                              */
+int hx_plan_mfma_flops(hx_plan *plan, int spin, int ncomp, double *flops);
 
 /* maps  : [ncomp][npix] double; spin 2: components come in (Q,U) pairs, ncomp even
  * alms  : [ncomp][nlm] complex; spin 2: (E,B) pairs
