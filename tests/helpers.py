@@ -50,3 +50,27 @@ def band_limited_maps(oracle, rng, nside, lmax, spin, nfield):
         alm[..., s : s + lmax - m + 1] *= np.sqrt(cl[m:])
     maps = oracle.alm2map(alm, nside, lmax, spin=spin)
     return alm, maps
+
+
+def lambda_lm_column(m, lmax, x, sth):
+    """lambda_lm(theta) = Y_lm(theta, 0) for l = m..lmax on an array of co-latitudes, by the textbook
+    normalised three-term recursion in EXTENDED precision (np.longdouble: 64-bit mantissa and a
+    2^+-16384 range, so sin^m(theta) does not underflow for any m, theta of the full-size tests).
+    Independent of the recursions in the oracle and the kernels (two-step / Wigner-d forms)."""
+    ld = np.longdouble
+    x, sth = np.asarray(x, dtype=ld), np.asarray(sth, dtype=ld)
+    k = np.arange(1, m + 1, dtype=ld)
+    lognorm = ld(0.5) * (np.log(ld(2 * m + 1)) - np.log(ld(4) * ld(np.pi)) + np.sum(np.log((2 * k - 1) / (2 * k))))
+    with np.errstate(divide="ignore"):
+        cur = (ld(-1.0) if m & 1 else ld(1.0)) * np.exp(lognorm + ld(m) * np.log(sth))
+    out = np.empty((lmax - m + 1,) + x.shape, dtype=ld)
+    out[0] = cur
+    prev = np.zeros_like(cur)
+    for l in range(m, lmax):
+        l1 = ld(l + 1)
+        a = np.sqrt((4 * l1 * l1 - 1) / (l1 * l1 - ld(m) * m))
+        b = np.sqrt((ld(l) * l - ld(m) * m) / (4 * ld(l) * l - 1)) if l > 0 else ld(0)
+        nxt = a * (x * cur - b * prev)
+        prev, cur = cur, nxt
+        out[l + 1 - m] = cur
+    return out

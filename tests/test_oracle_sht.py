@@ -116,3 +116,18 @@ def test_parseval(oracle):
     cl = oracle.alm2cl(alm)
     lhs = ((2 * np.arange(lmax + 1) + 1) * cl).sum() / (4 * np.pi)
     assert abs(lhs - (mp**2).mean()) < 2e-3 * lhs
+
+
+def test_extended_precision_lambda_helper():
+    """tests/helpers.lambda_lm_column (the closed form of the full-size GPU test) against scipy."""
+    import scipy.special as sp
+    from helpers import lambda_lm_column
+
+    th = np.array([0.01, 0.7, 1.5, 3.0])
+    for m in (0, 1, 5, 30):
+        lam = lambda_lm_column(m, 60, np.cos(th), np.sin(th)).astype(float)
+        ref = np.array([[sp.sph_harm_y(l, m, t, 0.0).real for t in th] for l in range(m, 61)])
+        assert np.abs(lam - ref).max() <= 1e-13 * np.abs(ref).max()
+    # no underflow where a double recursion would start from zero: sin^m(theta) ~ 1e-22200
+    lam = lambda_lm_column(6000, 6144, np.cos([2e-4]), np.sin([2e-4]))
+    assert np.all(np.isfinite(lam.astype(np.longdouble))) and lam[0, 0] != 0
