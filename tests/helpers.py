@@ -55,7 +55,8 @@ def band_limited_maps(oracle, rng, nside, lmax, spin, nfield):
 def lambda_lm_column(m, lmax, x, sth):
     """lambda_lm(theta) = Y_lm(theta, 0) for l = m..lmax on an array of co-latitudes, by the textbook
     normalised three-term recursion in EXTENDED precision (np.longdouble: 64-bit mantissa and a
-    2^+-16384 range, so sin^m(theta) does not underflow for any m, theta of the full-size tests).
+    2^+-16384 range: sin^m(theta) stays a normal number down to 1e-4932, and a term below that is zero
+    at any precision that matters).
     Independent of the recursions in the oracle and the kernels (two-step / Wigner-d forms)."""
     ld = np.longdouble
     x, sth = np.asarray(x, dtype=ld), np.asarray(sth, dtype=ld)
