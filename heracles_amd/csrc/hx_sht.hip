@@ -559,11 +559,10 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
     // residual maps of the Jacobi iterations: plan-owned scratch (no per-call hipMalloc)
     DevBuf &resid = pl->resid_maps;
     if (niter > 0) HX_TRY(resid.alloc(sizeof(double) * (size_t)8 * pl->npix));
-    // without iterations a launch takes 8*NGMAX components; the synthesis of the Jacobi
-    // iterations works on 8 at a time
-    const int bs = niter > 0 ? 8 : analysis_max_comp(spin);
-    for (int c0 = 0; c0 < ncomp; c0 += bs) {
-        const int nb = std::min(bs, ncomp - c0);
+    // without iterations the sweeps are sized by analysis_next_batch(); the synthesis of the
+    // Jacobi iterations works on 8 components at a time
+    for (int c0 = 0, nb = 0; c0 < ncomp; c0 += nb) {
+        nb = niter > 0 ? std::min(8, ncomp - c0) : analysis_next_batch(spin, ncomp - c0);
         const double *dm = vmaps.as<double>() + (size_t)c0 * pl->npix;
         double2 *da = valms.as<double2>() + (size_t)c0 * pl->nlm;
         // the filter fl is applied once, after the last iteration

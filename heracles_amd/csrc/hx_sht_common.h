@@ -158,5 +158,6 @@ int build_tasks(hx_plan *pl, int spin);
 int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 *d_alms, const double *d_rw,
                    const double *d_pw, const double *d_fl, int add);
 int analysis_max_comp(int spin);
+int analysis_next_batch(int spin, int remaining);
 int legendre_synthesis(hx_plan *pl, int spin, int nb, const double2 *d_alms, double *d_Fsyn);
 }  // namespace hx
