@@ -149,6 +149,8 @@ __global__ __launch_bounds__(512) void k_init_bhat(PlanDev P, const int *__restr
 // =====================================================================================
 // MODE 0: input = real maps (N ring -> real part, S ring -> imaginary part)
 // MODE 1: input = complex spectrum Zc[c][ny-layout natural order] (synthesis: conj trick)
+constexpr int RING_JMAX = 4;  // values of j per thread: the launch uses >= n / RING_JMAX threads
+
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_ring_subdft(PlanDev P, const int *__restrict__ rp_list,
                                                       const double *__restrict__ maps,
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(1024) void k_ring_subdft(PlanDev P, const int *__re
 {
     extern __shared__ double2 buf[];
     const int rp = rp_list[blockIdx.y];          // ring pairs of one FFT-size class
-    const int r = blockIdx.x, c = blockIdx.z;    // r fastest: the 4 sub-DFTs of a ring pair share its pixels in L2
+    const int c = blockIdx.z;
     const int n = P.nsub[rp];
     const long long sN = P.startN[rp], sS = P.startS[rp];
     const int M = fft_size_for(n);
@@ -167,67 +169,81 @@ __global__ __launch_bounds__(1024) void k_ring_subdft(PlanDev P, const int *__re
     const double *mp = maps + (long long)c * P.npix;
     const double2 *zp = zin + (long long)c * P.ny + sN;
 
-    for (int j = threadIdx.x; j < M; j += blockDim.x) {
-        double2 val = make_double2(0.0, 0.0);
-        if (j < n) {
-            double2 zq[4];
+    // One work-group owns the ring pair: its 4n pixels (z_q[j] = z[j + q n]) are read from HBM ONCE
+    // into registers -- the launch gives every thread at most RING_JMAX values of j -- and the four
+    // length-n sub-DFTs r = 0..3 (X[4k + r]) run back to back through the same LDS buffer.
+    double2 zq[RING_JMAX][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+    for (int u = 0; u < RING_JMAX; ++u) {
+        const int j = threadIdx.x + u * blockDim.x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            zq[u][q] = make_double2(0.0, 0.0);
+            if (j < n) {
                 if (MODE == 0) {
-                    long long iN = sN + j + (long long)q * n;
+                    const long long iN = sN + j + (long long)q * n;
 #if HX_FFT_ABL & 16
-                    zq[q] = make_double2(1.0 + j, 2.0 + q); continue;
+                    zq[u][q] = make_double2(1.0 + j, 2.0 + q); continue;
 #endif
                     double fn = mp[iN];
                     if (pixw) fn *= pixw[iN];
                     double fs = 0.0;
                     if (sS >= 0) {
-                        long long iS = sS + j + (long long)q * n;
+                        const long long iS = sS + j + (long long)q * n;
                         fs = mp[iS];
                         if (pixw) fs *= pixw[iS];
                     }
-                    zq[q] = make_double2(fn, fs);
+                    zq[u][q] = make_double2(fn, fs);
                 } else {
-                    zq[q] = zp[j + (long long)q * n];
+                    zq[u][q] = zp[j + (long long)q * n];
                 }
             }
-            double2 t = dif4_combine(zq[0], zq[1], zq[2], zq[3], r);
-            unsigned qn = load_phase_num(j, r, n, blu);
-#if HX_FFT_ABL & 1
-            val = cmul(t, make_double2(0.5, (double)qn));
-#else
-            val = qn ? cmul(t, expipi(-(double)qn / (2.0 * n))) : t;
-#endif
         }
-        buf[j] = val;
-    }
-    __syncthreads();
-#if !(HX_FFT_ABL & 2)
-    lds_fft_dif(buf, M, P.tw, P.twN);
-#endif
-    double2 *out = Y + (long long)c * P.ny + sN + (long long)r * n;
-    if (!blu) {
-        for (int k = threadIdx.x; k < n; k += blockDim.x) out[k] = buf[bitrev(k, p)];
-        return;
     }
     const double2 *bh = P.bhat + P.bhat_off[rp];
-#if HX_FFT_ABL & 4
-    for (int j = threadIdx.x; j < M; j += blockDim.x) buf[j] = cmul(buf[j], make_double2(0.5, (double)j));
-#else
-    for (int j = threadIdx.x; j < M; j += blockDim.x) buf[j] = cmul(buf[j], bh[j]);
-#endif
-    __syncthreads();
-#if !(HX_FFT_ABL & 8)
-    lds_fft_dit_inv(buf, M, P.tw, P.twN);
-#endif
     const double inv = 1.0 / M;
-    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+    for (int r = 0; r < 4; ++r) {
+        if (r) __syncthreads();  // the previous sub-DFT has been read out of buf
+#pragma unroll
+        for (int u = 0; u < RING_JMAX; ++u) {
+            const int j = threadIdx.x + u * blockDim.x;
+            if (j < n) {
+                const double2 t = dif4_combine(zq[u][0], zq[u][1], zq[u][2], zq[u][3], r);
+                const unsigned qn = load_phase_num(j, r, n, blu);
 #if HX_FFT_ABL & 1
-        double2 cz = make_double2(0.5, (double)chirp_num(k, n));
+                buf[j] = cmul(t, make_double2(0.5, (double)qn));
 #else
-        double2 cz = expipi(-(double)chirp_num(k, n) / (double)n);
+                buf[j] = qn ? cmul(t, expipi(-(double)qn / (2.0 * n))) : t;
 #endif
-        out[k] = cscale(cmul(buf[k], cz), inv);
+            }
+        }
+        for (int j = n + threadIdx.x; j < M; j += blockDim.x) buf[j] = make_double2(0.0, 0.0);  // Bluestein padding
+        __syncthreads();
+#if !(HX_FFT_ABL & 2)
+        lds_fft_dif(buf, M, P.tw, P.twN);
+#endif
+        double2 *out = Y + (long long)c * P.ny + sN + (long long)r * n;
+        if (!blu) {
+            for (int k = threadIdx.x; k < n; k += blockDim.x) out[k] = buf[bitrev(k, p)];
+            continue;
+        }
+#if HX_FFT_ABL & 4
+        for (int j = threadIdx.x; j < M; j += blockDim.x) buf[j] = cmul(buf[j], make_double2(0.5, (double)j));
+#else
+        for (int j = threadIdx.x; j < M; j += blockDim.x) buf[j] = cmul(buf[j], bh[j]);
+#endif
+        __syncthreads();
+#if !(HX_FFT_ABL & 8)
+        lds_fft_dit_inv(buf, M, P.tw, P.twN);
+#endif
+        for (int k = threadIdx.x; k < n; k += blockDim.x) {
+#if HX_FFT_ABL & 1
+            const double2 cz = make_double2(0.5, (double)chirp_num(k, n));
+#else
+            const double2 cz = expipi(-(double)chirp_num(k, n) / (double)n);
+#endif
+            out[k] = cscale(cmul(buf[k], cz), inv);
+        }
     }
 }
 
@@ -477,8 +493,9 @@ template <int MODE>
 static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, const double2 *zin, double2 *Y)
 {
     for (const auto &c : pl->fft_classes) {
-        const int threads = c.M >= 8192 ? 1024 : (c.M >= 1024 ? 512 : 256);
-        hipLaunchKernelGGL(k_ring_subdft<MODE>, dim3(4, c.count, nb), dim3(threads), (size_t)c.M * sizeof(double2), rt().stream,
+        // one radix-4 butterfly per thread and pass (M/4 threads); n <= M <= RING_JMAX * threads
+        const int threads = std::min(1024, std::max(256, c.M / 4));
+        hipLaunchKernelGGL(k_ring_subdft<MODE>, dim3(1, c.count, nb), dim3(threads), (size_t)c.M * sizeof(double2), rt().stream,
                            pl->dev(), pl->fft_rp_list.as<int>() + c.first, d_maps, d_pw, zin, Y);
     }
     HX_HIP(hipGetLastError());

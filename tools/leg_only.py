@@ -7,7 +7,7 @@ hx.init(0)
 nside, lmax = int(os.environ.get("NSIDE", 2048)), int(os.environ.get("LMAX", 3072))
 spin = int(os.environ.get("SPIN", 0))
 plan = hx.Plan(nside, lmax)
-m = torch.randn((8, 12 * nside * nside), dtype=torch.float64, device="cuda")
+m = torch.randn((int(os.environ.get("NCOMP", 8)), 12 * nside * nside), dtype=torch.float64, device="cuda")
 for _ in range(2):
     plan.map2alm(m, spin)
 hx._lib.profile_enable(True); hx._lib.profile_reset()
