@@ -60,10 +60,26 @@ HX_HD int fft_size_for(int n)
     return m;
 }
 
+/* Twiddle provider of the LDS-resident FFT: W^k = exp(-2 pi i k / twN) = hi[k >> 6] * lo[k & 63] with
+ * hi[a] = W^{64a}, lo[b] = W^b (twN/128 + 64 table entries instead of a twN/2-entry table in global
+ * memory: a butterfly's twiddles then cost two LDS reads and a complex multiply, not an L2 round trip). */
+struct TwFactored {
+    const double2 *hi, *lo;
+    HX_HD double2 operator[](int k) const
+    {
+        const double2 a = hi[k >> 6], b = lo[k & 63];
+        double2 r;
+        r.x = a.x * b.x - a.y * b.y;
+        r.y = a.x * b.y + a.y * b.x;
+        return r;
+    }
+};
+
 /* Gentleman-Sande (DIF) butterfly number i of the stage with half-size h.
- * tw[k] = exp(-2 pi i k / twN), k < twN/2.  Natural-order input -> bit-reversed output
+ * tw[k] = exp(-2 pi i k / twN), k < twN/2 (a pointer to the full table or a TwFactored).  Natural-order input -> bit-reversed output
  * after stages h = M/2, M/4, ..., 1. */
-HX_HD void dif_butterfly(double2 *buf, int i, int h, const double2 *tw, int twN)
+template <class TW>
+HX_HD void dif_butterfly(double2 *buf, int i, int h, TW tw, int twN)
 {
     int t = i & (h - 1);
     int p0 = ((i - t) << 1) + t, p1 = p0 + h;
@@ -75,7 +91,8 @@ HX_HD void dif_butterfly(double2 *buf, int i, int h, const double2 *tw, int twN)
 
 /* Cooley-Tukey (DIT) inverse butterfly, conj twiddles: bit-reversed input -> natural
  * output after stages h = 1, 2, ..., M/2 (unnormalised inverse DFT). */
-HX_HD void dit_inv_butterfly(double2 *buf, int i, int h, const double2 *tw, int twN)
+template <class TW>
+HX_HD void dit_inv_butterfly(double2 *buf, int i, int h, TW tw, int twN)
 {
     int t = i & (h - 1);
     int p0 = ((i - t) << 1) + t, p1 = p0 + h;
@@ -88,7 +105,8 @@ HX_HD void dit_inv_butterfly(double2 *buf, int i, int h, const double2 *tw, int 
 /* Two fused Gentleman-Sande stages (half-sizes 2h and h) = one radix-4 DIF butterfly on
  * (p, p+h, p+2h, p+3h); same in-place layout and final (bit-reversed) order as the two
  * radix-2 stages.  i in [0, M/4), W = exp(-2 pi i / 4h). */
-HX_HD void dif4_butterfly(double2 *buf, int i, int h, const double2 *tw, int twN)
+template <class TW>
+HX_HD void dif4_butterfly(double2 *buf, int i, int h, TW tw, int twN)
 {
     int t = i & (h - 1);
     int p = ((i - t) << 2) + t;
@@ -105,7 +123,8 @@ HX_HD void dif4_butterfly(double2 *buf, int i, int h, const double2 *tw, int twN
 }
 
 /* Two fused inverse Cooley-Tukey stages (half-sizes h then 2h), conj twiddles. */
-HX_HD void dit4_inv_butterfly(double2 *buf, int i, int h, const double2 *tw, int twN)
+template <class TW>
+HX_HD void dit4_inv_butterfly(double2 *buf, int i, int h, TW tw, int twN)
 {
     int t = i & (h - 1);
     int p = ((i - t) << 2) + t;

@@ -96,7 +96,8 @@ __global__ void k_init_norm2(int lmax, double2 *__restrict__ coef, double *__res
 // In-LDS FFT drivers (all threads of the block participate): fused radix-4 stages, plus one
 // radix-2 stage when log2(M) is odd.  Same data layout / bit-reversed order as pure radix-2
 // (tests/csrc/test_fft_core.cpp runs this exact schedule on the host).
-__device__ inline void lds_fft_dif(double2 *buf, int M, const double2 *__restrict__ tw, int twN)
+template <class TW>
+__device__ inline void lds_fft_dif(double2 *buf, int M, TW tw, int twN)
 {
     int h = M >> 1;
     if (ilog2(M) & 1) {
@@ -109,7 +110,8 @@ __device__ inline void lds_fft_dif(double2 *buf, int M, const double2 *__restric
         __syncthreads();
     }
 }
-__device__ inline void lds_fft_dit_inv(double2 *buf, int M, const double2 *__restrict__ tw, int twN)
+template <class TW>
+__device__ inline void lds_fft_dit_inv(double2 *buf, int M, TW tw, int twN)
 {
     int h = 1;
     for (; 4 * h <= M; h <<= 2) {
@@ -120,6 +122,19 @@ __device__ inline void lds_fft_dit_inv(double2 *buf, int M, const double2 *__res
         for (int i = threadIdx.x; i < (M >> 1); i += blockDim.x) dit_inv_butterfly(buf, i, h, tw, twN);
         __syncthreads();
     }
+}
+
+// Fills the factored twiddle tables of TwFactored from the plan's full table (twN/2 entries).
+// LDS: hi[twN/128], lo[64].  The caller synchronises before the first butterfly.
+constexpr int TW_HI_MAX = 128;  // twN <= 16384
+__device__ inline TwFactored load_tw_factored(double2 *hi, double2 *lo, const double2 *__restrict__ tw, int twN)
+{
+    for (int i = threadIdx.x; i < (twN >= 128 ? twN / 128 : 1); i += blockDim.x) hi[i] = tw[i * 64];  // hi[0] = 1
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) lo[i] = tw[i];
+    TwFactored f;
+    f.hi = hi;
+    f.lo = lo;
+    return f;
 }
 
 // Bluestein filter spectra, one block per ring pair whose sub-length is not a power of two
@@ -202,6 +217,8 @@ __global__ __launch_bounds__(1024) void k_ring_subdft(PlanDev P, const int *__re
     }
     const double2 *bh = P.bhat + P.bhat_off[rp];
     const double inv = 1.0 / M;
+    __shared__ double2 tw_hi[TW_HI_MAX], tw_lo[64];
+    const TwFactored twf = load_tw_factored(tw_hi, tw_lo, P.tw, P.twN);  // visible after the first barrier below
     for (int r = 0; r < 4; ++r) {
         if (r) __syncthreads();  // the previous sub-DFT has been read out of buf
 #pragma unroll
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(1024) void k_ring_subdft(PlanDev P, const int *__re
         for (int j = n + threadIdx.x; j < M; j += blockDim.x) buf[j] = make_double2(0.0, 0.0);  // Bluestein padding
         __syncthreads();
 #if !(HX_FFT_ABL & 2)
-        lds_fft_dif(buf, M, P.tw, P.twN);
+        lds_fft_dif(buf, M, twf, P.twN);
 #endif
         double2 *out = Y + (long long)c * P.ny + sN + (long long)r * n;
         if (!blu) {
@@ -234,7 +251,7 @@ __global__ __launch_bounds__(1024) void k_ring_subdft(PlanDev P, const int *__re
 #endif
         __syncthreads();
 #if !(HX_FFT_ABL & 8)
-        lds_fft_dit_inv(buf, M, P.tw, P.twN);
+        lds_fft_dit_inv(buf, M, twf, P.twN);
 #endif
         for (int k = threadIdx.x; k < n; k += blockDim.x) {
 #if HX_FFT_ABL & 1
@@ -443,8 +460,9 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
     (void)hipMemsetAsync(pl->al0.p, 0, sizeof(double) * (pl->nlm + 128), st);
     hipLaunchKernelGGL(k_init_norm0, dim3((2 * (lmax + 1) + 63) / 64), dim3(64), 0, st, lmax, pl->cn0.as<double2>(), pl->al0.as<double>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_bhat), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // 3 KiB of the 160 KiB are the static factored-twiddle tables of k_ring_subdft
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     if (!blu_list.empty()) {
         DevBuf d_list;
         if (upload(d_list, blu_list) != HX_OK) { delete pl; return nullptr; }
@@ -494,7 +512,7 @@ static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, cons
 {
     for (const auto &c : pl->fft_classes) {
         // one radix-4 butterfly per thread and pass (M/4 threads); n <= M <= RING_JMAX * threads
-        const int threads = std::min(1024, std::max(256, c.M / 4));
+        const int threads = std::min(1024, std::max(256, c.M / 4));  // M/8 threads (two butterflies each): 23.0 vs 21.0 ms
         hipLaunchKernelGGL(k_ring_subdft<MODE>, dim3(1, c.count, nb), dim3(threads), (size_t)c.M * sizeof(double2), rt().stream,
                            pl->dev(), pl->fft_rp_list.as<int>() + c.first, d_maps, d_pw, zin, Y);
     }

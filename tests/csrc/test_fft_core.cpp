@@ -23,23 +23,25 @@ static double2 expipi(double x) /* exp(i pi x) */ { return mk(cos(M_PI * x), sin
 
 // same stage schedule as lds_fft_dif / lds_fft_dit_inv in hx_sht.hip: fused radix-4 stages,
 // plus one radix-2 stage when log2(M) is odd
-static void fft_dif(std::vector<double2> &b, int M, const std::vector<double2> &tw, int twN)
+template <class TW>
+static void fft_dif(std::vector<double2> &b, int M, TW tw, int twN)
 {
     int h = M / 2;
     if (ilog2(M) & 1) {
-        for (int i = 0; i < M / 2; ++i) dif_butterfly(b.data(), i, h, tw.data(), twN);
+        for (int i = 0; i < M / 2; ++i) dif_butterfly(b.data(), i, h, tw, twN);
         h >>= 1;
     }
     for (h >>= 1; h >= 1; h >>= 2)
-        for (int i = 0; i < M / 4; ++i) dif4_butterfly(b.data(), i, h, tw.data(), twN);
+        for (int i = 0; i < M / 4; ++i) dif4_butterfly(b.data(), i, h, tw, twN);
 }
-static void fft_dit_inv(std::vector<double2> &b, int M, const std::vector<double2> &tw, int twN)
+template <class TW>
+static void fft_dit_inv(std::vector<double2> &b, int M, TW tw, int twN)
 {
     int h = 1;
     for (; 4 * h <= M; h <<= 2)
-        for (int i = 0; i < M / 4; ++i) dit4_inv_butterfly(b.data(), i, h, tw.data(), twN);
+        for (int i = 0; i < M / 4; ++i) dit4_inv_butterfly(b.data(), i, h, tw, twN);
     if (2 * h <= M)
-        for (int i = 0; i < M / 2; ++i) dit_inv_butterfly(b.data(), i, h, tw.data(), twN);
+        for (int i = 0; i < M / 2; ++i) dit_inv_butterfly(b.data(), i, h, tw, twN);
 }
 
 // emulate one (ring, r) sub-DFT: input z[4n], output Y[k] = X[4k+r], k<n
@@ -48,6 +50,14 @@ static std::vector<double2> subdft(const std::vector<double2> &z, int n, int r,
 {
     bool blu = (n & (n - 1)) != 0;
     int M = fft_size_for(n), p = ilog2(M);
+    // the ring kernel's twiddles: factored tables hi[a] = W^{64a}, lo[b] = W^b (TwFactored); the
+    // filter-spectrum kernel reads the full table
+    std::vector<double2> hi(twN >= 128 ? twN / 128 : 1), lo(64, mk(1, 0));
+    for (size_t a = 0; a < hi.size(); ++a) hi[a] = tw[a * 64];
+    for (int b = 0; b < 64 && b < twN / 2; ++b) lo[b] = tw[b];
+    TwFactored twf;
+    twf.hi = hi.data();
+    twf.lo = lo.data();
     std::vector<double2> buf(M, mk(0, 0));
     for (int j = 0; j < n; ++j) {
         double2 t = dif4_combine(z[j], z[j + n], z[j + 2 * n], z[j + 3 * n], r);
@@ -56,7 +66,7 @@ static std::vector<double2> subdft(const std::vector<double2> &z, int n, int r,
     }
     std::vector<double2> out(n);
     if (!blu) {
-        fft_dif(buf, M, tw, twN);
+        fft_dif(buf, M, twf, twN);
         for (int k = 0; k < n; ++k) out[k] = buf[bitrev(k, p)];
         return out;
     }
@@ -67,10 +77,10 @@ static std::vector<double2> subdft(const std::vector<double2> &z, int n, int r,
         h[j] = c;
         if (j) h[M - j] = c;
     }
-    fft_dif(h, M, tw, twN);
-    fft_dif(buf, M, tw, twN);
+    fft_dif(h, M, tw.data(), twN);
+    fft_dif(buf, M, twf, twN);
     for (int i = 0; i < M; ++i) buf[i] = cmul(buf[i], h[i]);
-    fft_dit_inv(buf, M, tw, twN);
+    fft_dit_inv(buf, M, twf, twN);
     for (int k = 0; k < n; ++k)
         out[k] = cscale(cmul(buf[k], expipi(-(double)chirp_num(k, n) / n)), 1.0 / M);
     return out;
