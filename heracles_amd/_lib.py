@@ -26,9 +26,9 @@ SYMBOLS = (
     "hx_version", "hx_last_error", "hx_device_count", "hx_init", "hx_set_stream",
     "hx_get_stream", "hx_set_async", "hx_synchronize", "hx_timer_start", "hx_timer_stop",
     "hx_profile_enable", "hx_profile_reset", "hx_profile_get", "hx_plan_create",
-    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_plan_mfma_flops", "hx_map2alm", "hx_alm2map",
+    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_plan_mfma_flops", "hx_measure_peaks", "hx_map2alm", "hx_alm2map",
     "hx_alm2cl_pairs", "hx_gauss_legendre", "hx_wigner_d_table", "hx_mixmat",
-    "hx_mixmat_eb", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade",
+    "hx_mixmat_eb", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_alm_resample",
 )
 
 
@@ -76,6 +76,7 @@ def load():
         L.hx_plan_scratch_bytes.argtypes = [vp]
         L.hx_plan_scratch_bytes.restype = C.c_int64
         L.hx_plan_mfma_flops.argtypes = [vp, i, i, C.POINTER(C.c_double)]
+        L.hx_measure_peaks.argtypes = [C.POINTER(C.c_double)]
         L.hx_map2alm.argtypes = [vp, i, i, dp, dp, dp, dp, dp, i]
         L.hx_alm2map.argtypes = [vp, i, i, dp, dp]
         L.hx_alm2cl_pairs.argtypes = [i, vp, vp, i, i, vp, vp, dp]
@@ -88,6 +89,7 @@ def load():
         L.hx_ang2pix_ring.argtypes = [i, C.c_int64, dp, dp, dp]
         L.hx_map_values.argtypes = [i, C.c_int64, dp, dp, i, dp, dp, i]
         L.hx_ud_grade.argtypes = [i, i, i, dp, dp]
+        L.hx_alm_resample.argtypes = [i, i, i, dp, dp]
         L.hx_timer_stop.argtypes = [C.POINTER(C.c_float)]
         L.hx_profile_get.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         _lib = L
@@ -144,6 +146,14 @@ def ensure_init():
 
 def device_count() -> int:
     return load().hx_device_count()
+
+
+def measure_peaks():
+    """{hbm_read_gbs, hbm_copy_gbs, fp64_mfma_tflops, fp64_valu_tflops} sustained by this device."""
+    ensure_init()
+    out = (C.c_double * 4)()
+    check(load().hx_measure_peaks(out))
+    return {"hbm_read_gbs": out[0], "hbm_copy_gbs": out[1], "fp64_mfma_tflops": out[2], "fp64_valu_tflops": out[3]}
 
 
 def synchronize():

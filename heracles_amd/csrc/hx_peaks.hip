@@ -1,0 +1,112 @@
+// hx_peaks.hip -- what this device sustains: HBM read / copy bandwidth, FP64 MFMA and FP64 VALU FMA
+// rates, measured by micro-kernels so that bench.py can print the roofline both against the datasheet
+// peak and against what the box delivers (SURVEY.md 8d asks the harness for exactly that).
+#include "hx_common.h"
+
+namespace hx {
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_peak_valu(double *out, int iters, double seed)
+{
+    double a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = seed + threadIdx.x * 1e-9 + u * 1e-3;
+    const double x = 0.999999 + seed * 1e-12, y = 1e-7;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a[u & 7] = __builtin_fma(a[u & 7], x, y);
+    }
+    double r = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r += a[u];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+__global__ __launch_bounds__(256) void k_peak_mfma(double *out, int iters, double seed)
+{
+    double4_t c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const double ma = seed * 1e-3 + threadIdx.x * 1e-6, mb = 1.0 + threadIdx.x * 1e-7;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ma, mb, c[u], 0, 0, 0);
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = c[0][0] + c[1][1] + c[2][2] + c[3][3];
+}
+
+__global__ __launch_bounds__(256) void k_peak_copy(const double2 *__restrict__ in, double2 *__restrict__ out, size_t n)
+{
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) out[i] = in[i];
+}
+
+__global__ __launch_bounds__(256) void k_peak_read(const double2 *__restrict__ in, double *out, size_t n)
+{
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    double s = 0.0;
+    for (; i < n; i += st) {
+        const double2 v = in[i];
+        s += v.x + v.y;
+    }
+    if (s == 1.2345e-300) out[0] = s;
+}
+
+}  // namespace
+}  // namespace hx
+
+using namespace hx;
+
+// out[0] HBM read GB/s, out[1] HBM copy GB/s (read + write bytes), out[2] FP64 MFMA 16x16x4 TFLOP/s,
+// out[3] FP64 VALU FMA TFLOP/s.  Best of three runs each, ~0.3 s in total.
+extern "C" int hx_measure_peaks(double *out4)
+{
+    HX_TRY(ensure_ready());
+    if (!out4) return fail(HX_ERR_ARG, "hx_measure_peaks: null output");
+    hipStream_t st = rt().stream;
+    hipDeviceProp_t prop;
+    HX_HIP(hipGetDeviceProperties(&prop, rt().device));
+    const int cus = prop.multiProcessorCount;
+    const size_t n = (size_t)1 << 27;  // 2 GiB of double2 per buffer
+    DevBuf a, b, small;
+    HX_TRY(a.alloc(n * sizeof(double2)));
+    HX_TRY(b.alloc(n * sizeof(double2)));
+    HX_TRY(small.alloc((size_t)cus * 4 * 256 * sizeof(double)));
+    HX_HIP(hipMemsetAsync(a.p, 0, n * sizeof(double2), st));
+    hipEvent_t e0, e1;
+    HX_HIP(hipEventCreate(&e0));
+    HX_HIP(hipEventCreate(&e1));
+    auto best_ms = [&](auto launch, float &best) -> int {
+        best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            HX_HIP(hipEventRecord(e0, st));
+            launch();
+            HX_HIP(hipEventRecord(e1, st));
+            HX_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HX_HIP(hipEventElapsedTime(&ms, e0, e1));
+            best = ms < best ? ms : best;
+        }
+        HX_HIP(hipGetLastError());
+        return HX_OK;
+    };
+    float ms;
+    const int blocks = cus * 16;
+    HX_TRY(best_ms([&] { hipLaunchKernelGGL(k_peak_read, dim3(blocks), dim3(256), 0, st, a.as<double2>(), small.as<double>(), n); }, ms));
+    out4[0] = (double)n * 16.0 / (ms * 1e-3) / 1e9;
+    HX_TRY(best_ms([&] { hipLaunchKernelGGL(k_peak_copy, dim3(blocks), dim3(256), 0, st, a.as<double2>(), b.as<double2>(), n); }, ms));
+    out4[1] = (double)n * 32.0 / (ms * 1e-3) / 1e9;
+    const int iters = 20000, fblocks = cus * 4;  // 4 blocks of 4 waves per CU = 4 waves per SIMD
+    HX_TRY(best_ms([&] { hipLaunchKernelGGL(k_peak_mfma, dim3(fblocks), dim3(256), 0, st, small.as<double>(), iters, 1.0); }, ms));
+    out4[2] = (double)fblocks * 4 * iters * 4.0 * 2048.0 / (ms * 1e-3) / 1e12;
+    HX_TRY(best_ms([&] { hipLaunchKernelGGL(k_peak_valu, dim3(fblocks), dim3(256), 0, st, small.as<double>(), iters, 1.0); }, ms));
+    out4[3] = (double)fblocks * 4 * iters * 16.0 * 2.0 * 64.0 / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HX_HIP(hipStreamSynchronize(st));
+    return HX_OK;
+}

@@ -163,3 +163,38 @@ extern "C" int hx_alm2cl_pairs(int ncomp, const int *lmax_i, const double *const
     HX_HIP(hipStreamSynchronize(st));
     return HX_OK;
 }
+
+// ---- alm re-pack between band limits (DiscreteMapper.resample, heracles/ducc.py:145-162) ---------
+namespace hx {
+__global__ __launch_bounds__(256) void k_alm_resample(int lmax_in, int lmax_out, long long nlm_in, long long nlm_out,
+                                                      const double2 *__restrict__ in, double2 *__restrict__ out)
+{
+    // one block per (m of the OUTPUT layout, component): rows l = m..lmax_out, zero beyond the input
+    const int m = blockIdx.x;
+    const double2 *src = in + (long long)blockIdx.y * nlm_in;
+    double2 *dst = out + (long long)blockIdx.y * nlm_out;
+    const long long bo = (long long)m * (2 * lmax_out + 1 - m) / 2, bi = (long long)m * (2 * lmax_in + 1 - m) / 2;
+    for (int l = m + threadIdx.x; l <= lmax_out; l += blockDim.x)
+        dst[bo + l] = (m <= lmax_in && l <= lmax_in) ? src[bi + l] : make_double2(0.0, 0.0);
+}
+}  // namespace hx
+
+extern "C" int hx_alm_resample(int lmax_in, int lmax_out, int ncomp, const double *alm_in, double *alm_out)
+{
+    using namespace hx;
+    HX_TRY(ensure_ready());
+    if (lmax_in < 0 || lmax_out < 0 || ncomp < 0 || (ncomp > 0 && (!alm_in || !alm_out)))
+        return fail(HX_ERR_ARG, "hx_alm_resample: bad arguments");
+    if (ncomp == 0) return HX_OK;
+    const long long ni = (long long)(lmax_in + 1) * (lmax_in + 2) / 2, no = (long long)(lmax_out + 1) * (lmax_out + 2) / 2;
+    InView vin;
+    OutView vout;
+    HX_TRY(vin.bind(alm_in, sizeof(double2) * ni * ncomp));
+    HX_TRY(vout.bind(alm_out, sizeof(double2) * no * ncomp));
+    hipLaunchKernelGGL(k_alm_resample, dim3(lmax_out + 1, ncomp), dim3(256), 0, rt().stream, lmax_in, lmax_out, ni, no,
+                       vin.as<double2>(), vout.as<double2>());
+    HX_HIP(hipGetLastError());
+    HX_TRY(vout.finish());
+    return finish_call();
+}
+

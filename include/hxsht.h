@@ -61,6 +61,9 @@ int hx_profile_get(const char *name, int *launches, double *total_ms);
 hx_plan *hx_plan_create(int nside, int lmax, int max_comp);
 void hx_plan_destroy(hx_plan *plan);
 int64_t hx_plan_scratch_bytes(const hx_plan *plan);
+/* Measurement aid: what this device sustains, from micro-kernels (~0.3 s): out4 = { HBM read GB/s,
+ * HBM copy GB/s (read + write), FP64 MFMA 16x16x4 TFLOP/s, FP64 VALU FMA TFLOP/s }.             */
+int hx_measure_peaks(double *out4);
 /* Measurement aid (bench.py's roofline): matrix-instruction flops one hx_map2alm(niter = 0) of
  * ncomp components EXECUTES (task list x MFMAs per wave-block), as opposed to the algorithmic
  * 8 * 2 nside * nlm per component the roofline is quoted on.                              */
@@ -105,6 +108,11 @@ int hx_mixmat_eb(const double *cl, int ncl, int l1max, int l2max, int l3max, dou
  * nspec spectra at once: cls [nspec][lmax+1][4] <-> corrs [nspec][lmax+1][4].          */
 int hx_cl2corr(int lmax, int nspec, const double *cls, double *corrs);
 int hx_corr2cl(int lmax, int nspec, const double *corrs, double *cls);
+
+/* Replaces the m-block loop of DiscreteMapper.resample (heracles/ducc.py:145-162): re-packs m-major
+ * alms from band limit lmax_in to lmax_out (truncate or zero-pad).  alm_in: [ncomp][nlm(lmax_in)]
+ * complex, alm_out: [ncomp][nlm(lmax_out)] complex.                                             */
+int hx_alm_resample(int lmax_in, int lmax_out, int ncomp, const double *alm_in, double *alm_out);
 
 /* ---- catalogue -> map accumulation (first "next" row of SURVEY.md 8f) ---------------
  * hx_ang2pix_ring replaces hp.ang2pix(nside, lon, lat, lonlat=True) at

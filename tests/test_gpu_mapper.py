@@ -289,3 +289,39 @@ def test_ud_grade_full_size_properties():
     assert float(d.sum()) * 16 == float(m.sum())        # integer-valued pixels: every sum is exact
     u = ud_grade(d, 4096)
     assert torch.equal(ud_grade(u, 1024), d)
+
+
+# ---- DiscreteMapper.resample (hx_alm_resample) -------------------------------------------
+def test_discrete_resample_reference_case():
+    """tests/test_ducc.py:12-45 with the HIP mapper: identity, truncation, zero-padding."""
+    import torch
+    from heracles_amd import HipDiscreteMapper, alm_resample
+
+    lmax = 200
+    alm = np.concatenate([np.arange(m, lmax + 1) for m in range(lmax + 1)], dtype=complex)
+    np.testing.assert_array_equal(HipDiscreteMapper(lmax).resample(alm), alm)
+    lmax_out = lmax // 2
+    out = HipDiscreteMapper(lmax_out).resample(alm)
+    assert out.shape == ((lmax_out + 1) * (lmax_out + 2) // 2,)
+    i = j = 0
+    for m in range(lmax_out + 1):
+        i, j = j, j + lmax_out - m + 1
+        np.testing.assert_array_equal(out[i:j], np.arange(m, lmax_out + 1))
+    lmax_out = lmax * 2
+    out = HipDiscreteMapper(lmax_out).resample(alm)
+    assert out.shape == ((lmax_out + 1) * (lmax_out + 2) // 2,)
+    i = j = 0
+    for m in range(lmax + 1):
+        i, j = j, j + lmax_out - m + 1
+        np.testing.assert_array_equal(out[i:j], np.pad(np.arange(m, lmax + 1), (0, lmax_out - lmax)))
+    np.testing.assert_array_equal(out[j:], 0.0)
+    # leading dimensions, dtype, device tensors
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((2, 3, 21 * 22 // 2)) + 1j * rng.standard_normal((2, 3, 21 * 22 // 2))
+    o = HipDiscreteMapper(9, dtype=np.complex64).resample(a)
+    assert o.shape == (2, 3, 55) and o.dtype == np.complex64
+    d = alm_resample(torch.as_tensor(a).cuda(), 30)
+    back = alm_resample(d, 20)
+    assert d.is_cuda and np.array_equal(back.cpu().numpy(), a)
+    with pytest.raises(ValueError):
+        alm_resample(a[..., :-1], 5)

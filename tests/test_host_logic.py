@@ -267,3 +267,21 @@ def test_oracle_ring_nest_and_ud_grade(oracle):
     assert d2[7] == (m[kids[7, 2]] + m[kids[7, 3]]) / 2          # masked children enter the sum as zeros
     with pytest.raises(ValueError):
         oracle.ud_grade(m, 12)
+
+
+def test_discrete_mapper_surface():
+    """heracles/ducc.py:40-162 surface: protocol members, metadata of create, identity transform,
+    no silent fallback for map_values."""
+    from heracles_amd import HipDiscreteMapper
+
+    mapper = HipDiscreteMapper(12, nthreads=4)
+    for attr in ("area", "create", "map_values", "transform", "resample"):
+        assert hasattr(mapper, attr)
+    assert mapper.lmax == 12 and mapper.area == 1.0
+    m = mapper.create(2, 3, spin=2)
+    assert m.shape == (2, 3, 13 * 14 // 2) and m.dtype == np.complex128 and not m.any()
+    assert m.dtype.metadata == {"geometry": "discrete", "kernel": "none", "lmax": 12, "spin": 2}
+    assert mapper.transform(m, spin=2) is m
+    assert HipDiscreteMapper(4, dtype=np.complex64).create().dtype == np.complex64
+    with pytest.raises(NotImplementedError, match="no CPU fallback"):
+        mapper.map_values(np.zeros(3), np.zeros(3), m, np.zeros(3))
