@@ -284,15 +284,11 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
             // one recursion step of this lane's chain: spin 0 advances l by 2 (entry 2j+h),
             // spin 2 advances l by 1 (entry s)
             auto advance = [&](int e) {
-#ifdef HX_FAKECOEF
-                const double2 c = make_double2(1.0e-3 * e, 0.5);  // timing experiment only
-#else
                 // spin 2: the entry is the same for every lane -> scalar loads (s_load_dwordx16, four
                 // steps each) through the constant cache instead of 64-lane LDS broadcasts, which
                 // cost the LDS pipe as much as the tile stores (measured -10 % kernel time).
                 // spin 0: entry 2j+h differs between the lane halves and stays in LDS.
                 const double2 c = SPIN == 2 ? coefn[cbs + lb + coff + e] : cf[e];
-#endif
                 const double vn = fma(fma(c.x, xx, sgn * c.y), vc, -vp);
                 vp = vc;
                 vc = vn;
