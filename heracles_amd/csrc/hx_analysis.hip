@@ -452,7 +452,7 @@ struct SynParams {
     const double2 *__restrict__ alm;   // [comp][nlm]
     long long alm_stride;
     int ncomp;
-    double *__restrict__ Fsyn;         // [m][rp][north/south][16]
+    double *__restrict__ Fsyn;         // [rp][m][north/south][16]: all m of a ring pair contiguous for the ring FFT stage
 };
 
 // column `col` of the B operand of function `op` at (l, m): alpha_l times
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_synthesis(Sy
         for (int r4 = 0; r4 < 4; ++r4) {
             const int ring = rb * RBLK + 16 * rg + ak + 4 * r4;
             if (ring >= P.nrp_pad) continue;
-            double *base = A.Fsyn + (((long long)m * P.nrp_pad + ring) * 2) * NCOL;
+            double *base = A.Fsyn + (((long long)ring * (lmax + 1) + m) * 2) * NCOL;
             if (SPIN == 0) {
                 const double e = acc[0][0][rg][r4], o = acc[1][0][rg][r4];
                 base[ai] = e + o;

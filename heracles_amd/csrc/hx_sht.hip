@@ -267,44 +267,48 @@ __global__ __launch_bounds__(1024) void k_ring_subdft(PlanDev P, const int *__re
 // =====================================================================================
 // synthesis: Fsyn -> ring spectra -> pixels (the Legendre part lives in hx_analysis.hip)
 // =====================================================================================
-// Fsyn -> conj(Z) spectra of the packed ring pair z = f_N + i f_S.
+// Fsyn[rp][m][N/S][16] -> conj(Z) spectra of the packed ring pair z = f_N + i f_S.
 // X[k] = sum_{m == k mod nphi} (c_m/2) Ft_m + sum_{m == -k} (c_m/2) conj(Ft_m), Ft = F e^{i m phi0}
-// grid: x = ring pair, y = comp; block loops over k.  Output Zc[c][startN + k] = conj(X_N + i X_S)
-__global__ __launch_bounds__(256) void k_synth_spectrum(PlanDev P, const double *__restrict__ Fsyn,
+// grid: x = ring pair; lanes = (k, component): the 8 components of a (ring pair, m) row are 128
+// contiguous bytes, and consecutive k are consecutive rows.  Output Zc[c][startN + k] = conj(X_N + i X_S)
+__global__ __launch_bounds__(256) void k_synth_spectrum(PlanDev P, const double *__restrict__ Fsyn, int ncomp,
                                                         int lmax, double2 *__restrict__ Zc)
 {
-    const int rp = blockIdx.x, c = blockIdx.y;
+    const int rp = blockIdx.x, c = threadIdx.x & 7;
     const int n = P.nsub[rp], nphi = 4 * n;
     const bool shifted = P.shifted[rp] != 0;
-    for (int k = threadIdx.x; k < nphi; k += blockDim.x) {
+    if (c >= ncomp) return;
+    const double *row = Fsyn + ((long long)rp * (lmax + 1)) * 2 * NCOL + 2 * c;
+    for (int k = threadIdx.x >> 3; k < nphi; k += blockDim.x >> 3) {
         double2 xn = make_double2(0.0, 0.0), xs = xn;
         // m == k (mod nphi)
         for (int m = k; m <= lmax; m += nphi) {
-            const double *b = Fsyn + (((long long)m * P.nrp_pad + rp) * 2) * NCOL + 2 * c;
+            const double2 *b = reinterpret_cast<const double2 *>(row + (long long)m * 2 * NCOL);
             double2 ph = make_double2(1.0, 0.0);
             if (shifted) ph = expipi((double)(m % (2 * nphi)) / (double)nphi);
-            double2 fn = cmul(make_double2(b[0], b[1]), ph), fs = cmul(make_double2(b[NCOL], b[NCOL + 1]), ph);
+            const double2 fn = cmul(b[0], ph), fs = cmul(b[NCOL / 2], ph);
             const double sc = m == 0 ? 0.5 : 1.0;  // c_m / 2
             xn = cadd(xn, cscale(fn, sc));
             xs = cadd(xs, cscale(fs, sc));
         }
         // m == -k (mod nphi)
         for (int m = (nphi - k) % nphi; m <= lmax; m += nphi) {
-            const double *b = Fsyn + (((long long)m * P.nrp_pad + rp) * 2) * NCOL + 2 * c;
+            const double2 *b = reinterpret_cast<const double2 *>(row + (long long)m * 2 * NCOL);
             double2 ph = make_double2(1.0, 0.0);
             if (shifted) ph = expipi((double)(m % (2 * nphi)) / (double)nphi);
-            double2 fn = cconj(cmul(make_double2(b[0], b[1]), ph)), fs = cconj(cmul(make_double2(b[NCOL], b[NCOL + 1]), ph));
+            const double2 fn = cconj(cmul(b[0], ph)), fs = cconj(cmul(b[NCOL / 2], ph));
             const double sc = m == 0 ? 0.5 : 1.0;
             xn = cadd(xn, cscale(fn, sc));
             xs = cadd(xs, cscale(fs, sc));
         }
         // Z = X_N + i X_S ; store conj(Z)
-        double2 zz = cadd(xn, mul_pi(xs));
+        const double2 zz = cadd(xn, mul_pi(xs));
         Zc[(long long)c * P.ny + P.startN[rp] + k] = cconj(zz);
     }
 }
 
-// Y_r[k] = DFT(conj Z)[4k+r] = conj(z[4k+r]) -> f_N = Re, f_S = -Im
+// Y_r[k] = DFT(conj Z)[4k+r] = conj(z[4k+r]) -> f_N = Re, f_S = -Im.  One thread per k gathers its four
+// sub-spectra values (coalesced along k) and writes four consecutive pixels of each ring (32 B per lane).
 __global__ __launch_bounds__(256) void k_synth_scatter(PlanDev P, const double2 *__restrict__ Y,
                                                        double *__restrict__ maps, int accumulate_neg,
                                                        const double *__restrict__ ref)
@@ -315,17 +319,30 @@ __global__ __launch_bounds__(256) void k_synth_scatter(PlanDev P, const double2 
     const double2 *y = Y + (long long)c * P.ny + sN;
     double *mp = maps + (long long)c * P.npix;
     const double *rf = ref ? ref + (long long)c * P.npix : nullptr;
-    for (int i = threadIdx.x; i < 4 * n; i += blockDim.x) {
-        const int r = i / n, k = i - r * n;
-        const int j = 4 * k + r;
-        const double2 v = y[i];
-        double fn = v.x, fs = -v.y;
-        if (accumulate_neg) {  // residual: ref - synthesised
-            fn = rf[sN + j] - fn;
-            if (sS >= 0) fs = rf[sS + j] - fs;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        double fn[4], fs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double2 v = y[(long long)r * n + k];
+            fn[r] = v.x;
+            fs[r] = -v.y;
         }
-        mp[sN + j] = fn;
-        if (sS >= 0) mp[sS + j] = fs;
+        const long long jN = sN + 4 * k, jS = sS + 4 * k;  // even offsets: 16-byte aligned pairs
+        if (accumulate_neg) {  // residual: ref - synthesised
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                fn[r] = rf[jN + r] - fn[r];
+                if (sS >= 0) fs[r] = rf[jS + r] - fs[r];
+            }
+        }
+        double2 *dn = reinterpret_cast<double2 *>(mp + jN);
+        dn[0] = make_double2(fn[0], fn[1]);
+        dn[1] = make_double2(fn[2], fn[3]);
+        if (sS >= 0) {
+            double2 *ds = reinterpret_cast<double2 *>(mp + jS);
+            ds[0] = make_double2(fs[0], fs[1]);
+            ds[1] = make_double2(fs[2], fs[3]);
+        }
     }
 }
 
@@ -542,7 +559,7 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
     HX_TRY(legendre_synthesis(pl, spin, nb, d_alms, pl->Fsyn.as<double>()));
     {
         ProfScope ps("ring_fft");
-        hipLaunchKernelGGL(k_synth_spectrum, dim3(pl->nrp, nb), dim3(256), 0, st, P, pl->Fsyn.as<double>(), pl->lmax, pl->resid.as<double2>());
+        hipLaunchKernelGGL(k_synth_spectrum, dim3(pl->nrp), dim3(256), 0, st, P, pl->Fsyn.as<double>(), nb, pl->lmax, pl->resid.as<double2>());
         HX_TRY(launch_subdft_classes<1>(pl, nb, nullptr, nullptr, pl->resid.as<double2>(), pl->Y.as<double2>()));
         hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, nb), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps, d_ref ? 1 : 0, d_ref);
     }
