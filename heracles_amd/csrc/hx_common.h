@@ -96,6 +96,11 @@ struct OutView {
     template <class T> T *as() const { return static_cast<T *>(dev); }
 };
 
+// Host <-> device copies on the library stream; large pageable host buffers are staged through
+// pinned memory by several host threads.  copy_d2h is complete on return, copy_h2d is stream-ordered.
+int copy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int copy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+
 int finish_call();  // synchronise unless async
 
 // Gauss-Legendre nodes/weights into device arrays (hx_mixmat.hip)

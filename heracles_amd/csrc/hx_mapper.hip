@@ -297,7 +297,7 @@ extern "C" int hx_map_values(int nside, int64_t n, const double *lon, const doub
     const bool host_maps = !is_device_ptr(maps);
     if (host_maps) {
         HX_TRY(mtmp.alloc(sizeof(double) * npix * nval));
-        HX_HIP(hipMemcpyAsync(mtmp.p, maps, sizeof(double) * npix * nval, hipMemcpyHostToDevice, st));
+        HX_TRY(copy_h2d(mtmp.p, maps, sizeof(double) * npix * nval));
         dmaps = mtmp.as<double>();
     }
     DevBuf bpix, bord, bpix2, bord2, btmp;
@@ -334,9 +334,7 @@ extern "C" int hx_map_values(int nside, int64_t n, const double *lon, const doub
         HX_HIP(hipGetLastError());
     }
     if (host_maps) {
-        HX_HIP(hipMemcpyAsync(maps, dmaps, sizeof(double) * npix * nval, hipMemcpyDeviceToHost, st));
-        HX_HIP(hipStreamSynchronize(st));
-        return HX_OK;
+        return copy_d2h(maps, dmaps, sizeof(double) * npix * nval);
     }
     // temporaries die with this scope: the stream must have drained them
     HX_HIP(hipStreamSynchronize(st));
