@@ -142,6 +142,19 @@ __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double
 __device__ __host__ inline int tile_swz(int r) { return r & 15; }
 __device__ __host__ inline int ringsel(int q, int k) { return (k & 1) * 16 + 2 * q + (k >> 1); }
 
+// Returns v through an empty asm statement that differs per K: the compiler cannot prove the 16
+// swizzled tile-store addresses of an unrolled block loop-invariant and keeps ONE lane index in a
+// register instead of 16 addresses (an xor + shift-add per store is free here; the registers are
+// what the extra B operands of the spin-0 hybrid sweep need to stay out of scratch: 48 -> 16 spilled
+// VGPRs).  Used for spin 0 only -- the spin-2 kernels have the registers and ran 8 % slower with it.
+// Not volatile: it does not order anything.
+template <int K>
+__device__ inline int opaque(int v)
+{
+    asm("; opaque %1" : "+v"(v) : "n"(K));
+    return v;
+}
+
 // NGQ > 0: NGQ groups of 16 columns on v_mfma_f64_16x16x4_f64.
 // NGQ < 0: -NGQ blocks of 4 columns on v_mfma_f64_4x4x4_4b_f64 (small batches: the four 4x4x4
 //          blocks take the four 4-row groups of the same [16 l x 4 rings] A operand, so the A
@@ -315,14 +328,14 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
 #pragma unroll
                     for (int s = 0; s < NSTEP; ++s) {
                         const int t = SPIN == 0 ? 0 : ((s + off) & 1), r = SPIN == 0 ? s : (s >> 1);
-                        mytile[(t * 16 + r) * 64 + (lane ^ tile_swz(r))] = vc;
+                        mytile[(t * 16 + r) * 64 + ((SPIN == 0 ? opaque<0>(lane) : lane) ^ tile_swz(r))] = vc;
                         advance(SPIN == 0 ? 2 * s + h : s);
                     }
                 } else {
 #pragma unroll
                     for (int s = 0; s < NSTEP; ++s) {
                         const int t = SPIN == 0 ? 0 : ((s + off) & 1), r = SPIN == 0 ? s : (s >> 1);
-                        mytile[(t * 16 + r) * 64 + (lane ^ tile_swz(r))] = sc == 0 ? vc : 0.0;
+                        mytile[(t * 16 + r) * 64 + ((SPIN == 0 ? opaque<1>(lane) : lane) ^ tile_swz(r))] = sc == 0 ? vc : 0.0;
                         advance(SPIN == 0 ? 2 * s + h : s);
                         if ((s & 3) == 3) promote();
                     }
