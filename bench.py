@@ -176,12 +176,29 @@ def main():
         n_, ms_ = hx._lib.profile_get(k)
         prof[k] = {"launches": n_, "ms_per_step": ms_ / max(args.steps, 1)}
 
+    # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process):
+    # launch-weighted mean over the instantiations of the kernel family, or None without the file
+    def pmc_traffic(prefix):
+        if (nside, lmax, nbins) != (4096, 6144, 10):
+            return None  # the committed counters belong to the default workload
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tk = json.load(f)["kernels"]
+        except (OSError, ValueError, KeyError):
+            return None
+        sel = [v for k, v in tk.items() if k.startswith(prefix)]
+        n = sum(v["launches"] for v in sel)
+        return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n if n else None
+
     def roof(name, kernel, flops_per_step, executed_per_step):
         nl_, ms_ = hx._lib.profile_get(name)
         ach = flops_per_step * args.steps / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
         exe = executed_per_step * args.steps / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
         return {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "launches": nl_,
+                "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                "traffic": pmc_traffic(kernel.split("|")[0].rstrip(">") if "|" not in kernel else "hx::k_legendre_analysis<"),
+                "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json, full-size PMC passes)",
+                "launches": nl_,
                 "avg_launch_ms": ms_ / nl_ if nl_ else None,
                 "algorithmic_flops_per_launch": flops_per_step * args.steps / nl_ if nl_ else None,
                 # what the matrix pipe actually ran: north/south symmetry halves the algorithmic
