@@ -89,10 +89,18 @@ def cpu_baseline(nside, lmax, nbins):
     ncs = nbins * (nbins + 1) // 2 * 5 + nbins * nbins * 2
     s0, s2 = f0 + l0 * stride, f2 + l2 * stride  # full-transform estimates
     total = nbins * s0 + nbins * s2 + (t3 - t2) * ncs / 6.0
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
     return {
         "value": npairs / total,
         "unit": "map->Cl pairs/s",
         "cores": ho.num_threads(),
+        "cpu_model": cpu_model,
+        "host_logical_cpus": os.cpu_count(),
         "kind": "port",
         "sample": f"oracle map2alm of 1 spin-0 + 1 spin-2 map at nside={nside} lmax={lmax}, all rings, every "
                   f"{stride}th m (measured fourier+legendre {f0:.2f}+{l0:.2f}s / {f2:.2f}+{l2:.2f}s; full-transform "
