@@ -209,11 +209,18 @@ class HipHealpixMapper:
 
     def transform(self, data, spin=0):
         """Spherical harmonic transform of HEALPix maps; heracles/healpy.py:162-203."""
-        md = data.dtype.metadata or {}
         if spin not in (0, 2):
             raise NotImplementedError(f"spin-{spin} maps not yet supported")
         fl = self._fl(spin)
         plan = sht.get_plan(self.__nside, self.__lmax)
+        if hasattr(data, "data_ptr"):
+            # device-resident maps (e.g. accumulated by map_values on the GPU): alms stay in HBM; a torch
+            # tensor cannot carry dtype metadata, so none is attached
+            if spin == 2 and (data.ndim < 2 or data.shape[-2] != 2):
+                raise ValueError("spin-2 maps must have shape (..., 2, npix)")
+            return plan.map2alm(data, spin, ring_weights=self.ring_weights, pix_weights=self.pixel_weights,
+                                fl=fl, niter=self.niter)
+        md = data.dtype.metadata or {}
         maps = np.ascontiguousarray(_native(data), dtype=np.float64)
         if spin == 2 and (maps.ndim < 2 or maps.shape[-2] != 2):
             raise ValueError("spin-2 maps must have shape (..., 2, npix)")

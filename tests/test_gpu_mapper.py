@@ -325,3 +325,32 @@ def test_discrete_resample_reference_case():
     assert d.is_cuda and np.array_equal(back.cpu().numpy(), a)
     with pytest.raises(ValueError):
         alm_resample(a[..., :-1], 5)
+
+
+def test_device_resident_catalogue_to_alm(oracle):
+    """catalogue page -> map_values on the device -> transform on the device: nothing crosses PCIe
+    until the alms are read; same numbers as the host path and the oracle."""
+    import torch
+    from heracles_amd import HipHealpixMapper
+
+    nside, lmax = 32, 48
+    rng = np.random.default_rng(21)
+    n = 50_000
+    lon = rng.uniform(0, 360, n)
+    lat = np.degrees(np.arcsin(rng.uniform(-1, 1, n)))
+    w = rng.standard_normal((2, n))
+    mapper = HipHealpixMapper(nside, lmax, deconvolve=False, niter=0)
+    dmaps = torch.zeros((2, 12 * nside**2), dtype=torch.float64, device="cuda")
+    for sl in (slice(0, n // 2), slice(n // 2, n)):          # two pages
+        mapper.map_values(lon[sl], lat[sl], dmaps, w[:, sl])
+    hmaps = mapper.create(2, spin=2)
+    mapper.map_values(lon, lat, hmaps, w)
+    np.testing.assert_array_equal(dmaps.cpu().numpy(), hmaps)
+    dalm = mapper.transform(dmaps, spin=2)
+    assert dalm.is_cuda and dalm.shape == (2, (lmax + 1) * (lmax + 2) // 2)
+    halm = mapper.transform(hmaps, spin=2)
+    np.testing.assert_array_equal(dalm.cpu().numpy(), np.asarray(halm))
+    ref = oracle.map2alm(np.asarray(hmaps), nside, lmax, spin=2)
+    assert np.abs(np.asarray(halm) - ref).max() <= 1e-11 * np.abs(ref).max()
+    with pytest.raises(ValueError, match="spin-2 maps"):
+        mapper.transform(dmaps[0], spin=2)
