@@ -13,4 +13,4 @@ for _ in range(2):
 hx._lib.profile_enable(True); hx._lib.profile_reset()
 plan.map2alm(m, spin)
 n, ms = hx._lib.profile_get("legendre_analysis")
-print("spin", spin, "legendre ms/launch", ms / n)
+print("spin", spin, "legendre ms/launch", ms / n, "launches", n, "total ms", ms)
