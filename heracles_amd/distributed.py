@@ -56,6 +56,18 @@ class PairWork:
             self.counts.append(sum(len(comps_of_map(i, nbins)) * len(comps_of_map(j, nbins)) for i, j in self.pairs[l:h]))
         self._gather_buf = None
 
+    def _all_gather(self, out, inp):
+        """all_gather_into_tensor; over gloo (CPU tests, one-GPU rehearsals) device tensors go through
+        host copies, because gloo gathers host memory only.  RCCL ("nccl") takes the device path."""
+        import torch.distributed as dist
+
+        if inp.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = out.new_empty(out.shape, device="cpu")
+            dist.all_gather_into_tensor(host, inp.cpu(), group=self.group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.group)
+
     def gathered_components(self, alm0, alm2):
         """List of all 3*nbins*world component arrays (views into the gather buffer)."""
         import torch
@@ -70,7 +82,7 @@ class PairWork:
         if self._gather_buf is None or self._gather_buf.device != local.device:
             self._gather_buf = torch.empty((self.world * 3 * nb, nlm), dtype=local.dtype, device=local.device)
         # complex dtypes are gathered through their real view (same bytes)
-        dist.all_gather_into_tensor(torch.view_as_real(self._gather_buf), torch.view_as_real(local), group=self.group)
+        self._all_gather(torch.view_as_real(self._gather_buf), torch.view_as_real(local))
         if local.is_cuda:
             # libhxsht launches on its own stream: the gathered shards must have landed first
             torch.cuda.current_stream(local.device).synchronize()
@@ -95,7 +107,7 @@ class PairWork:
         if mine.shape[0]:
             send[: mine.shape[0]] = torch.from_numpy(mine).to(dev)
         recv = torch.empty((self.world * nmax, self.lmax + 1), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(recv, send, group=self.group)
+        self._all_gather(recv, send)
         if recv.is_cuda:
             torch.cuda.current_stream(recv.device).synchronize()
         recv = recv.reshape(self.world, nmax, self.lmax + 1)
