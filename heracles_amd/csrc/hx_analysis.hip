@@ -27,6 +27,17 @@
 namespace hx {
 using namespace hxfft;
 
+// 32-l sub-blocks swept per flush (NSUB) of the variants whose D tiles leave room in the wave's LDS tile
+// and whose registers hold NSUB accumulator sets: measured against NSUB = 1 at nside 4096 --
+// <2,-1> 117 -> 107 ms, <2,-2> 147 -> 141, <2,1> 195 -> 188, <0,-1> 76 -> 70, <0,-2> 95 -> 91, <0,1> 117 -> 112.
+// <2,2> (registers) and the spin-0 hybrid <0,1,x> (its two D groups fill the 8 KiB tile) stay at 1.
+#ifndef HX_QSUB2
+#define HX_QSUB2 4   // spin-2 4x4x4 variants
+#define HX_QSUB0 2   // spin-0 4x4x4 variants
+#define HX_FSUB0 2   // <0,1>
+#define HX_FSUB2 2   // <2,1>
+#endif
+
 template <int SPIN>
 struct LegCfg {
     static constexpr int NW = SPIN == 0 ? 16 : 8;   // waves per workgroup
@@ -160,7 +171,7 @@ __device__ inline int opaque(int v)
 //          blocks take the four 4-row groups of the same [16 l x 4 rings] A operand, so the A
 //          layout -- row = lane&15, k = lane>>4 -- is unchanged; B lane (k, b, j) = F[ring k][col j],
 //          D lane (i, b, j) = row 4b+i, col j; measured 16 cycles / instruction).
-template <int SPIN, int NGQ, int NBX = 0>
+template <int SPIN, int NGQ, int NBX = 0, int NSUB = 1>
 __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(LegParams A,
                                                                            const double2 *__restrict__ coefn,
                                                                            const double *__restrict__ alphan)
@@ -177,8 +188,11 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
     static_assert(!(QUAD && NBX > 0), "extra blocks only next to full groups");
     static_assert(NGT * 512 <= LegCfg<SPIN>::NT * 1024, "D tiles must fit the wave's tile");
     __shared__ double tiles[NW][NT][16][64];  // 128 KiB; after the MFMA phase each wave's tiles carry its D tiles
-    __shared__ double2 coefs[2][LBLK];        // recursion coefficients of this / the next block
-    __shared__ double alphas[2][LBLK];        // output scalings alpha_l of this / the next block
+    // NSUB 32-l sub-blocks are swept between two flushes (their D tiles kept in registers): one work-group
+    // reduction, one pair of barriers per NSUB * 32 l
+    static_assert(NSUB * (NG + (NBX > 0 ? 1 : 0)) * 512 <= LegCfg<SPIN>::NT * 1024, "D tiles of all sub-blocks must fit the wave's tile");
+    __shared__ double2 coefs[2][NSUB * LBLK]; // recursion coefficients of this / the next block
+    __shared__ double alphas[2][NSUB * LBLK]; // output scalings alpha_l of this / the next block
     const PlanDev &P = A.P;
     const LegTask task = A.tasks[blockIdx.x];
     const int m = task.m, lmax = P.lmax;
@@ -261,32 +275,42 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
     };
+    constexpr int LB = NSUB * LBLK;  // l values per flush; threads 0..2LB-1 stage coefficients, 2LB..3LB-1 alphas
     double cpre = 0.0, apre = 0.0;
-    if (threadIdx.x < 2 * LBLK)
+    if (threadIdx.x < 2 * LB)
         (&coefs[0][0].x)[threadIdx.x] = reinterpret_cast<const double *>(coefn + cb + l0 + coff)[threadIdx.x];
-    else if (threadIdx.x < 3 * LBLK)
-        alphas[0][threadIdx.x - 2 * LBLK] = alphan[cb + l0 + (threadIdx.x - 2 * LBLK)];
+    else if (threadIdx.x < 3 * LB)
+        alphas[0][threadIdx.x - 2 * LB] = alphan[cb + l0 + (threadIdx.x - 2 * LB)];
     __syncthreads();
     int cbuf = 0;
-    for (int lb = l0; lb <= lmax; lb += LBLK, cbuf ^= 1) {
-        if (threadIdx.x < 2 * LBLK)
-            cpre = reinterpret_cast<const double *>(coefn + cb + lb + LBLK + coff)[threadIdx.x];
-        else if (threadIdx.x < 3 * LBLK)
-            apre = alphan[cb + lb + LBLK + (threadIdx.x - 2 * LBLK)];
-        const double2 *cf = coefs[cbuf];
-        double4_t acc[NG][2];
-        double accq[NB][2];
+    for (int lb = l0; lb <= lmax; lb += LB, cbuf ^= 1) {
+        if (threadIdx.x < 2 * LB)
+            cpre = reinterpret_cast<const double *>(coefn + cb + lb + LB + coff)[threadIdx.x];
+        else if (threadIdx.x < 3 * LB)
+            apre = alphan[cb + lb + LB + (threadIdx.x - 2 * LB)];
+        double4_t accs[NSUB][NG][2];
+        double accqs[NSUB][NB][2];
+        double accxs[NSUB][NBX > 0 ? NBX : 1][2];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            acc[g][0] = (double4_t){0.0, 0.0, 0.0, 0.0};
-            acc[g][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        for (int sub = 0; sub < NSUB; ++sub) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                accs[sub][g][0] = (double4_t){0.0, 0.0, 0.0, 0.0};
+                accs[sub][g][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            }
+#pragma unroll
+            for (int g = 0; g < NB; ++g) accqs[sub][g][0] = accqs[sub][g][1] = 0.0;
+#pragma unroll
+            for (int g = 0; g < (NBX > 0 ? NBX : 1); ++g) accxs[sub][g][0] = accxs[sub][g][1] = 0.0;
         }
 #pragma unroll
-        for (int g = 0; g < NB; ++g) accq[g][0] = accq[g][1] = 0.0;
-        double accx[NBX > 0 ? NBX : 1][2];
-#pragma unroll
-        for (int g = 0; g < (NBX > 0 ? NBX : 1); ++g) accx[g][0] = accx[g][1] = 0.0;
-        if (wave_on && !(A.ablate & 2)) {
+        for (int sub = 0; sub < NSUB; ++sub) {
+        double4_t (&acc)[NG][2] = accs[sub];
+        double (&accq)[NB][2] = accqs[sub];
+        double (&accx)[NBX > 0 ? NBX : 1][2] = accxs[sub];
+        const int lbs = lb + sub * LBLK;                 // first l of this sub-block (beyond lmax: skipped)
+        const double2 *cf = coefs[cbuf] + sub * LBLK;
+        if (wave_on && (NSUB == 1 || lbs <= lmax) && !(A.ablate & 2)) {
             // A chain is LIVE when its scale exponent is 0: its true value is >= 2^-300 and from
             // there on a plain double.  Below that it contributes nothing at double precision
             // and the tile gets an exact zero; such a chain is only stepped and, every 4 steps,
@@ -301,7 +325,7 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
                 // steps each) through the constant cache instead of 64-lane LDS broadcasts, which
                 // cost the LDS pipe as much as the tile stores (measured -10 % kernel time).
                 // spin 0: entry 2j+h differs between the lane halves and stays in LDS.
-                const double2 c = SPIN == 2 ? coefn[cbs + lb + coff + e] : cf[e];
+                const double2 c = SPIN == 2 ? coefn[cbs + lbs + coff + e] : cf[e];
                 const double vn = fma(fma(c.x, xx, sgn * c.y), vc, -vp);
                 vp = vc;
                 vc = vn;
@@ -371,45 +395,54 @@ __global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(Leg
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        }  // sub-blocks
         // ---- flush: combine the waves' D tiles through LDS (fixed order) --------------------
         // D layout of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4*reg, col = lane&15
-        if (threadIdx.x < 2 * LBLK)
+        if (threadIdx.x < 2 * LB)
             (&coefs[cbuf ^ 1][0].x)[threadIdx.x] = cpre;
-        else if (threadIdx.x < 3 * LBLK)
-            alphas[cbuf ^ 1][threadIdx.x - 2 * LBLK] = apre;
-        if (QUAD) {
-            // D lane (i = lane>>4, b = (lane>>2)&3, j = lane&3): row 4b+i, column 4g+j
+        else if (threadIdx.x < 3 * LB)
+            alphas[cbuf ^ 1][threadIdx.x - 2 * LB] = apre;
+        // sub-block `sub` of this wave sits at doubles [sub * NGT * 512, (sub + 1) * NGT * 512) of its tile
 #pragma unroll
-            for (int g = 0; g < NB; ++g)
+        for (int sub = 0; sub < NSUB; ++sub) {
+            double *dt = mytile + sub * NGT * 512;
+            if (QUAD) {
+                // D lane (i = lane>>4, b = (lane>>2)&3, j = lane&3): row 4b+i, column 4g+j
 #pragma unroll
-                for (int par = 0; par < 2; ++par)
-                    mytile[par * 256 + (4 * ((lane >> 2) & 3) + ak) * 16 + 4 * g + (lane & 3)] = accq[g][par];
-        } else {
+                for (int g = 0; g < NB; ++g)
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+                    for (int par = 0; par < 2; ++par)
+                        dt[par * 256 + (4 * ((lane >> 2) & 3) + ak) * 16 + 4 * g + (lane & 3)] = accqs[sub][g][par];
+            } else {
 #pragma unroll
-                for (int par = 0; par < 2; ++par)
+                for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        mytile[(g * 2 + par) * 256 + (ak + 4 * r) * 16 + ai] = acc[g][par][r];
+                    for (int par = 0; par < 2; ++par)
 #pragma unroll
-            for (int g = 0; g < NBX; ++g)
+                        for (int r = 0; r < 4; ++r)
+                            dt[(g * 2 + par) * 256 + (ak + 4 * r) * 16 + ai] = accs[sub][g][par][r];
 #pragma unroll
-                for (int par = 0; par < 2; ++par)
-                    mytile[(NG * 2 + par) * 256 + (4 * ((lane >> 2) & 3) + ak) * 16 + 4 * g + (lane & 3)] = accx[g][par];
+                for (int g = 0; g < NBX; ++g)
+#pragma unroll
+                    for (int par = 0; par < 2; ++par)
+                        dt[(NG * 2 + par) * 256 + (4 * ((lane >> 2) & 3) + ak) * 16 + 4 * g + (lane & 3)] = accxs[sub][g][par];
+            }
         }
         lds_barrier();
-        for (int t = threadIdx.x; t < NGT * 512; t += NW * 64) {
-            const int g = t >> 9, par = (t >> 8) & 1, r16 = (t >> 4) & 15, col = t & 15;
-            if (g >= A.ng || g * NCOL + col >= A.ncol || (QUAD && col >= 4 * NB)) continue;
-            // fixed association (bit-reproducible), four independent chains for latency
-            double s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int ww = 0; ww < NW; ++ww) s4[ww & 3] += (&tiles[ww][0][0][0])[(g * 2 + par) * 256 + r16 * 16 + col];
-            const double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-            const int l = lb + 2 * r16 + (par ^ off);
-            if (l <= lmax)
-                A.partial[(task.pout - A.row0 + (l - l0)) * A.ncol + g * NCOL + col] = s * alphas[cbuf][l - lb];
+        for (int sub = 0; sub < NSUB; ++sub) {
+            for (int t = threadIdx.x; t < NGT * 512; t += NW * 64) {
+                const int g = t >> 9, par = (t >> 8) & 1, r16 = (t >> 4) & 15, col = t & 15;
+                if (g >= A.ng || g * NCOL + col >= A.ncol || (QUAD && col >= 4 * NB)) continue;
+                // fixed association (bit-reproducible), four independent chains for latency
+                double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) s4[ww & 3] += (&tiles[ww][0][0][0])[sub * NGT * 512 + (g * 2 + par) * 256 + r16 * 16 + col];
+                const double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+                const int l = lb + sub * LBLK + 2 * r16 + (par ^ off);
+                if (l <= lmax)
+                    A.partial[(task.pout - A.row0 + (l - l0)) * A.ncol + g * NCOL + col] = s * alphas[cbuf][l - lb];
+            }
         }
         lds_barrier();  // D tiles consumed: the tile buffers may be overwritten by the next block
     }
@@ -813,16 +846,17 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         const char *eq = getenv("HX_NO_QUAD");
         const bool quad_ok = !(eq && atoi(eq));
         dim3 grid((unsigned)(t1 - t0)), block(NW * 64);
+        constexpr int QSUB = SPIN == 2 ? HX_QSUB2 : HX_QSUB0, FSUB = SPIN == 2 ? HX_FSUB2 : HX_FSUB0;
         if (quad_ok && ncols_used <= 4)
-            hipLaunchKernelGGL((k_legendre_analysis<SPIN, -1>), grid, block, 0, st, A, cn, al);
+            hipLaunchKernelGGL((k_legendre_analysis<SPIN, -1, 0, QSUB>), grid, block, 0, st, A, cn, al);
         else if (quad_ok && ncols_used <= 8)
-            hipLaunchKernelGGL((k_legendre_analysis<SPIN, -2>), grid, block, 0, st, A, cn, al);
+            hipLaunchKernelGGL((k_legendre_analysis<SPIN, -2, 0, QSUB>), grid, block, 0, st, A, cn, al);
         else if (SPIN == 0 && ncol == NCOL + 4)
             hipLaunchKernelGGL((k_legendre_analysis<0, 1, 1>), grid, block, 0, st, A, cn, al);
         else if (SPIN == 0 && ncol == NCOL + 8)
             hipLaunchKernelGGL((k_legendre_analysis<0, 1, 2>), grid, block, 0, st, A, cn, al);
         else if (ng == 1)
-            hipLaunchKernelGGL((k_legendre_analysis<SPIN, 1>), grid, block, 0, st, A, cn, al);
+            hipLaunchKernelGGL((k_legendre_analysis<SPIN, 1, 0, FSUB>), grid, block, 0, st, A, cn, al);
         else
             hipLaunchKernelGGL((k_legendre_analysis<SPIN, 2>), grid, block, 0, st, A, cn, al);
         if (A.ablate & 8) {
