@@ -469,12 +469,12 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
     chk(pl->bhat.alloc(sizeof(double2) * std::max<long long>(btot, 1)));
     if (rc != HX_OK) { delete pl; return nullptr; }
     hipStream_t st = rt().stream;
-    if (pl->cn0.alloc(sizeof(double2) * (pl->nlm + 128)) != HX_OK || pl->al0.alloc(sizeof(double) * (pl->nlm + 128)) != HX_OK) {
+    if (pl->cn0.alloc(sizeof(double2) * (pl->nlm + TABLE_PAD)) != HX_OK || pl->al0.alloc(sizeof(double) * (pl->nlm + TABLE_PAD)) != HX_OK) {
         delete pl;
         return nullptr;
     }
-    (void)hipMemsetAsync(pl->cn0.p, 0, sizeof(double2) * (pl->nlm + 128), st);
-    (void)hipMemsetAsync(pl->al0.p, 0, sizeof(double) * (pl->nlm + 128), st);
+    (void)hipMemsetAsync(pl->cn0.p, 0, sizeof(double2) * (pl->nlm + TABLE_PAD), st);
+    (void)hipMemsetAsync(pl->al0.p, 0, sizeof(double) * (pl->nlm + TABLE_PAD), st);
     hipLaunchKernelGGL(k_init_norm0, dim3((2 * (lmax + 1) + 63) / 64), dim3(64), 0, st, lmax, pl->cn0.as<double2>(), pl->al0.as<double>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_bhat), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // 3 KiB of the 160 KiB are the static factored-twiddle tables of k_ring_subdft
@@ -513,10 +513,10 @@ namespace hx {
 int ensure_rec2(hx_plan *pl)
 {
     if (pl->cn2.p) return HX_OK;
-    HX_TRY(pl->cn2.alloc(sizeof(double2) * (pl->nlm + 128)));
-    HX_TRY(pl->al2.alloc(sizeof(double) * (pl->nlm + 128)));
-    HX_HIP(hipMemsetAsync(pl->cn2.p, 0, sizeof(double2) * (pl->nlm + 128), rt().stream));
-    HX_HIP(hipMemsetAsync(pl->al2.p, 0, sizeof(double) * (pl->nlm + 128), rt().stream));
+    HX_TRY(pl->cn2.alloc(sizeof(double2) * (pl->nlm + TABLE_PAD)));
+    HX_TRY(pl->al2.alloc(sizeof(double) * (pl->nlm + TABLE_PAD)));
+    HX_HIP(hipMemsetAsync(pl->cn2.p, 0, sizeof(double2) * (pl->nlm + TABLE_PAD), rt().stream));
+    HX_HIP(hipMemsetAsync(pl->al2.p, 0, sizeof(double) * (pl->nlm + TABLE_PAD), rt().stream));
     hipLaunchKernelGGL(k_init_norm2, dim3((pl->lmax + 64) / 64), dim3(64), 0, rt().stream, pl->lmax, pl->cn2.as<double2>(), pl->al2.as<double>());
     HX_HIP(hipGetLastError());
     return HX_OK;

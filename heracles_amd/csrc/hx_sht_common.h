@@ -14,6 +14,9 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int LBLK = 32;   // l values per block (16 even-parity + 16 odd-parity rows)
 constexpr int NCOL = 16;   // MFMA N: real columns per group (8 spin-0 maps / 4 spin-2 fields)
+// entries past idx(lmax, lmax) of the recursion tables: the kernels prefetch one flush span (up to 4 x 32 l)
+// ahead and read whole spans, i.e. up to 2 x 128 entries beyond the last valid one
+constexpr int TABLE_PAD = 512;
 constexpr int NGMAX = 2;   // column groups per analysis launch
 constexpr int RBLK = 32;   // ring pairs per wave of the Legendre analysis kernel
 constexpr double SC_BIG = 0x1p+300, SC_SMALL = 0x1p-300;
