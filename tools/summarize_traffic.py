@@ -4,6 +4,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
@@ -16,7 +17,7 @@ def short(name):
 res = collections.defaultdict(dict)
 for kind in ("fetch", "write"):
     # a stale run directory may sit beside the new one: take the newest
-    f = sorted(glob.glob(f"gpurun_out/pmc_{tag}/{kind}/*/*counter_collection.csv"))[-1]
+    f = max(glob.glob(f"gpurun_out/pmc_{tag}/{kind}/*/*counter_collection.csv"), key=os.path.getmtime)
     agg, n = collections.defaultdict(float), collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
