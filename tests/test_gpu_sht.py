@@ -151,3 +151,45 @@ def test_errors():
         plan.map2alm(np.zeros((3, 12 * 16)), 2)
     with pytest.raises(ValueError):
         plan.map2alm(np.zeros((1, 10)), 0)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_map2alm_randomised_shapes(oracle, case):
+    """Seeded random (nside, lmax, spin, batch, weights, filter): odd NSIDE, lmax up to 3 nside - 1 and
+    beyond 2 nside (m aliasing on the polar rings), batches that hit every sweep variant, and l ranges of
+    several flush spans (the 4x4x4 variants sweep 64-128 l per flush)."""
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(9000 + case)
+    nside = int(rng.choice([3, 5, 6, 8, 16, 24, 32, 64]))
+    lmax = int(rng.integers(max(2, nside), 3 * nside))
+    spin = int(rng.choice([0, 2]))
+    ncomp = int(rng.choice([1, 2, 3, 4, 7, 8, 10, 12])) if spin == 0 else int(rng.choice([2, 4, 6, 8, 10, 16]))
+    maps = rng.standard_normal((ncomp, 12 * nside**2))
+    kw = {}
+    if rng.random() < 0.5:
+        kw["ring_weights"] = rng.uniform(0.8, 1.2, 2 * nside)
+    if rng.random() < 0.3:
+        kw["pix_weights"] = rng.uniform(0.9, 1.1, 12 * nside**2)
+    fl = rng.uniform(0.5, 2.0, lmax + 1) if rng.random() < 0.5 else None
+    plan = hx.get_plan(nside, lmax)
+    out = plan.map2alm(maps, spin, fl=fl, **kw)
+    ref = oracle.map2alm(maps, nside, lmax, spin=spin, **kw)
+    if fl is not None:
+        for m in range(lmax + 1):
+            base = m * (2 * lmax + 1 - m) // 2
+            ref[:, base + m : base + lmax + 1] *= fl[m:]
+    close(out, ref)
+
+
+def test_long_l_ranges_small_batches(oracle):
+    """nside 64, lmax 191: six 32-l blocks per m, i.e. several flush spans for every NSUB in use."""
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(77)
+    nside, lmax = 64, 191
+    plan = hx.get_plan(nside, lmax)
+    for spin, ncomps in ((0, (1, 2, 4, 8)), (2, (2, 4, 8))):
+        for ncomp in ncomps:
+            maps = rng.standard_normal((ncomp, 12 * nside**2))
+            close(plan.map2alm(maps, spin), oracle.map2alm(maps, nside, lmax, spin=spin))
