@@ -37,6 +37,9 @@ using namespace hxfft;
 #define HX_FSUB0 2   // <0,1>
 #define HX_FSUB2 2   // <2,1>
 #endif
+#ifndef HX_GSUB2
+#define HX_GSUB2 1   // <2,2>: a second accumulator set spills 42 VGPRs: 354 ms against 329 ms per sweep
+#endif
 
 template <int SPIN>
 struct LegCfg {
@@ -858,7 +861,7 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         else if (ng == 1)
             hipLaunchKernelGGL((k_legendre_analysis<SPIN, 1, 0, FSUB>), grid, block, 0, st, A, cn, al);
         else
-            hipLaunchKernelGGL((k_legendre_analysis<SPIN, 2>), grid, block, 0, st, A, cn, al);
+            hipLaunchKernelGGL((k_legendre_analysis<SPIN, 2, 0, (SPIN == 2 ? HX_GSUB2 : 1)>), grid, block, 0, st, A, cn, al);
         if (A.ablate & 8) {
             unsigned long long hc[4] = {0, 0, 0, 0};
             HX_HIP(hipStreamSynchronize(st));
