@@ -37,6 +37,9 @@ using namespace hxfft;
 #define HX_FSUB0 2   // <0,1>
 #define HX_FSUB2 2   // <2,1>
 #endif
+#ifndef HX_QNW0
+#define HX_QNW0 8   // waves per work-group of the spin-0 one-block 4x4x4 variant <0,-1> (half of LegCfg<0>::NW)
+#endif
 #ifndef HX_GSUB2
 #define HX_GSUB2 1   // <2,2>: a second accumulator set spills 42 VGPRs: 354 ms against 329 ms per sweep
 #endif
@@ -174,13 +177,16 @@ __device__ inline int opaque(int v)
 //          blocks take the four 4-row groups of the same [16 l x 4 rings] A operand, so the A
 //          layout -- row = lane&15, k = lane>>4 -- is unchanged; B lane (k, b, j) = F[ring k][col j],
 //          D lane (i, b, j) = row 4b+i, col j; measured 16 cycles / instruction).
-template <int SPIN, int NGQ, int NBX = 0, int NSUB = 1>
-__global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_analysis(LegParams A,
+template <int SPIN, int NGQ, int NBX = 0, int NSUB = 1, int NWV = LegCfg<SPIN>::NW>
+__global__ __launch_bounds__(NWV * 64, (NWV < LegCfg<SPIN>::NW ? 2 : 1)) void k_legendre_analysis(LegParams A,
                                                                            const double2 *__restrict__ coefn,
                                                                            const double *__restrict__ alphan)
 {
     using C = LegCfg<SPIN>;
-    constexpr int NW = C::NW, NT = C::NT, NOP = C::NOP;
+    // NWV waves per work-group: C::NW, or half of it for the spin-0 variant of one or two maps (<0,-1>):
+    // its 64 KiB of tiles and 100 VGPRs let two work-groups share a CU, and with hardly any matrix work
+    // to wait for, one group's recursion fills the other's flush (70 -> 61 ms)
+    constexpr int NW = NWV, NT = C::NT, NOP = C::NOP;
     constexpr bool QUAD = NGQ < 0;            // 4-column MFMA path
     constexpr int NG = QUAD ? 1 : NGQ;        // 16-column groups held in the partial rows
     constexpr int NB = QUAD ? -NGQ : NGQ;     // B-operand register sets per (par, op, q)
@@ -777,12 +783,17 @@ int analysis_max_comp(int spin) { return spin == 0 ? 12 : 8 * NGMAX; }
 // one-group + 4-column-block sweep <2,1,1> was measured: 501 ms against 474 ms for 8 + 2.)
 int analysis_next_batch(int spin, int remaining) { return std::min(remaining, analysis_max_comp(spin)); }
 
+// ts[0], ts[1]: spin 0 / spin 2 tasks of NW ring blocks;  ts[2]: spin 0 tasks of NW / 2 ring blocks
+// (half-size work-groups of the 4x4x4 variants)
+static int build_task_set(hx_plan *pl, int spin, int nw, hx_plan::TaskSet &ts);
 int build_tasks(hx_plan *pl, int spin)
 {
-    hx_plan::TaskSet &ts = pl->ts[spin ? 1 : 0];
+    return build_task_set(pl, spin, spin == 0 ? LegCfg<0>::NW : LegCfg<2>::NW, pl->ts[spin ? 1 : 0]);
+}
+static int build_task_set(hx_plan *pl, int spin, int nw, hx_plan::TaskSet &ts)
+{
     if (ts.built) return HX_OK;
     const int lmax = pl->lmax;
-    const int nw = spin == 0 ? LegCfg<0>::NW : LegCfg<2>::NW;
     const int nrb = (pl->nrp + RBLK - 1) / RBLK;
     ts.tasks.clear();
     ts.of_m.assign(lmax + 1, MTasks{0, 0});
@@ -850,9 +861,10 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         const bool quad_ok = !(eq && atoi(eq));
         dim3 grid((unsigned)(t1 - t0)), block(NW * 64);
         constexpr int QSUB = SPIN == 2 ? HX_QSUB2 : HX_QSUB0, FSUB = SPIN == 2 ? HX_FSUB2 : HX_FSUB0;
+        constexpr int QNW = SPIN == 0 ? HX_QNW0 : NW;  // waves per work-group of the 4x4x4 variants
         if (quad_ok && ncols_used <= 4)
-            hipLaunchKernelGGL((k_legendre_analysis<SPIN, -1, 0, QSUB>), grid, block, 0, st, A, cn, al);
-        else if (quad_ok && ncols_used <= 8)
+            hipLaunchKernelGGL((k_legendre_analysis<SPIN, -1, 0, QSUB, QNW>), grid, dim3(QNW * 64), 0, st, A, cn, al);
+        else if (quad_ok && ncols_used <= 8)  // 140 VGPRs: two half-size groups do not fit a CU (104 vs 91 ms)
             hipLaunchKernelGGL((k_legendre_analysis<SPIN, -2, 0, QSUB>), grid, block, 0, st, A, cn, al);
         else if (SPIN == 0 && ncol == NCOL + 4)
             hipLaunchKernelGGL((k_legendre_analysis<0, 1, 1>), grid, block, 0, st, A, cn, al);
@@ -887,13 +899,15 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     const int sidx = spin ? 1 : 0, nop = spin ? 2 : 1;
     HX_TRY(build_tasks(pl, spin));
     if (spin) HX_TRY(ensure_rec2(pl));
-    hx_plan::TaskSet &ts = pl->ts[sidx];
     const int ng = (nb + 7) / 8;
     // spin 0 beyond 8 components: one full group + (nb - 8 + 1) / 2 blocks of 4 columns
     // doubles per F / partial row: only the columns in use are stored -- 4-column granularity on the
     // 4x4x4 path (<= 8 columns), 16 per full group, + 4 per extra block of the spin-0 hybrid
     const char *eq = getenv("HX_NO_QUAD");
     const bool quad = !(eq && atoi(eq)) && 2 * nb <= 8;
+    const bool half = quad && spin == 0 && 2 * nb <= 4 && HX_QNW0 < LegCfg<0>::NW;
+    if (half) HX_TRY(build_task_set(pl, 0, HX_QNW0, pl->ts[2]));
+    hx_plan::TaskSet &ts = half ? pl->ts[2] : pl->ts[sidx];
     const int ncol = quad ? 4 * ((2 * nb + 3) / 4) : (spin == 0 && nb > 8) ? NCOL + 4 * ((nb - 8 + 1) / 2) : NCOL * ng;
     HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
     HX_TRY(launch_ring_subdft_maps(pl, nb, d_maps, d_pw, pl->Y.as<double2>()));

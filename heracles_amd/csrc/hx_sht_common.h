@@ -144,7 +144,7 @@ struct hx_plan {
         std::vector<hx::MTasks> of_m;
         std::vector<long long> rows_before_m; // partial rows of all tasks with smaller m (size lmax+2)
         hx::DevBuf d_tasks, d_of_m;
-    } ts[2];
+    } ts[3];  // spin 0, spin 2, spin 0 with half-size work-groups
     struct FftClass { int M, first, count; };
     std::vector<FftClass> fft_classes;   // ring pairs grouped by in-LDS FFT length
     hx::DevBuf fft_rp_list;
