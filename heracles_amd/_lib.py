@@ -26,7 +26,7 @@ SYMBOLS = (
     "hx_version", "hx_last_error", "hx_device_count", "hx_init", "hx_set_stream",
     "hx_get_stream", "hx_set_async", "hx_synchronize", "hx_timer_start", "hx_timer_stop",
     "hx_profile_enable", "hx_profile_reset", "hx_profile_get", "hx_plan_create",
-    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_plan_mfma_flops", "hx_measure_peaks", "hx_map2alm", "hx_alm2map",
+    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_set_scratch_budget", "hx_plan_last_chunks", "hx_plan_mfma_flops", "hx_plan_executed_flops", "hx_measure_peaks", "hx_map2alm", "hx_alm2map",
     "hx_alm2cl_pairs", "hx_gauss_legendre", "hx_wigner_d_table", "hx_mixmat",
     "hx_mixmat_eb", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_alm_resample",
 )
@@ -75,7 +75,10 @@ def load():
         L.hx_plan_destroy.restype = None
         L.hx_plan_scratch_bytes.argtypes = [vp]
         L.hx_plan_scratch_bytes.restype = C.c_int64
+        L.hx_set_scratch_budget.argtypes = [C.c_double]
+        L.hx_plan_last_chunks.argtypes = [vp]
         L.hx_plan_mfma_flops.argtypes = [vp, i, i, C.POINTER(C.c_double)]
+        L.hx_plan_executed_flops.argtypes = [vp, i, i, C.POINTER(C.c_double)]
         L.hx_measure_peaks.argtypes = [C.POINTER(C.c_double)]
         L.hx_map2alm.argtypes = [vp, i, i, dp, dp, dp, dp, dp, i]
         L.hx_alm2map.argtypes = [vp, i, i, dp, dp]
@@ -158,6 +161,11 @@ def measure_peaks():
 
 def synchronize():
     check(load().hx_synchronize())
+
+
+def set_scratch_budget(nbytes: float):
+    """HBM one analysis m-chunk may use for its operands and partial sums (0 = automatic)."""
+    check(load().hx_set_scratch_budget(float(nbytes)))
 
 
 class Timer:

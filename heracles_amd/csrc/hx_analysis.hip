@@ -458,6 +458,406 @@ __global__ __launch_bounds__(NWV * 64, (NWV < LegCfg<SPIN>::NW ? 2 : 1)) void k_
 }
 
 // =====================================================================================
+// Legendre analysis, software-pipelined (batches of >= 3 spin-0 maps / >= 3 spin-2 fields)
+// =====================================================================================
+// Measured on this part (tools/ubench_power.hip, profiles/r02_ubench_power.txt): a v_mfma_f64_16x16x4 stream holds
+// 77 TFLOP/s at 2.38 GHz from ONE wave per SIMD, and FP64 VALU work + LDS stores placed BETWEEN the MFMAs of
+// the same wave cost 7 % -- whereas the same VALU work in ANOTHER wave of that SIMD is starved by the MFMA
+// stream (100 cycles per dependent FMA).  The first kernel above keeps recursion, matrix work and flush in
+// separate, barrier-locked phases (matrix pipe busy 48-63 % of the time).  This one has
+//   * 4 waves per work-group, one per SIMD (up to 512 registers each), one work-group per CU;
+//   * every wave owns NSETS = 2 ring sets (spin 0: 64 ring pairs, both parity chains in one lane; spin 2: 32 ring
+//     pairs x the two Wigner functions) with a private LDS tile pair each;
+//   * the recursion of the NEXT (set, 32-l block) is interleaved, instruction by instruction, with the MFMAs of
+//     the CURRENT one: stage (b, 0) = MFMA(set 0, block b) || recursion(set 1, block b),
+//                      stage (b, 1) = MFMA(set 1, block b) || recursion(set 0, block b + 1);
+//   * B operands of both sets, D tiles, chain states stay in registers; recursion coefficients come through a
+//     triple-buffered LDS table (staged two blocks ahead at the flush barrier -- no scalar-memory loads inside
+//     the loop, whose out-of-order return would force lgkmcnt(0) drains of the LDS queue);
+//   * the flush combines the 4 waves' D tiles through the wave's second tile (free at that point) in a fixed
+//     order, as before.
+// Layouts of F, partial and the task list are those of the first kernel (a task = 16 / 8 blocks of 32 ring pairs).
+template <int SPIN>
+struct PipeCfg {
+    static constexpr int NW = 4;                              // waves per work-group
+    static constexpr int NSETS = 2;                           // ring sets per wave
+    static constexpr int RBS = SPIN == 0 ? 2 : 1;             // 32-ring-pair blocks per set
+    static constexpr int NCH = SPIN == 0 ? 2 : 1;             // recursion chains per lane and set
+    static constexpr int NOP = SPIN == 0 ? 1 : 2;
+    static_assert(NW * NSETS * RBS == LegCfg<SPIN>::NW, "a task covers the same ring blocks as in the first kernel");
+};
+
+#ifndef HX_PIPE_ABL
+#define HX_PIPE_ABL 0  // timing experiments only (tools/build_diag.sh): 1 no MFMA, 2 no recursion, 4 no flush, 8 cycle accounting
+#endif
+
+// Tile of one ring set: element (lane-column c < 64, row r < 16, position p < 2) at double index
+//     c * 32 + ((r ^ (c & 7)) * 2) + p .
+// A lane-column is a recursion lane (spin 0: ring pair; spin 2: (function, ring pair)); row j / position p holds the value
+// of l = lb + 2 j + p.  Every LDS access of the loop is 128 bits wide -- a wave that is alone on its SIMD pays ~30 cycles of
+// issue for a 64-bit DS instruction and ~13 for a 128-bit one (measured: tools/stamp_pipe2.sh) --
+//   store: one lane writes (p = 0, 1) of row j after two recursion steps: 8 lanes of a store group hit 8 different 16-byte
+//          chunks of the 128-byte bank window because of the (c & 7) swizzle;
+//   read:  lane (row i = lane & 15, k = lane >> 4) reads (p = 0, 1) of lane-column rho(q, k) = 4 q + k: the two lane-columns in
+//          a 16-lane read group (k, k + 1) agree in bit 2, so their swizzled rows tile the 256-byte window.
+__device__ __host__ inline int pipe_rho(int q, int k) { return 4 * q + k; }
+__device__ __host__ inline int pipe_tile_idx(int c, int r) { return c * 32 + ((r ^ (c & 7)) * 2); }
+
+template <int SPIN, int NG, int NBX>
+__global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const double2 *__restrict__ coefn,
+                                                          const double *__restrict__ alphan)
+{
+    using C = PipeCfg<SPIN>;
+    constexpr int NW = C::NW, NOP = C::NOP, NCH = C::NCH;
+    constexpr int NPAIR = 16;                  // slot pairs per stage: spin 0 q = 0..15, spin 2 (q = 0..7, op); a pair = positions 0, 1
+    constexpr int NGA = NG > 0 ? NG : 1, NXA = NBX > 0 ? NBX : 1;
+    constexpr int DQ0 = NG * 512;              // first double of the 4-column blocks in a wave's D staging area
+    static_assert(NG >= 1 && NG * 512 + NBX * 128 <= 2048, "D tiles of a wave must fit its second tile");
+    __shared__ double tileA[NW][2048];         // set 0, 64 KiB
+    __shared__ double tileB[NW][2048];         // set 1; doubles as the D staging area of the flush
+    __shared__ double2 coefs[3][2][LBLK];      // recursion coefficients of blocks b, b + 1, b + 2; [1] = sign of q' flipped (spin 2)
+    __shared__ double alphas[2][LBLK];         // output scalings alpha_l of blocks b, b + 1
+    const PlanDev &P = A.P;
+    const LegTask task = A.tasks[blockIdx.x];
+    const int m = task.m, lmax = P.lmax;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ai = lane & 15, ak = lane >> 4;
+    const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
+    const int off = (l0 + m) & 1;              // parity (l + m) & 1 of position 0
+    const long long cb = almidx(lmax, 0, m);
+    const int coff = SPIN == 0 ? 0 : 1;        // spin-2 coefficients are indexed by the target l
+    const int nblk = (lmax - l0) / LBLK + 1;
+
+    // ---- rings of this lane: ring block (within the task) of set s.  The ring blocks of a task are dealt to
+    // the waves round-robin, so that every wave holds polar (late) and equatorial (early) rings alike ----
+    double xx[2];
+    bool valid[2];
+    int rpl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int rbi = SPIN == 0 ? 2 * (s * NW + w) + (lane >> 5) : s * NW + w;  // spin 0: 64 consecutive ring pairs per set
+        rpl[s] = (task.rb0 + rbi) * RBLK + (lane & 31);
+        valid[s] = rbi < task.nrb && rpl[s] < P.nrp;
+        const double x = valid[s] ? P.z[rpl[s]] : 0.0;
+        xx[s] = SPIN == 0 ? x * x : x;
+    }
+
+    // ---- B operands of both sets: lane (k = lane>>4, j = lane&15) holds F[ring k of the pair][parity of the position][op][column] ----
+    double fr[2][NPAIR][2][NGA], frx[2][NPAIR][2][NXA];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int sp = 0; sp < NPAIR; ++sp) {
+            const int op = SPIN == 0 ? 0 : sp & 1, q = SPIN == 0 ? sp : sp >> 1;
+            const int rbi = SPIN == 0 ? 2 * (s * NW + w) + (q >> 3) : s * NW + w;
+            const bool on = rbi < task.nrb;
+            const long long row = (long long)(m - A.m0) * P.nrp_pad + (task.rb0 + rbi) * RBLK + pipe_rho(q & 7, ak);
+#pragma unroll
+            for (int pos = 0; pos < 2; ++pos) {
+                const double *f = A.F + ((row * 2 + (pos ^ off)) * NOP + op) * A.ncol;
+#pragma unroll
+                for (int g = 0; g < NGA; ++g) fr[s][sp][pos][g] = (NG > 0 && on) ? f[g * NCOL + ai] : 0.0;
+#pragma unroll
+                for (int g = 0; g < NXA; ++g) frx[s][sp][pos][g] = (NBX > 0 && on) ? f[NG * NCOL + 4 * g + (lane & 3)] : 0.0;
+            }
+        }
+
+    // ---- seeds ----
+    double vc[2][NCH], vp[2][NCH];
+    int sc[2][NCH];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { vc[s][c] = 0.0; vp[s][c] = 0.0; sc[s][c] = -100; }
+        if (valid[s]) {
+            if (SPIN == 0) {
+                SVal a = spow(P.sth[rpl[s]], m);
+                a.v *= P.mfac[m];
+                SVal b = a;
+                b.v *= sqrt(2.0 * m + 3.0) * P.z[rpl[s]];  // lambda_{m+1,m} = sqrt(2m+3) x lambda_mm
+                snorm_small(a);
+                snorm_small(b);
+                vc[s][0] = a.v; sc[s][0] = a.e;
+                vc[s][NCH - 1] = b.v; sc[s][NCH - 1] = b.e;
+            } else {
+                SVal sp, sm;
+                spin2_seeds(m, P.sth[rpl[s]], P.omz[rpl[s]], P.kfac2[m], sp, sm);
+                vc[s][0] = (lane >> 5) ? sm.v : sp.v;
+                sc[s][0] = (lane >> 5) ? sm.e : sp.e;
+            }
+        }
+    }
+    const int chalf = SPIN == 2 ? (lane >> 5) : 0;  // q' enters with opposite sign for d_{m,+2}: second coefficient table
+
+    auto lds_barrier = []() __attribute__((always_inline)) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): global stores / prefetches in flight do not hold the barrier
+        __builtin_amdgcn_s_barrier();
+    };
+    // coefficient hand-over: thread t < 128 carries double (t & 63) of a block's 32 (p', q') pairs into table t >> 6
+    const double csign = (SPIN == 2 && (threadIdx.x & 1) && (threadIdx.x >> 6) == 1) ? -1.0 : 1.0;
+    if (threadIdx.x < 128) {
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+            (&coefs[bb][threadIdx.x >> 6][0].x)[threadIdx.x & 63] =
+                csign * reinterpret_cast<const double *>(coefn + cb + l0 + bb * LBLK + coff)[threadIdx.x & 63];
+    } else if (threadIdx.x < 160)
+        alphas[0][threadIdx.x - 128] = alphan[cb + l0 + (threadIdx.x - 128)];
+    __syncthreads();
+
+    // ---- one recursion step of chain c of set S; the caller stores the value it returns (the one BEFORE the step) ----
+    // RM 1: chains all dead (nothing stored), 2: mixed (a dead chain stores 0), 3: all live (no exponent bookkeeping)
+    auto rec_step = [&](auto SS, auto RMM, int c, int step, const double2 cc) __attribute__((always_inline)) {
+        constexpr int S = decltype(SS)::value, RM = decltype(RMM)::value;
+        // every 4 steps: promote a scaled chain that has grown past 1 (value *= 2^-300, exponent += 1) -- on the exponent
+        // bits, branch-free (a previous value below 2^-722 becomes 0)
+        if (RM != 3 && (step & 3) == 0) {
+            const int hc = __double2hiint(vc[S][c]), hp = __double2hiint(vp[S][c]);
+            const bool up = sc[S][c] < 0 && (hc & 0x7ff00000) >= 0x3ff00000;
+            const int sub = up ? (300 << 20) : 0;
+            const bool pz = up && (hp & 0x7ff00000) <= (300 << 20);
+            vc[S][c] = __hiloint2double(hc - sub, __double2loint(vc[S][c]));
+            vp[S][c] = pz ? 0.0 : __hiloint2double(hp - sub, __double2loint(vp[S][c]));
+            sc[S][c] += up ? 1 : 0;
+        }
+        const double cur = (RM == 3 || sc[S][c] == 0) ? vc[S][c] : 0.0;
+        const double vn = fma(fma(cc.x, xx[S], cc.y), vc[S][c], -vp[S][c]);
+        vp[S][c] = vc[S][c];
+        vc[S][c] = vn;
+        return cur;
+    };
+    double4_t acc[NGA][2];
+    double accx[NXA][2];
+    // ---- a stage: MFMAs of set SM (if MF) and the recursion of the other set (mode RM).
+    // FP64 vector instructions and FP64 MFMAs share one execution resource: a vector FMA placed between the MFMAs of the
+    // same wave costs ~17 cycles of matrix-pipe time (4 alone), from another wave of the SIMD it is starved (tools/ubench_slot.hip,
+    // tools/ubench_power.hip); 128-bit LDS traffic between MFMAs is free.  So a stage alternates
+    //     [HB recursion steps as one tight vector block: coefficients already in registers, results kept in registers]
+    //     [HB / 2 slot pairs of MFMAs; in their shadow ONLY LDS traffic: the stores of those HB values, the reads of the next
+    //      HB coefficients and of the A operands]                                                 (32 / HB times).
+    // cq = coefficients of the next 16 recursion steps, whatever set / block they belong to. ----
+    constexpr int PF = 2, HB = 8, PPB = HB / 2, NHB = LBLK / HB;  // (16 steps per block need 96 more registers than the wave has)
+    double2 cq[HB];
+    auto stage = [&](auto SMM, auto MFF, auto RMM, const double2 *cf_rec, const double2 *cf_next) __attribute__((always_inline)) {
+        constexpr int SM = decltype(SMM)::value, SR = 1 - SM, RM = (HX_PIPE_ABL & 2) ? 0 : decltype(RMM)::value;
+        constexpr bool MF = decltype(MFF)::value && !(HX_PIPE_ABL & 1);
+        using ISR = std::integral_constant<int, SR>;
+        using IRM = std::integral_constant<int, RM>;
+        const double *tm = SM == 0 ? &tileA[w][0] : &tileB[w][0];
+        double *tr = SR == 0 ? &tileA[w][0] : &tileB[w][0];
+        auto a_fetch = [&](int sp) __attribute__((always_inline)) {
+            const int op = SPIN == 0 ? 0 : sp & 1, q = SPIN == 0 ? sp : sp >> 1;
+            const int c = SPIN == 0 ? (q >> 3) * 32 + pipe_rho(q & 7, ak) : op * 32 + pipe_rho(q, ak);
+            return *reinterpret_cast<const double2 *>(tm + pipe_tile_idx(c, ai));
+        };
+#pragma unroll
+        for (int h = 0; h < NHB; ++h) {
+            double2 aq[PPB];
+            if (MF) {
+#pragma unroll
+                for (int j = 0; j < PF; ++j) aq[j] = a_fetch(h * PPB + j);  // lands while the vector block runs
+            }
+            // ---- vector block: chain-steps HB h .. HB h + HB - 1 (spin 0: HB / 2 steps of both parity chains) ----
+            double cur[HB];
+            if (RM) {
+#pragma unroll
+                for (int k = 0; k < HB; ++k) {
+                    const int kk = HB * h + k;
+                    cur[k] = rec_step(ISR{}, IRM{}, SPIN == 0 ? ((kk & 1) ? NCH - 1 : 0) : 0, SPIN == 0 ? kk >> 1 : kk, cq[k]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- matrix block ----
+#pragma unroll
+            for (int j = 0; j < PPB; ++j) {
+                const int sp = h * PPB + j;
+                if (MF && j + PF < PPB) aq[j + PF] = a_fetch(sp + PF);
+#pragma unroll
+                for (int pos = 0; pos < 2; ++pos) {
+                    const double a = MF ? (pos ? aq[j].y : aq[j].x) : 0.0;
+                    if (MF) acc[0][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[SM][sp][pos][0], acc[0][pos], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pos == 0) {
+                        if (RM >= 2) *reinterpret_cast<double2 *>(tr + pipe_tile_idx(lane, sp)) = make_double2(cur[2 * j], cur[2 * j + 1]);
+                    } else {
+                        // coefficients of the next vector block: second half of this recursion, or the first half of the next stage's
+                        const double2 *src = h + 1 < NHB ? cf_rec + HB * (h + 1) : cf_next;
+                        cq[2 * j] = src[chalf * LBLK + 2 * j];
+                        cq[2 * j + 1] = src[chalf * LBLK + 2 * j + 1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (MF) {
+#pragma unroll
+                        for (int g = 1; g < NG; ++g) acc[g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[SM][sp][pos][g], acc[g][pos], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < NBX; ++g) accx[g][pos] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[SM][sp][pos][g], accx[g][pos], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+    // 0: nothing to do, 1: all chains of the set dead, 2: mixed, 3: all live
+    auto set_mode = [&](auto SS) __attribute__((always_inline)) {
+        constexpr int S = decltype(SS)::value;
+        bool dead = !valid[S] || sc[S][0] < 0, live = !valid[S] || sc[S][0] == 0;
+        if (NCH == 2) {
+            dead = dead && (!valid[S] || sc[S][NCH - 1] < 0);
+            live = live && (!valid[S] || sc[S][NCH - 1] == 0);
+        }
+        return __all(dead) ? 1 : (__all(live) ? 3 : 2);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using BT = std::integral_constant<bool, true>;
+    using BF = std::integral_constant<bool, false>;
+    // dispatch on (MFMA of set SM wanted, recursion mode of the other set)
+    auto run_stage = [&](auto SMM, bool mf, int rm, const double2 *cf_rec, const double2 *cf_next) __attribute__((always_inline)) {
+        if (mf) {
+            if (rm == 3) stage(SMM, BT{}, I3{}, cf_rec, cf_next);
+            else if (rm == 2) stage(SMM, BT{}, I2{}, cf_rec, cf_next);
+            else if (rm == 1) stage(SMM, BT{}, I1{}, cf_rec, cf_next);
+            else stage(SMM, BT{}, I0{}, cf_rec, cf_next);
+        } else {
+            if (rm == 3) stage(SMM, BF{}, I3{}, cf_rec, cf_next);
+            else if (rm == 2) stage(SMM, BF{}, I2{}, cf_rec, cf_next);
+            else if (rm == 1) stage(SMM, BF{}, I1{}, cf_rec, cf_next);
+            else stage(SMM, BF{}, I0{}, cf_rec, cf_next);
+        }
+    };
+
+#if HX_PIPE_ABL & 8
+    // cycle accounting (diagnostic build): [0] prologue, [1] MFMA || live recursion, [2] MFMA || dead / no recursion,
+    // [3] live recursion alone, [4] dead recursion alone, [5] flush up to the first barrier, [6] reduction + second barrier;
+    // [8 + i] = number of intervals of kind i
+    unsigned long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#define HX_STAMP(i) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); cyc[i] += tn_ - tlast; cnt[i] += 1; tlast = tn_; } while (0)
+#else
+#define HX_STAMP(i) do { } while (0)
+#endif
+    auto kind_of = [](bool mf, int rm) __attribute__((always_inline)) { return mf ? (rm >= 2 ? 1 : 2) : (rm >= 2 ? 3 : 4); };
+    (void)kind_of;
+    HX_STAMP(0);
+    // ---- prologue: recursion of (set 0, block 0) ----
+    bool tl_live[2] = {false, false};  // the tile of set s holds the values of its current block
+    {
+#pragma unroll
+        for (int k = 0; k < HB; ++k) cq[k] = coefs[0][chalf][k];
+        const int rm = set_mode(I0{});
+        tl_live[0] = rm >= 2 || (HX_PIPE_ABL & 2);
+        run_stage(I1{}, false, rm, &coefs[0][0][0], &coefs[0][0][0]);  // "MFMA set 1" off: only the recursion of set 0
+    }
+    // flush roles of this thread: D values arrive as 16-byte chunks (col, chunk c): rows (c >> 1) + 8 (c & 1) and + 4
+    const int fcol = threadIdx.x & 15, fch = (threadIdx.x >> 4) & 7, fpos = (threadIdx.x >> 7) & 1;
+    const int frow = (fch >> 1) + 8 * (fch & 1);
+    // Global loads of the hand-over (threads < 128: a coefficient double of block b + 2; threads 128..159: alpha_l of
+    // block b + 1) are issued inside the flush of block b - 1, IN FRONT of its partial-sum stores, and stored to LDS in the
+    // flush of block b: vmcnt retires in order, so a load issued behind the stores could not be waited for without
+    // waiting for those stores to reach HBM, and a use right behind the load would expose its latency.  The reduction
+    // itself reads alpha_l from LDS: no vector-memory wait inside the flush.
+    double hpre = 0.0;
+    auto prefetch = [&](int bn) __attribute__((always_inline)) {  // for the flush of block bn
+        const int lbn = l0 + bn * LBLK;
+        double v = 0.0;
+        if (threadIdx.x < 128) v = reinterpret_cast<const double *>(coefn + cb + lbn + 2 * LBLK + coff)[threadIdx.x & 63];
+        else if (threadIdx.x < 160) v = alphan[cb + lbn + LBLK + (threadIdx.x - 128)];
+        return v;
+    };
+    hpre = prefetch(0);
+    // partial rows this thread writes: (group columns) rows 2 frow + fpos and + 8 of the block; (extra blocks) rows 2 qrow, + 1
+    const int qrow = threadIdx.x / (4 * NXA), qcol = threadIdx.x % (4 * NXA);
+    double *pgrp = A.partial + (task.pout - A.row0 + 2 * frow + fpos) * A.ncol + fcol;
+    double *pquad = A.partial + (task.pout - A.row0 + 2 * qrow) * A.ncol + NG * NCOL + qcol;
+    for (int b = 0; b < nblk; ++b) {
+#pragma unroll
+        for (int g = 0; g < NGA; ++g) acc[g][0] = acc[g][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < NXA; ++g) accx[g][0] = accx[g][1] = 0.0;
+        const double2 *cf_b = &coefs[b % 3][0][0], *cf_n = &coefs[(b + 1) % 3][0][0];
+        // stage (b, 0): MFMA(set 0, block b) || recursion(set 1, block b)
+        {
+            const int rm = set_mode(I1{});
+            run_stage(I0{}, tl_live[0], rm, cf_b, cf_n);
+            HX_STAMP(kind_of(tl_live[0], rm));
+            tl_live[1] = rm >= 2 || (HX_PIPE_ABL & 2);
+        }
+        // stage (b, 1): MFMA(set 1, block b) || recursion(set 0, block b + 1)
+        {
+            const int rm = b + 1 < nblk ? set_mode(I0{}) : 0;
+            run_stage(I1{}, tl_live[1], rm, cf_n, cf_n);
+            HX_STAMP(kind_of(tl_live[1], rm));
+            tl_live[0] = rm >= 2 || (HX_PIPE_ABL & 2);
+        }
+        if (HX_PIPE_ABL & 4) {
+            double chk = 0.0;  // keeps every accumulator alive
+#pragma unroll
+            for (int g = 0; g < NGA; ++g) chk += acc[g][0][0] + acc[g][0][1] + acc[g][0][2] + acc[g][0][3] + acc[g][1][0] + acc[g][1][1] + acc[g][1][2] + acc[g][1][3];
+#pragma unroll
+            for (int g = 0; g < NXA; ++g) chk += accx[g][0] + accx[g][1];
+            if (chk == 1.2345e-300) A.partial[0] = 1.0;
+            continue;
+        }
+        // ---- flush: D tiles of the 4 waves through tileB (consumed by the stage above), fixed order ----
+        // D of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4 reg, col = lane&15.  Staging of (group g, position p): column-major,
+        // 16-byte chunk c = 2 (lane>>4) + (reg>>1) of column col at  (g 2 + p) 256 + col 16 + (c ^ (col & 7)) 2  (128-bit stores,
+        // conflict-free through the swizzle);  D of v_mfma_f64_4x4x4_4b: lane (i = lane>>4, blk = (lane>>2)&3, j = lane&3) =
+        // row 4 blk + i, column j: both positions in one 16-byte store at  DQ0 + ((row 4 NBX + 4 x + j) 2)
+        double *dt = &tileB[w][0];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int pos = 0; pos < 2; ++pos)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    *reinterpret_cast<double2 *>(dt + (g * 2 + pos) * 256 + ai * 16 + (((2 * ak + h) ^ (ai & 7)) * 2)) =
+                        make_double2(acc[g][pos][2 * h], acc[g][pos][2 * h + 1]);
+#pragma unroll
+        for (int g = 0; g < NBX; ++g)
+            *reinterpret_cast<double2 *>(dt + DQ0 + ((4 * ((lane >> 2) & 3) + ak) * 4 * NBX + 4 * g + (lane & 3)) * 2) =
+                make_double2(accx[g][0], accx[g][1]);
+        if (threadIdx.x < 128) (&coefs[(b + 2) % 3][threadIdx.x >> 6][0].x)[threadIdx.x & 63] = csign * hpre;
+        else if (threadIdx.x < 160) alphas[(b + 1) & 1][threadIdx.x - 128] = hpre;
+        lds_barrier();
+        HX_STAMP(5);
+        hpre = prefetch(b + 1);
+        const double *alb = alphas[b & 1];
+        // (rows of a task are padded to whole 32-l blocks: no bounds tests)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            double2 s4[NW];
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww)
+                s4[ww] = *reinterpret_cast<const double2 *>(&tileB[ww][0] + (g * 2 + fpos) * 256 + fcol * 16 + ((fch ^ (fcol & 7)) * 2));
+            const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
+            pgrp[g * NCOL] = sx * alb[2 * frow + fpos];
+            pgrp[g * NCOL + 8 * (long long)A.ncol] = sy * alb[2 * frow + 8 + fpos];
+        }
+        if (NBX > 0 && threadIdx.x < 64 * NBX) {
+            double2 s4[NW];
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(&tileB[ww][0] + DQ0 + threadIdx.x * 2);
+            const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
+            pquad[0] = sx * alb[2 * qrow];
+            pquad[A.ncol] = sy * alb[2 * qrow + 1];
+        }
+        pgrp += (long long)LBLK * A.ncol;
+        pquad += (long long)LBLK * A.ncol;
+        HX_STAMP(7);
+        lds_barrier();  // D tiles consumed: tileB may be overwritten by the recursion of the next stage
+        HX_STAMP(6);
+    }
+#if HX_PIPE_ABL & 8
+    if (lane == 0 && A.counters)
+        for (int i = 0; i < 8; ++i) {
+            atomicAdd(&A.counters[i], cyc[i]);
+            atomicAdd(&A.counters[8 + i], cnt[i]);
+        }
+#endif
+}
+
+// =====================================================================================
 // partial sums -> alm (fixed order over the ring groups of each m)
 // =====================================================================================
 template <int SPIN>
@@ -773,15 +1173,45 @@ static int ring_mlim(int lmax, int spin, double sth, double cth)
     return (int)(res + 0.5);
 }
 
-// spin 0: one column group per launch (a second group does not fit 128 VGPRs at 4 waves/SIMD);
-// spin 2: two groups (8 fields) share one recursion pass.
-// spin 0: 8 components in a full group + 4 in two 4-column blocks.  spin 2: two full groups; a
-// third (<2,3>) needs 144 more VGPRs than the wave has and was measured 1.6x slower from spills.
-int analysis_max_comp(int spin) { return spin == 0 ? 12 : 8 * NGMAX; }
+// Column layout of one sweep over nb components (2 real columns per spin-0 map, 4 per spin-2 field):
+//   cols <= 8 : 4-column blocks on v_mfma_f64_4x4x4_4b, first kernel (quad = blocks);
+//   else      : ng full 16-column groups + nbx extra 4-column blocks on the pipelined kernel.
+// The pipelined kernel is matrix-bound, so a sweep costs what its (4-column padded) columns cost whatever the
+// split; 32 columns is what the B operands of two ring sets leave of the register file.
+struct SweepShape {
+    int ng, nbx, quad, ncol;
+};
+static SweepShape sweep_shape(int nb)
+{
+    const int cols = 2 * nb;
+    SweepShape sh = {0, 0, 0, 0};
+    if (cols <= 8) {
+        sh.quad = (cols + 3) / 4;
+        sh.ncol = 4 * sh.quad;
+        return sh;
+    }
+    sh.ng = cols / NCOL;
+    const int rem = cols % NCOL;
+    if (sh.ng == 0 || rem > 4 || (sh.ng == 2 && rem > 0)) {  // two extra blocks next to a full group spill (172 VGPRs)
+        sh.ng += 1;  // a partly filled group
+    } else {
+        sh.nbx = (rem + 3) / 4;
+    }
+    sh.ncol = NCOL * sh.ng + 4 * sh.nbx;
+    return sh;
+}
+int analysis_max_comp(int /*spin*/) { return 8 * NGMAX; }
 
-// Components of the next sweep when `remaining` are left.  (A 5 + 5 split of ten spin-2 fields on a
-// one-group + 4-column-block sweep <2,1,1> was measured: 501 ms against 474 ms for 8 + 2.)
-int analysis_next_batch(int spin, int remaining) { return std::min(remaining, analysis_max_comp(spin)); }
+// Components of the next sweep when `remaining` are left: as few sweeps as the 32-column limit allows, of equal
+// size (ten spin-2 fields = 5 + 5, each one group + one 4-column block: no padded columns, and both sweeps have
+// enough matrix work per recursion step to hide the recursion).
+int analysis_next_batch(int spin, int remaining)
+{
+    const int unit = spin == 0 ? 1 : 2, maxu = analysis_max_comp(spin) / unit;
+    const int units = remaining / unit;
+    const int nsweep = (units + maxu - 1) / maxu;
+    return unit * ((units + nsweep - 1) / nsweep);
+}
 
 // ts[0], ts[1]: spin 0 / spin 2 tasks of NW ring blocks;  ts[2]: spin 0 tasks of NW / 2 ring blocks
 // (half-size work-groups of the 4x4x4 variants)
@@ -812,7 +1242,7 @@ static int build_task_set(hx_plan *pl, int spin, int nw, hx_plan::TaskSet &ts)
             for (int rb = first / RBLK; rb < nrb; rb += nw) {
                 LegTask t;
                 t.m = m; t.rb0 = rb; t.nrb = std::min(nw, nrb - rb); t.pad = 0; t.pout = rows;
-                rows += (lmax - l0 + 1);
+                rows += (long long)LBLK * ((lmax - l0) / LBLK + 1);  // padded to whole 32-l blocks (the pipelined kernel stores unconditionally)
                 ts.tasks.push_back(t);
             }
         }
@@ -826,9 +1256,11 @@ static int build_task_set(hx_plan *pl, int spin, int nw, hx_plan::TaskSet &ts)
 }
 
 template <int SPIN>
-static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int nb, int ng, int ncol, const double *d_rw,
+static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int nb, const SweepShape &sh, const double *d_rw,
                         const double *d_fl, int add, double2 *d_alms)
 {
+    // column groups of the F / partial rows: full groups (+ 1 holding the extra blocks); the 4x4x4 path has one
+    const int ng = sh.quad ? 1 : sh.ng + (sh.nbx > 0 ? 1 : 0), ncol = sh.ncol;
     hipStream_t st = rt().stream;
     PlanDev P = pl->dev();
     const int t0 = ts.of_m[m0].first;
@@ -844,42 +1276,61 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         LegParams A;
         A.P = P; A.tasks = ts.d_tasks.as<LegTask>() + t0; A.F = pl->F.as<double>(); A.partial = pl->partial.as<double>();
         A.m0 = m0; A.row0 = ts.rows_before_m[m0]; A.ng = ng; A.ncol = ncol;
+        A.ablate = 0;
+        A.counters = nullptr;
+#if defined(HX_DIAG) && (HX_PIPE_ABL & 8)
+        HX_TRY(pl->d_dbg.alloc(128));
+        HX_HIP(hipMemsetAsync(pl->d_dbg.p, 0, 128, st));
+        A.counters = pl->d_dbg.as<unsigned long long>();
+#endif
+#ifdef HX_DIAG  // diagnostic builds only (tools/): phases of the first kernel can be switched off, results are then wrong
         const char *e = getenv("HX_ABLATE");
         A.ablate = e ? atoi(e) : 0;
-        A.counters = nullptr;
         if (A.ablate & 8) {
             HX_TRY(pl->d_dbg.alloc(64));
             HX_HIP(hipMemsetAsync(pl->d_dbg.p, 0, 64, st));
             A.counters = pl->d_dbg.as<unsigned long long>();
         }
+#endif
         const double2 *cn = SPIN == 0 ? pl->cn0.as<double2>() : pl->cn2.as<double2>();
         const double *al = SPIN == 0 ? pl->al0.as<double>() : pl->al2.as<double>();
         constexpr int NW = LegCfg<SPIN>::NW;
-        // real columns in use: 2 per spin-0 component, 4 per spin-2 field
-        const int ncols_used = SPIN == 0 ? 2 * nb : 2 * nb;
-        const char *eq = getenv("HX_NO_QUAD");
-        const bool quad_ok = !(eq && atoi(eq));
-        dim3 grid((unsigned)(t1 - t0)), block(NW * 64);
-        constexpr int QSUB = SPIN == 2 ? HX_QSUB2 : HX_QSUB0, FSUB = SPIN == 2 ? HX_FSUB2 : HX_FSUB0;
+        dim3 grid((unsigned)(t1 - t0)), block(NW * 64), pblock(PipeCfg<SPIN>::NW * 64);
+        constexpr int QSUB = SPIN == 2 ? HX_QSUB2 : HX_QSUB0;
         constexpr int QNW = SPIN == 0 ? HX_QNW0 : NW;  // waves per work-group of the 4x4x4 variants
-        if (quad_ok && ncols_used <= 4)
+        if (sh.quad == 1)
             hipLaunchKernelGGL((k_legendre_analysis<SPIN, -1, 0, QSUB, QNW>), grid, dim3(QNW * 64), 0, st, A, cn, al);
-        else if (quad_ok && ncols_used <= 8)  // 140 VGPRs: two half-size groups do not fit a CU (104 vs 91 ms)
+        else if (sh.quad == 2)  // 140 VGPRs: two half-size groups do not fit a CU (104 vs 91 ms)
             hipLaunchKernelGGL((k_legendre_analysis<SPIN, -2, 0, QSUB>), grid, block, 0, st, A, cn, al);
-        else if (SPIN == 0 && ncol == NCOL + 4)
-            hipLaunchKernelGGL((k_legendre_analysis<0, 1, 1>), grid, block, 0, st, A, cn, al);
-        else if (SPIN == 0 && ncol == NCOL + 8)
-            hipLaunchKernelGGL((k_legendre_analysis<0, 1, 2>), grid, block, 0, st, A, cn, al);
-        else if (ng == 1)
-            hipLaunchKernelGGL((k_legendre_analysis<SPIN, 1, 0, FSUB>), grid, block, 0, st, A, cn, al);
+        else if (sh.ng == 1 && sh.nbx == 0)
+            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 0>), grid, pblock, 0, st, A, cn, al);
+        else if (sh.ng == 1 && sh.nbx == 1)
+            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 1>), grid, pblock, 0, st, A, cn, al);
+        else if (sh.ng == 2 && sh.nbx == 0)
+            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 2, 0>), grid, pblock, 0, st, A, cn, al);
         else
-            hipLaunchKernelGGL((k_legendre_analysis<SPIN, 2, 0, (SPIN == 2 ? HX_GSUB2 : 1)>), grid, block, 0, st, A, cn, al);
+            return fail(HX_ERR_ARG, "legendre analysis: no kernel for %d groups + %d blocks", sh.ng, sh.nbx);
+#if defined(HX_DIAG) && (HX_PIPE_ABL & 8)
+        if (!sh.quad) {
+            unsigned long long hc[16];
+            HX_HIP(hipStreamSynchronize(st));
+            HX_HIP(hipMemcpy(hc, pl->d_dbg.p, 128, hipMemcpyDeviceToHost));
+            const char *nm[8] = {"prologue", "mfma||rec", "mfma||dead", "rec alone", "dead alone", "flush->bar1", "bar2 wait", "reduce"};
+            double tot = 0;
+            for (int i = 0; i < 8; ++i) tot += (double)hc[i];
+            for (int i = 0; i < 8; ++i)
+                fprintf(stderr, "[hx] pipe spin %d m [%d,%d): %-13s %5.1f %%  %12llu intervals, %8.1f cycles each\n", SPIN, m0, m1, nm[i],
+                        100.0 * hc[i] / tot, hc[8 + i], hc[8 + i] ? (double)hc[i] / hc[8 + i] : 0.0);
+        }
+#endif
+#ifdef HX_DIAG
         if (A.ablate & 8) {
             unsigned long long hc[4] = {0, 0, 0, 0};
             HX_HIP(hipStreamSynchronize(st));
             HX_HIP(hipMemcpy(hc, pl->d_dbg.p, 32, hipMemcpyDeviceToHost));
             fprintf(stderr, "[hx] spin %d m [%d,%d) legendre wave-blocks: dead %llu live %llu mixed %llu\n", SPIN, m0, m1, hc[0], hc[1], hc[2]);
         }
+#endif
     }
     {
         ProfScope ps("alm_reduce");
@@ -899,36 +1350,32 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     const int sidx = spin ? 1 : 0, nop = spin ? 2 : 1;
     HX_TRY(build_tasks(pl, spin));
     if (spin) HX_TRY(ensure_rec2(pl));
-    const int ng = (nb + 7) / 8;
-    // spin 0 beyond 8 components: one full group + (nb - 8 + 1) / 2 blocks of 4 columns
     // doubles per F / partial row: only the columns in use are stored -- 4-column granularity on the
-    // 4x4x4 path (<= 8 columns), 16 per full group, + 4 per extra block of the spin-0 hybrid
-    const char *eq = getenv("HX_NO_QUAD");
-    const bool quad = !(eq && atoi(eq)) && 2 * nb <= 8;
-    const bool half = quad && spin == 0 && 2 * nb <= 4 && HX_QNW0 < LegCfg<0>::NW;
+    // 4x4x4 path (<= 8 columns), 16 per full group + 4 per extra block on the pipelined kernel
+    const SweepShape sh = sweep_shape(nb);
+    const bool half = sh.quad == 1 && spin == 0 && HX_QNW0 < LegCfg<0>::NW;
     if (half) HX_TRY(build_task_set(pl, 0, HX_QNW0, pl->ts[2]));
     hx_plan::TaskSet &ts = half ? pl->ts[2] : pl->ts[sidx];
-    const int ncol = quad ? 4 * ((2 * nb + 3) / 4) : (spin == 0 && nb > 8) ? NCOL + 4 * ((nb - 8 + 1) / 2) : NCOL * ng;
+    const int ncol = sh.ncol;
     HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
     HX_TRY(launch_ring_subdft_maps(pl, nb, d_maps, d_pw, pl->Y.as<double2>()));
 
-    // budget: HX_SCRATCH_GB, else 64 GB but never more than half of what is free on the device
-    // (what this plan already holds for F / partial counts as free)
-    const char *eb = getenv("HX_SCRATCH_GB");
+    // budget: hx_set_scratch_budget() / HX_SCRATCH_GB, else 64 GB but never more than half of what is free on
+    // the device (what this plan already holds for F / partial counts as free)
     double budget = 64e9;
-    if (eb) budget = atof(eb) * 1e9;
+    if (scratch_budget_bytes() > 0.0) budget = scratch_budget_bytes();
     else {
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess)
             budget = std::min(budget, 0.5 * (double)(fr + pl->F.bytes + pl->partial.bytes));
+        budget = std::max(budget, 2e9);
     }
-    budget = std::max(budget, 2e9);
     const double f_per_m = (double)pl->nrp_pad * 2 * nop * ncol * sizeof(double);
     const int lmax = pl->lmax;
     std::vector<std::pair<int, int>> chunks;
     size_t maxF = 16, maxP = 16;
     for (int m0 = 0; m0 <= lmax;) {
-        int m1 = m0 + 1;
+        int m1 = m0 + 1;  // a chunk holds at least one m, whatever the budget
         while (m1 <= lmax) {
             const double bytes = f_per_m * (m1 + 1 - m0) +
                                  (double)(ts.rows_before_m[m1 + 1] - ts.rows_before_m[m0]) * ncol * sizeof(double);
@@ -942,11 +1389,12 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     }
     HX_TRY(pl->F.alloc(maxF));
     HX_TRY(pl->partial.alloc(maxP));
+    pl->last_chunks = (int)chunks.size();
     for (auto &ch : chunks) {
         if (spin == 0)
-            HX_TRY(launch_chunk<0>(pl, ts, ch.first, ch.second, nb, ng, ncol, d_rw, d_fl, add, d_alms));
+            HX_TRY(launch_chunk<0>(pl, ts, ch.first, ch.second, nb, sh, d_rw, d_fl, add, d_alms));
         else
-            HX_TRY(launch_chunk<2>(pl, ts, ch.first, ch.second, nb, ng, ncol, d_rw, d_fl, add, d_alms));
+            HX_TRY(launch_chunk<2>(pl, ts, ch.first, ch.second, nb, sh, d_rw, d_fl, add, d_alms));
     }
     return HX_OK;
 }
@@ -970,19 +1418,33 @@ extern "C" int hx_plan_mfma_flops(hx_plan *pl, int spin, int ncomp, double *flop
         const int l0 = std::max(t.m, l0min);
         wave_blocks += (double)t.nrb * ((pl->lmax - l0) / LBLK + 1);
     }
-    const char *eq = getenv("HX_NO_QUAD");
-    const bool quad_ok = !(eq && atoi(eq));
     double per_wave_block = 0.0;
     for (int c0 = 0, nb = 0; c0 < ncomp; c0 += nb) {
         nb = analysis_next_batch(spin, ncomp - c0);
-        const int cols = 2 * nb;
-        double full = 0, quad = 0;
-        if (quad_ok && cols <= 8) quad = (cols + 3) / 4;
-        else if (spin == 0 && nb > 8) { full = 1; quad = (nb - 8 + 1) / 2; }
-        else full = (nb + 7) / 8;
-        per_wave_block += 16.0 * nop * (full * 2048.0 + quad * 512.0);
+        const SweepShape sh = sweep_shape(nb);
+        per_wave_block += 16.0 * nop * (sh.ng * 2048.0 + (sh.nbx + sh.quad) * 512.0);
     }
     *flops = wave_blocks * per_wave_block;
     return HX_OK;
 }
 
+// The same with the vector-unit share beside it: out2[0] = matrix-instruction flops (as above), out2[1] = FP64 flops of the
+// recursions (4 per value lambda_lm(theta): every sweep runs the chains of all ring pairs of the task list once; spin 2 runs
+// two functions per ring pair).  executed = out2[0] + out2[1] is what bench.py's roofline fraction is quoted on.
+extern "C" int hx_plan_executed_flops(hx_plan *pl, int spin, int ncomp, double *out2)
+{
+    using namespace hx;
+    if (!out2) return fail(HX_ERR_ARG, "hx_plan_executed_flops: null output");
+    HX_TRY(hx_plan_mfma_flops(pl, spin, ncomp, &out2[0]));
+    const hx_plan::TaskSet &ts = pl->ts[spin ? 1 : 0];
+    const int nop = spin ? 2 : 1, l0min = spin ? 2 : 0;
+    double wave_blocks = 0.0;
+    for (const LegTask &t : ts.tasks) {
+        const int l0 = std::max(t.m, l0min);
+        wave_blocks += (double)t.nrb * ((pl->lmax - l0) / LBLK + 1);
+    }
+    int sweeps = 0;
+    for (int c0 = 0, nb = 0; c0 < ncomp; c0 += nb, ++sweeps) nb = analysis_next_batch(spin, ncomp - c0);
+    out2[1] = wave_blocks * sweeps * (double)RBLK * LBLK * nop * 4.0;
+    return HX_OK;
+}

@@ -103,6 +103,9 @@ int copy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 
 int finish_call();  // synchronise unless async
 
+// Scratch budget of one analysis m-chunk in bytes (hx_set_scratch_budget, else HX_SCRATCH_GB); 0 = automatic
+double scratch_budget_bytes();
+
 // Gauss-Legendre nodes/weights into device arrays (hx_mixmat.hip)
 int launch_gauss_legendre(int n, double *d_x, double *d_w);
 

@@ -66,13 +66,29 @@ __device__ inline long long ang2pix_ring_one(long long nside, double lon_deg, do
     return (z > 0.0) ? 2 * ir * (ir - 1) + ip : npix - 2 * ir * (ir + 1) + ip;
 }
 
+// healpy.ang2pix validates its input (check_theta_valid: 0 <= theta <= pi + 1e-5, which a NaN fails) and
+// raises ValueError before any pixel is touched; the formulas above yield negative or out-of-range
+// indices for such points.  Invalid points (a non-finite longitude included) get pixel -1 and are counted
+// in *nbad; the entry points return HX_ERR_ARG before anything is scattered.
+__device__ inline bool lonlat_valid(double lon_deg, double lat_deg)
+{
+    const double theta = kHalfPi - lat_deg * kDeg2Rad;
+    return isfinite(lon_deg) && theta >= 0.0 && theta <= 3.14159265358979323846 + 1e-5;
+}
+
 __global__ __launch_bounds__(256) void k_ang2pix(long long nside, long long n, const double *__restrict__ lon,
                                                  const double *__restrict__ lat, long long *__restrict__ ipix,
-                                                 unsigned *__restrict__ order)
+                                                 unsigned *__restrict__ order, unsigned long long *__restrict__ nbad)
 {
     long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    ipix[j] = ang2pix_ring_one(nside, lon[j], lat[j]);
+    const double lo = lon[j], la = lat[j];
+    const bool ok = lonlat_valid(lo, la);
+    const long long npix = 12 * nside * nside;
+    long long p = ok ? ang2pix_ring_one(nside, lo, la) : -1;
+    if (ok && (p < 0 || p >= npix)) p = -1;  // never scatter outside the map
+    if (p < 0) atomicAdd(nbad, 1ULL);
+    ipix[j] = p;
     if (order) order[j] = (unsigned)j;
 }
 
@@ -241,12 +257,26 @@ __global__ __launch_bounds__(256) void k_ud_grade(int order_in, int order_out, c
 bool nside_ok(int nside) { return nside >= 1 && nside <= (1 << 24); }
 bool nside_pow2(int nside) { return nside >= 1 && nside <= 8192 && (nside & (nside - 1)) == 0; }
 
-int launch_ang2pix(int nside, long long n, const double *lon, const double *lat, long long *ipix, unsigned *order)
+// Pixel indices of n points; fails with HX_ERR_ARG (the reference: ValueError from healpy) if any point is
+// outside 0 <= theta <= pi or not finite.  Synchronises the stream (the count is read back).
+int launch_ang2pix(int nside, long long n, const double *lon, const double *lat, long long *ipix, unsigned *order,
+                   const char *who)
 {
     if (n == 0) return HX_OK;
+    static DevBuf d_bad;  // 8 bytes, lives with the process
+    HX_TRY(d_bad.alloc(sizeof(unsigned long long)));
+    hipStream_t st = rt().stream;
+    HX_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(unsigned long long), st));
     unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_ang2pix, dim3(blocks), dim3(256), 0, rt().stream, (long long)nside, n, lon, lat, ipix, order);
+    hipLaunchKernelGGL(k_ang2pix, dim3(blocks), dim3(256), 0, st, (long long)nside, n, lon, lat, ipix, order,
+                       d_bad.as<unsigned long long>());
     HX_HIP(hipGetLastError());
+    unsigned long long nbad = 0;
+    HX_HIP(hipMemcpyAsync(&nbad, d_bad.p, sizeof(nbad), hipMemcpyDeviceToHost, st));
+    HX_HIP(hipStreamSynchronize(st));
+    if (nbad)
+        return fail(HX_ERR_ARG, "%s: %llu of %lld points have a latitude outside [-90, 90] or a non-finite coordinate "
+                    "(healpy: THETA is out of range [0,pi])", who, nbad, n);
     return HX_OK;
 }
 
@@ -269,7 +299,7 @@ extern "C" int hx_ang2pix_ring(int nside, int64_t n, const double *lon, const do
     HX_TRY(vout.bind(ipix, sizeof(int64_t) * n));
     {
         ProfScope ps("ang2pix");
-        HX_TRY(launch_ang2pix(nside, n, vlon.as<double>(), vlat.as<double>(), (long long *)vout.as<int64_t>(), nullptr));
+        HX_TRY(launch_ang2pix(nside, n, vlon.as<double>(), vlat.as<double>(), (long long *)vout.as<int64_t>(), nullptr, "hx_ang2pix_ring"));
     }
     HX_TRY(vout.finish());
     return finish_call();
@@ -308,7 +338,7 @@ extern "C" int hx_map_values(int nside, int64_t n, const double *lon, const doub
     {
         ProfScope ps("ang2pix");
         HX_TRY(launch_ang2pix(nside, n, vlon.as<double>(), vlat.as<double>(), bpix.as<long long>(),
-                              ordered ? bord.as<unsigned>() : nullptr));
+                              ordered ? bord.as<unsigned>() : nullptr, "hx_map_values"));
     }
     if (ordered) {
         HX_TRY(bpix2.alloc(sizeof(long long) * n));

@@ -80,9 +80,13 @@ extern "C" int hx_measure_peaks(double *out4)
     hipEvent_t e0, e1;
     HX_HIP(hipEventCreate(&e0));
     HX_HIP(hipEventCreate(&e1));
+    // The clock of an idle device takes milliseconds to ramp up: a single 5-15 ms launch of the FP64 loops read
+    // 47 TFLOP/s here in round 1, the same loops after 0.3 s of back-to-back launches 77 (tools/ubench_power.hip).
+    // Every probe is therefore repeated for >= 0.25 s and the best of the launches is kept.
     auto best_ms = [&](auto launch, float &best) -> int {
         best = 1e30f;
-        for (int rep = 0; rep < 3; ++rep) {
+        float total = 0.f;
+        for (int rep = 0; rep < 400 && (rep < 3 || total < 250.f); ++rep) {
             HX_HIP(hipEventRecord(e0, st));
             launch();
             HX_HIP(hipEventRecord(e1, st));
@@ -90,6 +94,7 @@ extern "C" int hx_measure_peaks(double *out4)
             float ms = 0.f;
             HX_HIP(hipEventElapsedTime(&ms, e0, e1));
             best = ms < best ? ms : best;
+            total += ms;
         }
         HX_HIP(hipGetLastError());
         return HX_OK;

@@ -244,6 +244,17 @@ int OutView::finish()
     return copy_d2h(host, dev, bytes);  // synchronous on return
 }
 
+static double g_scratch_budget = -1.0;  // < 0: not yet read from the environment
+
+double scratch_budget_bytes()
+{
+    if (g_scratch_budget < 0.0) {
+        const char *e = getenv("HX_SCRATCH_GB");
+        g_scratch_budget = e ? std::max(0.0, atof(e)) * 1e9 : 0.0;
+    }
+    return g_scratch_budget;
+}
+
 int finish_call()
 {
     HX_HIP(hipGetLastError());
@@ -320,6 +331,13 @@ void *hx_get_stream(void)
 int hx_set_async(int on)
 {
     rt().async = on != 0;
+    return HX_OK;
+}
+
+int hx_set_scratch_budget(double bytes)
+{
+    if (!(bytes >= 0.0)) return fail(HX_ERR_ARG, "hx_set_scratch_budget: negative or NaN budget");
+    hx::g_scratch_budget = bytes;
     return HX_OK;
 }
 

@@ -509,6 +509,8 @@ extern "C" int64_t hx_plan_scratch_bytes(const hx_plan *pl)
                      pl->bhat.bytes + pl->resid.bytes + pl->Fsyn.bytes);
 }
 
+extern "C" int hx_plan_last_chunks(const hx_plan *pl) { return pl ? pl->last_chunks : 0; }
+
 namespace hx {
 int ensure_rec2(hx_plan *pl)
 {
@@ -626,8 +628,12 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
         if (niter > 0 && fl) HX_TRY(apply_fl(pl, nb, da, vfl.as<double>()));
     }
     HX_TRY(valms.finish());
-    HX_HIP(hipStreamSynchronize(rt().stream));  // staging buffers are released on return
-    return HX_OK;
+    // staging buffers of host arguments are released on return: only an all-device call may stay asynchronous
+    if (vmaps.tmp.p || vrw.tmp.p || vpw.tmp.p || vfl.tmp.p || valms.tmp.p) {
+        HX_HIP(hipStreamSynchronize(rt().stream));
+        return HX_OK;
+    }
+    return finish_call();
 }
 
 
@@ -646,6 +652,9 @@ extern "C" int hx_alm2map(hx_plan *pl, int spin, int ncomp, const double *alms, 
                                vmaps.as<double>() + (size_t)c0 * pl->npix, nullptr));
     }
     HX_TRY(vmaps.finish());
-    HX_HIP(hipStreamSynchronize(rt().stream));
-    return HX_OK;
+    if (valms.tmp.p || vmaps.tmp.p) {
+        HX_HIP(hipStreamSynchronize(rt().stream));
+        return HX_OK;
+    }
+    return finish_call();
 }

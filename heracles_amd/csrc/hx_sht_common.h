@@ -133,6 +133,7 @@ inline int upload(DevBuf &b, const std::vector<T> &v)
 struct hx_plan {
     int nside = 0, lmax = 0, max_comp = 0;
     int nrp = 0, nrp_pad = 0, twN = 1;
+    int last_chunks = 0;  // m-chunks of the most recent analysis sweep (hx_plan_last_chunks)
     long long npix = 0, ny = 0, nlm = 0;
     size_t lds_fft = 0;
     hx::DevBuf z, omz, sth, rwdef, nsub, shifted, startN, startS, bhat_off, tw, bhat, mfac, kfac2, rec0, rec2, cn0, al0, cn2, al2;

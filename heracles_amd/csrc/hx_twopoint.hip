@@ -34,6 +34,9 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_alm2cl_tiles(
     const int l = lblk * CL_LB + lane;
     const int lhi = min(lblk * CL_LB + CL_LB - 1, lmax_out);
 
+    // A tile may hold components whose own band limit is below lmax_out (mixed-lmax alms: only the
+    // components of REQUESTED pairs are checked against lmax_out by the host).  Their loads are
+    // predicated on (m, l) lying inside their own triangle -- the index would otherwise leave the buffer.
     const double2 *pa[CL_T], *pb[CL_T];
     long long La[CL_T], Lb[CL_T];
 #pragma unroll
@@ -51,8 +54,8 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_alm2cl_tiles(
             double2 a[CL_T], b[CL_T];
 #pragma unroll
             for (int t = 0; t < CL_T; ++t) {
-                a[t] = pa[t][(long long)m * (2 * La[t] + 1 - m) / 2 + l];
-                b[t] = pb[t][(long long)m * (2 * Lb[t] + 1 - m) / 2 + l];
+                a[t] = l <= La[t] ? pa[t][(long long)m * (2 * La[t] + 1 - m) / 2 + l] : make_double2(0.0, 0.0);
+                b[t] = l <= Lb[t] ? pb[t][(long long)m * (2 * Lb[t] + 1 - m) / 2 + l] : make_double2(0.0, 0.0);
             }
             const double wgt = m == 0 ? 1.0 : 2.0;
 #pragma unroll

@@ -40,6 +40,35 @@ def pixel_window(nside, lmax, pixwin=None):
     return hp.pixwin(nside, lmax=lmax, pol=True)
 
 
+def _check_points(rc):
+    """healpy.ang2pix raises ValueError for points outside 0 <= theta <= pi (or NaN); libhxsht reports them
+    as HX_ERR_ARG before anything is scattered."""
+    from . import _lib
+
+    if rc == _lib.HX_ERR_ARG:
+        raise ValueError(_lib.load().hx_last_error().decode(errors="replace"))
+    _lib.check(rc)
+
+
+_warned_unit_weights = False
+
+
+def _warn_unit_weights():
+    """One-time note: the reference calls hp.map2alm(use_pixel_weights=True, datapath=DATAPATH); the weight
+    files are healpy data this package cannot ship, so without ``pixel_weights`` / ``ring_weights`` the
+    quadrature uses unit weights (+ ``niter`` Jacobi iterations) and differs from the reference at the level of
+    the HEALPix quadrature error (~1e-3 relative at l ~ 2 nside without iterations, ~1e-5 with niter=3)."""
+    global _warned_unit_weights
+    if not _warned_unit_weights:
+        import warnings
+
+        _warned_unit_weights = True
+        warnings.warn("HipHealpixMapper.transform: no pixel_weights / ring_weights given; using unit quadrature "
+                      "weights (healpy's use_pixel_weights=True files are not shipped with heracles_amd). Pass "
+                      "pixel_weights= (full-sky array from healpy's weight file) for reference-equal alms.",
+                      RuntimeWarning, stacklevel=3)
+
+
 def _native(arr):
     """heracles/healpy.py:43-55: inputs in non-native byte order are byteswapped."""
     arr = np.asanyarray(arr)
@@ -69,7 +98,7 @@ def ang2pix_ring(nside, lon, lat, out=None):
         n = lon.size
     if lon.shape != lat.shape:
         raise ValueError("lon and lat must have the same shape")
-    _lib.check(_lib.load().hx_ang2pix_ring(int(nside), n, _lib.ptr(lon), _lib.ptr(lat), _lib.ptr(out)))
+    _check_points(_lib.load().hx_ang2pix_ring(int(nside), n, _lib.ptr(lon), _lib.ptr(lat), _lib.ptr(out)))
     return out
 
 
@@ -110,8 +139,8 @@ def map_values(nside, lon, lat, data, values, *, ordered=True):
         # the compiled reference loop broadcasts values[..., j] into maps[..., i]
         values = (np.broadcast_to(values, (*data.shape[:-1], n)).copy() if not on_dev
                   else values.expand(*data.shape[:-1], n).contiguous())
-    _lib.check(_lib.load().hx_map_values(int(nside), n, _lib.ptr(lon), _lib.ptr(lat), nval, _lib.ptr(values),
-                                         _lib.ptr(maps), 0 if ordered else 1))
+    _check_points(_lib.load().hx_map_values(int(nside), n, _lib.ptr(lon), _lib.ptr(lat), nval, _lib.ptr(values),
+                                            _lib.ptr(maps), 0 if ordered else 1))
     if maps is not data:
         data[...] = maps
 
@@ -213,6 +242,8 @@ class HipHealpixMapper:
             raise NotImplementedError(f"spin-{spin} maps not yet supported")
         fl = self._fl(spin)
         plan = sht.get_plan(self.__nside, self.__lmax)
+        if self.pixel_weights is None and self.ring_weights is None:
+            _warn_unit_weights()
         if hasattr(data, "data_ptr"):
             # device-resident maps (e.g. accumulated by map_values on the GPU): alms stay in HBM; a torch
             # tensor cannot carry dtype metadata, so none is attached

@@ -48,6 +48,11 @@ class Plan:
     def scratch_bytes(self) -> int:
         return int(_lib.load().hx_plan_scratch_bytes(self._h))
 
+    @property
+    def last_chunks(self) -> int:
+        """m-chunks of the most recent analysis sweep (see hx_set_scratch_budget)."""
+        return int(_lib.load().hx_plan_last_chunks(self._h))
+
     def mfma_flops(self, spin, ncomp):
         """Matrix-instruction flops one map2alm(niter=0) of ncomp components executes."""
         import ctypes
@@ -55,6 +60,14 @@ class Plan:
         out = ctypes.c_double(0.0)
         _lib.check(_lib.load().hx_plan_mfma_flops(self._h, int(spin), int(ncomp), ctypes.byref(out)))
         return out.value
+
+    def executed_flops(self, spin, ncomp):
+        """(matrix-instruction flops, FP64 vector flops of the recursions) one map2alm(niter=0) executes."""
+        import ctypes
+
+        out = (ctypes.c_double * 2)()
+        _lib.check(_lib.load().hx_plan_executed_flops(self._h, int(spin), int(ncomp), out))
+        return out[0], out[1]
 
     # -- helpers ------------------------------------------------------------------
     def _out_like(self, ref, shape, complex_):

@@ -174,27 +174,27 @@ def angular_power_spectra(alms, alms2=None, *, lmax=None, debias=True, bins=None
         seen.add((k1, k2, i1, i2))
         names.add((k1, k2))
     # pass 2: one launch for every component pair of every map pair
-    comps, index, plist, shapes = [], {}, [], []
-
-    def comp_ids(arr):
-        a2 = np.ascontiguousarray(arr, dtype=np.complex128).reshape(-1, arr.shape[-1])
-        ids = []
-        for row in range(a2.shape[0]):
-            key = (id(arr), row)
-            if key not in index:
-                index[key] = len(comps)
-                comps.append(a2[row])
-            ids.append(index[key])
-        return ids
-
     louts = []
     for key, alm1, alm2 in todo:
         l1, l2 = alm2lmax(alm1), alm2lmax(alm2)
         louts.append(min(l1, l2) if lmax is None else min(lmax, l1, l2))
-    # the kernel writes a common output length; group by output lmax
+    # the kernel writes a common output length; group by output lmax.  Each group stages only the
+    # components its own pairs use (alms of different band limits may be mixed, twopoint.py:78-99).
     results = [None] * len(todo)
     for lo in sorted(set(louts)):
-        plist, owners = [], []
+        comps, index, plist, owners = [], {}, [], []
+
+        def comp_ids(arr, comps=comps, index=index):
+            a2 = np.ascontiguousarray(arr, dtype=np.complex128).reshape(-1, arr.shape[-1])
+            ids = []
+            for row in range(a2.shape[0]):
+                key = (id(arr), row)
+                if key not in index:
+                    index[key] = len(comps)
+                    comps.append(a2[row])
+                ids.append(index[key])
+            return ids
+
         for n, (key, alm1, alm2) in enumerate(todo):
             if louts[n] != lo:
                 continue

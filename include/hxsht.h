@@ -61,13 +61,21 @@ int hx_profile_get(const char *name, int *launches, double *total_ms);
 hx_plan *hx_plan_create(int nside, int lmax, int max_comp);
 void hx_plan_destroy(hx_plan *plan);
 int64_t hx_plan_scratch_bytes(const hx_plan *plan);
-/* Measurement aid: what this device sustains, from micro-kernels (~0.3 s): out4 = { HBM read GB/s,
+/* HBM the analysis may use for the operands and ring-group partial sums of ONE m-chunk (bytes; a chunk always
+ * holds at least one m).  0 (default) = min(64 GB, half of the free HBM); the environment variable
+ * HX_SCRATCH_GB sets the initial value.  The result does not depend on the chunking (tests/test_gpu_sht.py). */
+int hx_set_scratch_budget(double bytes);
+/* m-chunks the most recent analysis sweep of this plan was cut into (diagnostic / tests). */
+int hx_plan_last_chunks(const hx_plan *plan);
+/* Measurement aid: what this device sustains, from micro-kernels repeated for ~0.25 s each (clock settled): out4 = { HBM read GB/s,
  * HBM copy GB/s (read + write), FP64 MFMA 16x16x4 TFLOP/s, FP64 VALU FMA TFLOP/s }.             */
 int hx_measure_peaks(double *out4);
 /* Measurement aid (bench.py's roofline): matrix-instruction flops one hx_map2alm(niter = 0) of
  * ncomp components EXECUTES (task list x MFMAs per wave-block), as opposed to the algorithmic
  * 8 * 2 nside * nlm per component the roofline is quoted on.                              */
 int hx_plan_mfma_flops(hx_plan *plan, int spin, int ncomp, double *flops);
+/* out2[0] = the same, out2[1] = FP64 vector flops of the recursions (4 per value of lambda_lm(theta) generated). */
+int hx_plan_executed_flops(hx_plan *plan, int spin, int ncomp, double *out2);
 
 /* maps  : [ncomp][npix] double; spin 2: components come in (Q,U) pairs, ncomp even
  * alms  : [ncomp][nlm] complex; spin 2: (E,B) pairs

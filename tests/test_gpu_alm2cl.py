@@ -86,3 +86,32 @@ def test_alm2cl_full_size_properties():
     idx = np.array([m * (2 * lmax + 1 - m) // 2 + l for m in range(l + 1)])
     ref = (a[idx[0]].real * b[idx[0]].real + 2 * (a[idx[1:]] * np.conj(b[idx[1:]])).real.sum()) / (2 * l + 1)
     assert abs(cab[l] - ref) < 1e-12 * max(1, abs(ref))
+
+
+def test_mixed_lmax_in_one_call(oracle):
+    """Alms of different band limits in one angular_power_spectra call (the reference's alm2cl supports it,
+    twopoint.py:78-99): every output-lmax group sweeps a tile at ITS lmax, so components with a smaller
+    band limit that share the component list / a tile must never be indexed outside their triangle."""
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(2024)
+    lm = {"A": 50, "B": 1000, "C": 100, "D": 7}
+    alms = {}
+    for n, (name, lmax) in enumerate(lm.items()):
+        spin = 2 if name in ("B", "D") else 0
+        a = random_alm(rng, lmax, spin, (2,) if spin else ())
+        a.dtype = np.dtype(a.dtype, metadata={"spin": spin, "nside": 64})
+        alms[name, 0] = a
+    cls = hx.angular_power_spectra(alms, debias=False)
+    assert len(cls) == 10
+    for (k1, k2, i1, i2), res in cls.items():
+        ref = oracle.alm2cl(np.asarray(alms[k1, i1]), np.asarray(alms[k2, i2]))
+        assert res.array.shape == ref.shape, (k1, k2)
+        np.testing.assert_allclose(np.asarray(res.array), ref, rtol=RTOL, atol=1e-13)
+    # the raw kernel with a low-lmax component inside a tile swept at a much higher lmax_out
+    comps = [random_alm(rng, 1000), random_alm(rng, 50), random_alm(rng, 1000), random_alm(rng, 3)]
+    out = hx.alm2cl_pairs(comps, [(0, 2), (2, 0), (0, 0)], 1000)
+    np.testing.assert_allclose(out[0], oracle.alm2cl(comps[0], comps[2]), rtol=RTOL, atol=1e-13)
+    np.testing.assert_array_equal(out[0], out[1])
+    with pytest.raises(hx.HxError):
+        hx.alm2cl_pairs(comps, [(0, 1)], 1000)  # a REQUESTED pair beyond its band limit is an error

@@ -154,6 +154,33 @@ def test_ang2pix_matches_oracle(oracle, nside):
                                       np.arange(12 * nside**2))
 
 
+def test_invalid_points_raise_before_any_scatter():
+    """healpy.ang2pix raises ValueError for |lat| > 90 and for NaN (check_theta_valid), so the reference never
+    scatters such a page; here the device flags them and nothing is written."""
+    import heracles_amd as hx
+    from heracles_amd.mapper import ang2pix_ring, map_values
+
+    nside = 16
+    lon = np.array([10.0, 20.0, 30.0, 40.0])
+    for bad in (90.05, -91.0, np.nan, 1e300):
+        lat = np.array([0.0, bad, 45.0, -45.0])
+        with pytest.raises(ValueError):
+            ang2pix_ring(nside, lon, lat)
+        maps = np.full((2, 12 * nside**2), 7.0)
+        with pytest.raises(ValueError):
+            map_values(nside, lon, lat, maps, np.ones((2, 4)))
+        assert (maps == 7.0).all()
+    with pytest.raises(ValueError):
+        ang2pix_ring(nside, np.array([np.inf, 0.0, 0.0, 0.0]), np.zeros(4))
+    # the poles and the seam are valid
+    ang2pix_ring(nside, np.array([0.0, 360.0, -720.0, 1e6]), np.array([90.0, -90.0, 0.0, 12.0]))
+    m = hx.HipHealpixMapper(nside)
+    d = m.create()
+    with pytest.raises(ValueError):
+        m.map_values(lon, np.array([0.0, 0.0, 95.0, 0.0]), d, np.ones(4))
+    assert not d.any()
+
+
 def test_map_values_reference_case():
     """tests/test_healpy.py:44-77 with the GPU mapper: order-exact sums."""
     from heracles_amd import HipHealpixMapper

@@ -193,3 +193,38 @@ def test_long_l_ranges_small_batches(oracle):
         for ncomp in ncomps:
             maps = rng.standard_normal((ncomp, 12 * nside**2))
             close(plan.map2alm(maps, spin), oracle.map2alm(maps, nside, lmax, spin=spin))
+
+
+@pytest.mark.parametrize("spin,ncomp", [(0, 10), (2, 20), (0, 16), (2, 8), (0, 3), (2, 2)])
+def test_map2alm_m_chunked_batches_medium(oracle, spin, ncomp):
+    """The sweep shapes bench.py times -- 10 spin-0 maps in one sweep (one 16-column group + one 4-column block),
+    20 spin-2 components as two sweeps of 5 fields, full two-group sweeps -- at a size where the sweep is cut into
+    several m-chunks (scratch budget lowered through hx_set_scratch_budget) and polar pruning is active
+    (nside 256: rings beyond m > lmax sin(theta) + 100 are skipped), against the oracle on every 16th m."""
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(400 + 10 * spin + ncomp)
+    nside, lmax = 256, 511
+    maps = rng.standard_normal((ncomp, 12 * nside**2))
+    plan = hx.get_plan(nside, lmax)
+    whole = plan.map2alm(maps, spin)
+    nchunk_default = plan.last_chunks
+    hx._lib.set_scratch_budget(2.5e6 * min(ncomp, 10))
+    try:
+        out = plan.map2alm(maps, spin)
+        assert plan.last_chunks >= 3, plan.last_chunks
+    finally:
+        hx._lib.set_scratch_budget(0)
+    assert nchunk_default == 1
+    np.testing.assert_array_equal(out, whole)  # the chunking does not change a bit
+    stride = 16
+    oracle.set_mstride(stride)
+    try:
+        ref = oracle.map2alm(maps, nside, lmax, spin=spin)
+    finally:
+        oracle.set_mstride(1)
+    scale = np.abs(ref).max()
+    for m in range(0, lmax + 1, stride):
+        base = m * (2 * lmax + 1 - m) // 2
+        err = np.abs(out[:, base + m : base + lmax + 1] - ref[:, base + m : base + lmax + 1]).max()
+        assert err <= TOL * scale, (m, err / scale)
