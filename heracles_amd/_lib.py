@@ -26,7 +26,7 @@ SYMBOLS = (
     "hx_version", "hx_last_error", "hx_device_count", "hx_init", "hx_set_stream",
     "hx_get_stream", "hx_set_async", "hx_synchronize", "hx_timer_start", "hx_timer_stop",
     "hx_profile_enable", "hx_profile_reset", "hx_profile_get", "hx_plan_create",
-    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_set_scratch_budget", "hx_plan_last_chunks", "hx_plan_mfma_flops", "hx_plan_executed_flops", "hx_measure_peaks", "hx_map2alm", "hx_alm2map",
+    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_set_scratch_budget", "hx_plan_last_chunks", "hx_plan_mfma_flops", "hx_plan_executed_flops", "hx_measure_peaks", "hx_measured_mfma_clock", "hx_map2alm", "hx_alm2map",
     "hx_alm2cl_pairs", "hx_gauss_legendre", "hx_wigner_d_table", "hx_mixmat",
     "hx_mixmat_eb", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_alm_resample",
 )
@@ -80,6 +80,7 @@ def load():
         L.hx_plan_mfma_flops.argtypes = [vp, i, i, C.POINTER(C.c_double)]
         L.hx_plan_executed_flops.argtypes = [vp, i, i, C.POINTER(C.c_double)]
         L.hx_measure_peaks.argtypes = [C.POINTER(C.c_double)]
+        L.hx_measured_mfma_clock.restype = C.c_double
         L.hx_map2alm.argtypes = [vp, i, i, dp, dp, dp, dp, dp, i]
         L.hx_alm2map.argtypes = [vp, i, i, dp, dp]
         L.hx_alm2cl_pairs.argtypes = [i, vp, vp, i, i, vp, vp, dp]
@@ -156,7 +157,8 @@ def measure_peaks():
     ensure_init()
     out = (C.c_double * 4)()
     check(load().hx_measure_peaks(out))
-    return {"hbm_read_gbs": out[0], "hbm_copy_gbs": out[1], "fp64_mfma_tflops": out[2], "fp64_valu_tflops": out[3]}
+    return {"hbm_read_gbs": out[0], "hbm_copy_gbs": out[1], "fp64_mfma_tflops": out[2], "fp64_valu_tflops": out[3],
+            "fp64_mfma_clock_ghz": load().hx_measured_mfma_clock()}
 
 
 def synchronize():

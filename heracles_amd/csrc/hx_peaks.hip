@@ -3,6 +3,8 @@
 // peak and against what the box delivers (SURVEY.md 8d asks the harness for exactly that).
 #include "hx_common.h"
 
+#include <vector>
+
 namespace hx {
 namespace {
 
@@ -24,17 +26,26 @@ __global__ __launch_bounds__(256) void k_peak_valu(double *out, int iters, doubl
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
-__global__ __launch_bounds__(256) void k_peak_mfma(double *out, int iters, double seed)
+// 16 independent-enough MFMAs per iteration on 8 operand pairs and 4 accumulators, one wave per SIMD: 64.0 cycles per
+// instruction, 77 TFLOP/s at 2.38 GHz on this part.  (Round 1's probe -- 4 MFMAs per loop iteration -- read 47 TFLOP/s at the
+// SAME clock: 142 cycles per instruction from the wait states hipcc puts around the loop-carried accumulators, not a
+// property of the pipe; tools/ubench_power.hip reproduces both.)  clk[0..1] of wave 0: shader ticks, 100 MHz ticks.
+__global__ __launch_bounds__(256) void k_peak_mfma(double *out, int iters, const double *__restrict__ src, unsigned long long *clk)
 {
     double4_t c[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) c[u] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    const double ma = seed * 1e-3 + threadIdx.x * 1e-6, mb = 1.0 + threadIdx.x * 1e-7;
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a[u] = src[(threadIdx.x * 8 + u) & 2047]; b[u] = src[(threadIdx.x * 8 + u + 77) & 2047]; }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ma, mb, c[u], 0, 0, 0);
+        for (int u = 0; u < 16; ++u) c[u & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u & 7], b[u & 7], c[u & 3], 0, 0, 0);
     }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = c[0][0] + c[1][1] + c[2][2] + c[3][3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
 
 __global__ __launch_bounds__(256) void k_peak_copy(const double2 *__restrict__ in, double2 *__restrict__ out, size_t n)
@@ -61,8 +72,13 @@ __global__ __launch_bounds__(256) void k_peak_read(const double2 *__restrict__ i
 
 using namespace hx;
 
+static double g_mfma_clock_ghz = 0.0;
+
+// In-kernel shader clock (GHz) during the FP64 MFMA probe of the last hx_measure_peaks call (s_memtime / s_memrealtime).
+extern "C" double hx_measured_mfma_clock(void) { return g_mfma_clock_ghz; }
+
 // out[0] HBM read GB/s, out[1] HBM copy GB/s (read + write bytes), out[2] FP64 MFMA 16x16x4 TFLOP/s,
-// out[3] FP64 VALU FMA TFLOP/s.  Best of three runs each, ~0.3 s in total.
+// out[3] FP64 VALU FMA TFLOP/s.  Best launch of ~0.25 s of repeats each.
 extern "C" int hx_measure_peaks(double *out4)
 {
     HX_TRY(ensure_ready());
@@ -72,7 +88,7 @@ extern "C" int hx_measure_peaks(double *out4)
     HX_HIP(hipGetDeviceProperties(&prop, rt().device));
     const int cus = prop.multiProcessorCount;
     const size_t n = (size_t)1 << 27;  // 2 GiB of double2 per buffer
-    DevBuf a, b, small;
+    DevBuf a, b, small, mf_src;
     HX_TRY(a.alloc(n * sizeof(double2)));
     HX_TRY(b.alloc(n * sizeof(double2)));
     HX_TRY(small.alloc((size_t)cus * 4 * 256 * sizeof(double)));
@@ -106,8 +122,23 @@ extern "C" int hx_measure_peaks(double *out4)
     HX_TRY(best_ms([&] { hipLaunchKernelGGL(k_peak_copy, dim3(blocks), dim3(256), 0, st, a.as<double2>(), b.as<double2>(), n); }, ms));
     out4[1] = (double)n * 32.0 / (ms * 1e-3) / 1e9;
     const int iters = 20000, fblocks = cus * 4;  // 4 blocks of 4 waves per CU = 4 waves per SIMD
-    HX_TRY(best_ms([&] { hipLaunchKernelGGL(k_peak_mfma, dim3(fblocks), dim3(256), 0, st, small.as<double>(), iters, 1.0); }, ms));
-    out4[2] = (double)fblocks * 4 * iters * 4.0 * 2048.0 / (ms * 1e-3) / 1e12;
+    {
+        // operands: pseudo-random values of order 1e-3 (zeros or trivial operands would flatter the clock)
+        std::vector<double> h(2048);
+        unsigned long long x = 88172645463325252ULL;
+        for (auto &v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = ((double)(x >> 11) / 9007199254740992.0 - 0.5) * 2e-3; }
+        HX_TRY(mf_src.alloc(sizeof(double) * 2048 + 16));
+        HX_HIP(hipMemcpy(mf_src.p, h.data(), sizeof(double) * 2048, hipMemcpyHostToDevice));
+    }
+    unsigned long long *d_clk = reinterpret_cast<unsigned long long *>(mf_src.as<double>() + 2048);
+    const int miters = 4000;
+    HX_TRY(best_ms([&] { hipLaunchKernelGGL(k_peak_mfma, dim3(cus), dim3(256), 0, st, small.as<double>(), miters, mf_src.as<double>(), d_clk); }, ms));
+    out4[2] = (double)cus * 4 * miters * 16.0 * 2048.0 / (ms * 1e-3) / 1e12;
+    {
+        unsigned long long hclk[2] = {0, 1};
+        HX_HIP(hipMemcpy(hclk, d_clk, sizeof(hclk), hipMemcpyDeviceToHost));
+        g_mfma_clock_ghz = hclk[1] ? (double)hclk[0] / (double)hclk[1] * 0.1 : 0.0;
+    }
     HX_TRY(best_ms([&] { hipLaunchKernelGGL(k_peak_valu, dim3(fblocks), dim3(256), 0, st, small.as<double>(), iters, 1.0); }, ms));
     out4[3] = (double)fblocks * 4 * iters * 16.0 * 2.0 * 64.0 / (ms * 1e-3) / 1e12;
     (void)hipEventDestroy(e0);

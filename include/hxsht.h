@@ -70,6 +70,8 @@ int hx_plan_last_chunks(const hx_plan *plan);
 /* Measurement aid: what this device sustains, from micro-kernels repeated for ~0.25 s each (clock settled): out4 = { HBM read GB/s,
  * HBM copy GB/s (read + write), FP64 MFMA 16x16x4 TFLOP/s, FP64 VALU FMA TFLOP/s }.             */
 int hx_measure_peaks(double *out4);
+/* Shader clock in GHz held during the FP64 MFMA probe of the last hx_measure_peaks call (0 before any). */
+double hx_measured_mfma_clock(void);
 /* Measurement aid (bench.py's roofline): matrix-instruction flops one hx_map2alm(niter = 0) of
  * ncomp components EXECUTES (task list x MFMAs per wave-block), as opposed to the algorithmic
  * 8 * 2 nside * nlm per component the roofline is quoted on.                              */

@@ -1,13 +1,15 @@
-"""world_size-2 gloo test of the multi-GPU sharding logic on CPU: all-gather of alm shards,
-pair partition, gather of the Cl blocks.  The arithmetic kernel is the oracle here (the HIP
-kernel needs a GPU); what is tested is that the sharded job returns exactly the spectra of
-the single-process job over all maps."""
+"""world_size-2/3 gloo tests of the multi-GPU sharding logic on CPU: cost-balanced map assignment, in-place
+all-gather of the alm shards, tiled pair partition, gather of the Cl blocks.  The arithmetic kernel is the
+oracle here (the HIP kernel needs a GPU); what is tested is that the sharded job returns exactly the spectra
+of the single-process job over all maps."""
 
 import os
 import socket
 
 import numpy as np
 import pytest
+
+SPINS = [0, 2, 0, 2, 2, 0, 0, 2, 0]  # a job of 9 maps in a mixed order
 
 
 def _free_port():
@@ -25,28 +27,42 @@ def _kernel(comps, plist, lmax):
     return out
 
 
-def _make(rank, nbins, lmax):
+def _alm_of_map(g, spin, lmax):
+    """Seeded alms of global map g: (nlm,) for spin 0, (2, nlm) for spin 2 -- what a rank's map2alm would produce."""
     import torch
 
     nlm = (lmax + 1) * (lmax + 2) // 2
-    g = torch.Generator().manual_seed(100 + rank)
-    a0 = torch.randn((nbins, nlm, 2), dtype=torch.float64, generator=g)
-    a2 = torch.randn((nbins, 2, nlm, 2), dtype=torch.float64, generator=g)
-    return torch.view_as_complex(a0).contiguous(), torch.view_as_complex(a2).contiguous()
+    gen = torch.Generator().manual_seed(1000 + g)
+    shape = (nlm, 2) if spin == 0 else (2, nlm, 2)
+    return torch.view_as_complex(torch.randn(shape, dtype=torch.float64, generator=gen)).contiguous()
 
 
-def _worker(rank, world, port, nbins, lmax, outdir):
+def _fill_local(work, lmax):
+    a0, a2 = work.local_alm_views("cpu")
+    k0 = k2 = 0
+    for g in work.local_maps:
+        if work.spins[g] == 0:
+            a0[k0] = _alm_of_map(g, 0, lmax)
+            k0 += 1
+        else:
+            a2[k2] = _alm_of_map(g, 2, lmax)
+            k2 += 1
+    assert k0 == a0.shape[0] and k2 == a2.shape[0]
+
+
+def _worker(rank, world, port, lmax, outdir):
     import torch.distributed as dist
 
-    from heracles_amd.distributed import PairWork
+    from heracles_amd.distributed import ShardedTwoPoint
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     nlm = (lmax + 1) * (lmax + 2) // 2
-    a0, a2 = _make(rank, nbins, lmax)
-    work = PairWork(world, rank, nbins, nlm, lmax, kernel=_kernel)
-    res = work.all_pairs_cl(a0, a2)
+    work = ShardedTwoPoint(SPINS, world, rank, nlm, lmax, kernel=_kernel)
+    for _ in range(2):  # the second step reuses the buffer
+        _fill_local(work, lmax)
+        res = work.all_pairs_cl()
     if rank == 0:
         np.save(os.path.join(outdir, "sharded.npy"), res)
     else:
@@ -55,43 +71,67 @@ def _worker(rank, world, port, nbins, lmax, outdir):
     dist.destroy_process_group()
 
 
+def _reference(lmax):
+    """All spectra from the definition, map pairs in combinations_with_replacement order."""
+    rows = []
+    alms = [np.atleast_2d(_alm_of_map(g, s, lmax).numpy()) for g, s in enumerate(SPINS)]
+    for i in range(len(SPINS)):
+        for j in range(i, len(SPINS)):
+            for a in alms[i]:
+                for b in alms[j]:
+                    rows.append(_kernel([a, b], [(0, 1)], lmax)[0])
+    return np.array(rows)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_equals_single(tmp_path, world):
-    import torch
     import torch.multiprocessing as mp
 
-    from heracles_amd.distributed import PairWork, comps_of_map, map_pairs
+    from heracles_amd.distributed import ShardedTwoPoint
 
-    nbins, lmax = 2, 12
+    lmax = 12
     nlm = (lmax + 1) * (lmax + 2) // 2
-    mp.spawn(_worker, args=(world, _free_port(), nbins, lmax, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), lmax, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "sharded.npy")
-    # single-process job over the same maps
-    comps = []
-    for r in range(world):
-        a0, a2 = _make(r, nbins, lmax)
-        comps += [a0[k].numpy() for k in range(nbins)] + [a2.reshape(2 * nbins, nlm)[k].numpy() for k in range(2 * nbins)]
-    nmaps = 2 * nbins * world
-    cpairs = [(a, b) for (i, j) in map_pairs(nmaps) for a in comps_of_map(i, nbins) for b in comps_of_map(j, nbins)]
-    ref = _kernel(comps, cpairs, lmax)
+    ref = _reference(lmax)
     assert got.shape == ref.shape
     np.testing.assert_array_equal(got, ref)
-    # world == 1 path: no communication, same answer for rank 0's maps
-    a0, a2 = _make(0, nbins, lmax)
-    one = PairWork(1, 0, nbins, nlm, lmax, kernel=_kernel).all_pairs_cl(a0, a2)
-    n1 = 2 * nbins
-    assert one.shape[0] == n1 * (n1 + 1) // 2 - nbins * (nbins + 1) // 2 + 4 * (nbins * (nbins + 1) // 2) + nbins * nbins
-    assert torch.is_tensor(a0)
+    # world == 1 path: no communication, same answer
+    one = ShardedTwoPoint(SPINS, 1, 0, nlm, lmax, kernel=_kernel)
+    _fill_local(one, lmax)
+    np.testing.assert_array_equal(one.all_pairs_cl(), ref)
+
+
+def test_assignment_is_cost_balanced():
+    from heracles_amd.distributed import assign_maps, map_cost
+
+    # the north-star job: 10 spin-0 + 10 spin-2 maps = 40 cost units
+    spins = [0] * 10 + [2] * 10
+    for world, worst in ((1, 40), (2, 20), (4, 10), (8, 6)):
+        owner = assign_maps(spins, world)
+        load = [sum(map_cost(spins[g]) for g in range(20) if owner[g] == r) for r in range(world)]
+        assert sum(load) == 40 and max(load) == worst, (world, load)
+        assert min(load) >= worst - 2  # (8 ranks: two spin-2 maps on two of them is the best there is: 6 against a mean of 5)
+    # deterministic and identical on every rank
+    assert assign_maps(SPINS, 3) == assign_maps(list(SPINS), 3)
 
 
 def test_partition_covers_all_pairs():
-    from heracles_amd.distributed import PairWork
+    from heracles_amd.distributed import ShardedTwoPoint
 
-    for world in (1, 2, 4, 8):
-        seen = []
-        for r in range(world):
-            w = PairWork(world, r, 3, 10, 3, kernel=_kernel)
-            seen += w.my_pairs
-            assert sum(w.counts) == sum(len(PairWork(world, q, 3, 10, 3, kernel=_kernel).my_cpairs) for q in range(world))
-        assert sorted(seen) == sorted(PairWork(world, 0, 3, 10, 3, kernel=_kernel).pairs)
-        assert len(seen) == len(set(seen))
+    for spins in ([0] * 10 + [2] * 10, SPINS, [2], [0, 0, 0]):
+        for world in (1, 2, 4, 8):
+            ws = [ShardedTwoPoint(spins, world, r, 10, 3, kernel=_kernel) for r in range(world)]
+            seen = [p for w in ws for p in w.my_pairs]
+            assert sorted(seen) == sorted(ws[0].pairs) and len(seen) == len(set(seen))
+            rows = sorted(k for w in ws for k in w.rows_of[w.rank])
+            assert rows == list(range(ws[0].nrows))
+            # every component slot is owned by exactly one map, shards do not overlap
+            slots = sorted(c for g in range(len(spins)) for c in ws[0].comps_of_map[g])
+            assert len(slots) == len(set(slots)) and max(slots) < world * ws[0].ncomp_max
+            if world == 8 and len(spins) == 20:
+                # tiles: a rank reads far fewer than all 30 components
+                touched = [len({c for pr in w.my_cpairs for c in pr}) for w in ws]
+                assert max(touched) < 30 and sum(touched) / world <= 22, touched
+                counts = [len(w.my_cpairs) for w in ws]
+                assert max(counts) <= 1.5 * sum(counts) / world, counts

@@ -97,6 +97,52 @@ __global__ __launch_bounds__(512) void k_duty(double *out, Stamp *st, int iters,
     if (lane == 0) st[blockIdx.x * 8 + w] = s;
 }
 
+// round 1's probe (hx_measure_peaks of that round, tools/ubench_fp64.hip): ONE operand pair for every MFMA, 4 accumulators,
+// 4 MFMAs per loop iteration.  SAMEOP 1: as it was; 0: the operands rotate through 4 register pairs
+template <int SAMEOP>
+__global__ __launch_bounds__(256) void k_r1probe(double *out, Stamp *st, int iters, double seed)
+{
+    double4_t c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double ma[4], mb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { ma[u] = seed * 1e-3 + threadIdx.x * 1e-6 + (SAMEOP ? 0 : u * 1e-4); mb[u] = 1.0 + threadIdx.x * 1e-7 + (SAMEOP ? 0 : u * 1e-5); }
+    Stamp s;
+    s.t0 = __builtin_amdgcn_s_memtime(); s.r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[SAMEOP ? 0 : u], mb[SAMEOP ? 0 : u], c[u], 0, 0, 0);
+    }
+    s.t1 = __builtin_amdgcn_s_memtime(); s.r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = c[0][0] + c[1][1] + c[2][2] + c[3][3];
+    if ((threadIdx.x & 63) == 0) st[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 2047] = s;
+}
+
+template <int SAMEOP>
+int run_r1(const char *label, int bpc, double *d_out, Stamp *d_st, int cus)
+{
+    const int iters = 20000, blocks = cus * bpc;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms = 0.f; double total = 0.0;
+    for (int reps = 0; total < 400.0 && reps < 200; ++reps) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_r1probe<SAMEOP>), dim3(blocks), dim3(256), 0, 0, d_out, d_st, iters, 1.0);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        total += ms;
+    }
+    std::vector<Stamp> h(2048);
+    CK(hipMemcpy(h.data(), d_st, sizeof(Stamp) * 2048, hipMemcpyDeviceToHost));
+    std::vector<double> ghz, ticks;
+    for (auto &s : h) if (s.r1 > s.r0) { ghz.push_back((double)(s.t1 - s.t0) / (double)(s.r1 - s.r0) * 0.1); ticks.push_back((double)(s.t1 - s.t0) / (4.0 * iters)); }
+    std::sort(ghz.begin(), ghz.end()); std::sort(ticks.begin(), ticks.end());
+    printf("%-44s waves/SIMD %d: %8.3f ms  %6.1f TF  %6.1f ticks per MFMA per wave  clock %.2f GHz\n", label, bpc, ms,
+           (double)blocks * 4 * iters * 4.0 * 2048.0 / ms * 1e-9, ticks[ticks.size() / 2], ghz[ghz.size() / 2]);
+    fflush(stdout);
+    return 0;
+}
+
 struct Res { double tf, ticks_per_mfma, ghz, ms; };
 
 template <int MODE, int NMF, int SLEEP>
@@ -137,11 +183,15 @@ int main()
     const int cus = p.multiProcessorCount;
     printf("device %s CUs %d\n", p.name, cus);
     double *d_out, *d_src; Stamp *d_st;
-    CK(hipMalloc(&d_out, sizeof(double) * cus * 512)); CK(hipMalloc(&d_st, sizeof(Stamp) * cus * 8)); CK(hipMalloc(&d_src, sizeof(double) * 4096));
+    CK(hipMalloc(&d_out, sizeof(double) * cus * 512)); CK(hipMalloc(&d_st, sizeof(Stamp) * (cus * 8 > 2048 ? cus * 8 : 2048))); CK(hipMalloc(&d_src, sizeof(double) * 4096));
     std::vector<double> src(4096);
     srand(50);
     for (auto &v : src) v = (rand() / (double)RAND_MAX - 0.5) * 1e-3;
     CK(hipMemcpy(d_src, src.data(), sizeof(double) * 4096, hipMemcpyHostToDevice));
+    for (int bpc : {1, 2, 4}) {
+        if (run_r1<1>("round-1 probe: one operand pair", bpc, d_out, d_st, cus)) return 1;
+        if (run_r1<0>("round-1 probe: rotating operand pairs", bpc, d_out, d_st, cus)) return 1;
+    }
     for (int wpb : {4, 8}) {
         if (run<0, 16, 0>("16x16x4 stream", wpb, 0, d_out, d_st, d_src, cus)) return 1;
         if (run<1, 16, 0>("4x(4x4x4_4b) + DPP-rotated A", wpb, 0, d_out, d_st, d_src, cus)) return 1;
