@@ -28,7 +28,7 @@ SYMBOLS = (
     "hx_profile_enable", "hx_profile_reset", "hx_profile_get", "hx_plan_create",
     "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_set_scratch_budget", "hx_plan_last_chunks", "hx_plan_mfma_flops", "hx_plan_executed_flops", "hx_measure_peaks", "hx_measured_mfma_clock", "hx_map2alm", "hx_alm2map",
     "hx_alm2cl_pairs", "hx_gauss_legendre", "hx_wigner_d_table", "hx_mixmat",
-    "hx_mixmat_eb", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_alm_resample",
+    "hx_mixmat_eb", "hx_mixmat_batch", "hx_mixctx_create", "hx_mixctx_apply", "hx_mixctx_destroy", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_alm_resample",
 )
 
 
@@ -88,6 +88,12 @@ def load():
         L.hx_wigner_d_table.argtypes = [i, i, i, i, dp, dp]
         L.hx_mixmat.argtypes = [dp, i, i, i, i, i, i, dp]
         L.hx_mixmat_eb.argtypes = [dp, i, i, i, i, dp]
+        L.hx_mixmat_batch.argtypes = [i, dp, i, i, i, i, vp, vp, vp, vp]
+        L.hx_mixctx_create.restype = vp
+        L.hx_mixctx_create.argtypes = [i, i, i]
+        L.hx_mixctx_apply.argtypes = [vp, dp, i, i, dp]
+        L.hx_mixctx_destroy.argtypes = [vp]
+        L.hx_mixctx_destroy.restype = None
         L.hx_cl2corr.argtypes = [i, i, dp, dp]
         L.hx_corr2cl.argtypes = [i, i, dp, dp]
         L.hx_ang2pix_ring.argtypes = [i, C.c_int64, dp, dp, dp]

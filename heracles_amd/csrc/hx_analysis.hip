@@ -94,10 +94,15 @@ __device__ inline void ring_modes_ns(const PlanDev &P, const double2 *__restrict
 template <int SPIN>
 __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double2 *__restrict__ Y, int ncomp, int ng,
                                                          int ncol, int m0, const double *__restrict__ rw,
+                                                         const LegTask *__restrict__ tasks, const MTasks *__restrict__ of_m,
                                                          double *__restrict__ F)
 {
     constexpr int NOP = LegCfg<SPIN>::NOP;
     const int m = m0 + blockIdx.x;
+    // ring blocks in front of the first task of this m are pruned (m beyond what their rings resolve): their rows of F are
+    // never read
+    const MTasks mt = of_m[m];
+    if (mt.count == 0 || (int)blockIdx.y < tasks[mt.first].rb0) return;
     const int rp = blockIdx.y * 32 + (threadIdx.x >> 3);
     const int slot = threadIdx.x & 7;
     if (rp >= P.nrp_pad) return;
@@ -635,6 +640,17 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     //     [HB / 2 slot pairs of MFMAs; in their shadow ONLY LDS traffic: the stores of those HB values, the reads of the next
     //      HB coefficients and of the A operands]                                                 (32 / HB times).
     // cq = coefficients of the next 16 recursion steps, whatever set / block they belong to. ----
+#if HX_PIPE_ABL & 8
+    // cycle accounting (diagnostic build): [0] prologue, [1] MFMA || live recursion, [2] MFMA || dead / no recursion,
+    // [3] live recursion alone, [4] dead recursion alone, [5] flush up to the first barrier, [6] reduction + second barrier;
+    // [8 + i] = number of intervals of kind i
+    unsigned long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long cyc_v = 0, cyc_m = 0, tin = 0;  // inside MFMA || live-recursion stages: vector blocks, matrix blocks
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#define HX_STAMP(i) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); cyc[i] += tn_ - tlast; cnt[i] += 1; tlast = tn_; } while (0)
+#else
+#define HX_STAMP(i) do { } while (0)
+#endif
     constexpr int PF = 2, HB = 8, PPB = HB / 2, NHB = LBLK / HB;  // (16 steps per block need 96 more registers than the wave has)
     double2 cq[HB];
     auto stage = [&](auto SMM, auto MFF, auto RMM, const double2 *cf_rec, const double2 *cf_next) __attribute__((always_inline)) {
@@ -657,6 +673,9 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
                 for (int j = 0; j < PF; ++j) aq[j] = a_fetch(h * PPB + j);  // lands while the vector block runs
             }
             // ---- vector block: chain-steps HB h .. HB h + HB - 1 (spin 0: HB / 2 steps of both parity chains) ----
+#if HX_PIPE_ABL & 16
+            if (MF && RM >= 2) tin = __builtin_amdgcn_s_memtime();
+#endif
             double cur[HB];
             if (RM) {
 #pragma unroll
@@ -666,6 +685,9 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+#if HX_PIPE_ABL & 16
+            if (MF && RM >= 2) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); cyc_v += tn_ - tin; tin = tn_; }
+#endif
             // ---- matrix block ----
 #pragma unroll
             for (int j = 0; j < PPB; ++j) {
@@ -678,11 +700,19 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
                     __builtin_amdgcn_sched_barrier(0);
                     if (pos == 0) {
                         if (RM >= 2) *reinterpret_cast<double2 *>(tr + pipe_tile_idx(lane, sp)) = make_double2(cur[2 * j], cur[2 * j + 1]);
-                    } else {
-                        // coefficients of the next vector block: second half of this recursion, or the first half of the next stage's
+                    }
+                    // coefficients of the next vector block (second ... fourth quarter of this recursion, or the first quarter of
+                    // the next stage's): all HB reads in the shadows of the FIRST MFMAs of the matrix block, so that they have
+                    // landed when the block ends
+                    {
+                        constexpr int NQ = 2 * PPB;                    // MFMA shadows of the matrix block
+                        constexpr int PER = (HB + NQ / 2 - 1) / (NQ / 2);  // reads per shadow, all within the first half
                         const double2 *src = h + 1 < NHB ? cf_rec + HB * (h + 1) : cf_next;
-                        cq[2 * j] = src[chalf * LBLK + 2 * j];
-                        cq[2 * j + 1] = src[chalf * LBLK + 2 * j + 1];
+#pragma unroll
+                        for (int u = 0; u < PER; ++u) {
+                            const int k = (2 * j + pos) * PER + u;
+                            if (k < HB) cq[k] = src[chalf * LBLK + k];
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (MF) {
@@ -694,6 +724,9 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#if HX_PIPE_ABL & 16
+            if (MF && RM >= 2) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); cyc_m += tn_ - tin; tin = tn_; }
+#endif
         }
     };
     // 0: nothing to do, 1: all chains of the set dead, 2: mixed, 3: all live
@@ -727,16 +760,6 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         }
     };
 
-#if HX_PIPE_ABL & 8
-    // cycle accounting (diagnostic build): [0] prologue, [1] MFMA || live recursion, [2] MFMA || dead / no recursion,
-    // [3] live recursion alone, [4] dead recursion alone, [5] flush up to the first barrier, [6] reduction + second barrier;
-    // [8 + i] = number of intervals of kind i
-    unsigned long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tlast = __builtin_amdgcn_s_memtime();
-#define HX_STAMP(i) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); cyc[i] += tn_ - tlast; cnt[i] += 1; tlast = tn_; } while (0)
-#else
-#define HX_STAMP(i) do { } while (0)
-#endif
     auto kind_of = [](bool mf, int rm) __attribute__((always_inline)) { return mf ? (rm >= 2 ? 1 : 2) : (rm >= 2 ? 3 : 4); };
     (void)kind_of;
     HX_STAMP(0);
@@ -854,6 +877,10 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
             atomicAdd(&A.counters[i], cyc[i]);
             atomicAdd(&A.counters[8 + i], cnt[i]);
         }
+    if (lane == 0 && A.counters) {
+        atomicAdd(&A.counters[16], cyc_v);
+        atomicAdd(&A.counters[17], cyc_m);
+    }
 #endif
 }
 
@@ -1268,7 +1295,8 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
     {
         ProfScope ps("fourier_combine");
         dim3 grid(m1 - m0, pl->nrp_pad / 32);
-        hipLaunchKernelGGL(k_fourier_combine<SPIN>, grid, dim3(256), 0, st, P, pl->Y.as<double2>(), nb, ng, ncol, m0, d_rw, pl->F.as<double>());
+        hipLaunchKernelGGL(k_fourier_combine<SPIN>, grid, dim3(256), 0, st, P, pl->Y.as<double2>(), nb, ng, ncol, m0, d_rw,
+                           ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(), pl->F.as<double>());
     }
     if (t1 > t0) {
         ProfScope ps("legendre_analysis");
@@ -1279,8 +1307,8 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         A.ablate = 0;
         A.counters = nullptr;
 #if defined(HX_DIAG) && (HX_PIPE_ABL & 8)
-        HX_TRY(pl->d_dbg.alloc(128));
-        HX_HIP(hipMemsetAsync(pl->d_dbg.p, 0, 128, st));
+        HX_TRY(pl->d_dbg.alloc(144));
+        HX_HIP(hipMemsetAsync(pl->d_dbg.p, 0, 144, st));
         A.counters = pl->d_dbg.as<unsigned long long>();
 #endif
 #ifdef HX_DIAG  // diagnostic builds only (tools/): phases of the first kernel can be switched off, results are then wrong
@@ -1312,9 +1340,10 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
             return fail(HX_ERR_ARG, "legendre analysis: no kernel for %d groups + %d blocks", sh.ng, sh.nbx);
 #if defined(HX_DIAG) && (HX_PIPE_ABL & 8)
         if (!sh.quad) {
-            unsigned long long hc[16];
+            unsigned long long hc[18];
             HX_HIP(hipStreamSynchronize(st));
-            HX_HIP(hipMemcpy(hc, pl->d_dbg.p, 128, hipMemcpyDeviceToHost));
+            HX_HIP(hipMemcpy(hc, pl->d_dbg.p, 144, hipMemcpyDeviceToHost));
+            if (hc[9]) fprintf(stderr, "[hx] pipe spin %d: per mfma||rec stage: vector blocks %.1f cycles, matrix blocks %.1f\n", SPIN, (double)hc[16] / hc[9], (double)hc[17] / hc[9]);
             const char *nm[8] = {"prologue", "mfma||rec", "mfma||dead", "rec alone", "dead alone", "flush->bar1", "bar2 wait", "reduce"};
             double tot = 0;
             for (int i = 0; i < 8; ++i) tot += (double)hc[i];

@@ -28,6 +28,7 @@ constexpr double kTwoThird = 2.0 / 3.0;
 // healpix_cxx fmodulo(v, 4.0)
 __device__ inline double fmodulo4(double v)
 {
+#pragma clang fp contract(off)
     if (v >= 0.0) return (v < 4.0) ? v : fmod(v, 4.0);
     double t = fmod(v, 4.0) + 4.0;
     return (t == 4.0) ? 0.0 : t;
@@ -35,6 +36,9 @@ __device__ inline double fmodulo4(double v)
 
 __device__ inline long long ang2pix_ring_one(long long nside, double lon_deg, double lat_deg)
 {
+    // every operation rounds on its own, as in numpy / healpix_cxx built without FMA contraction: a fused
+    // pi/2 - lat * (pi/180) gives theta = -6e-17 instead of 0 for lat = 90
+#pragma clang fp contract(off)
     // healpy lonlat2thetaphi: theta = pi/2 - radians(lat), phi = radians(lon)
     double theta = kHalfPi - lat_deg * kDeg2Rad;
     double phi = lon_deg * kDeg2Rad;
@@ -72,6 +76,7 @@ __device__ inline long long ang2pix_ring_one(long long nside, double lon_deg, do
 // in *nbad; the entry points return HX_ERR_ARG before anything is scattered.
 __device__ inline bool lonlat_valid(double lon_deg, double lat_deg)
 {
+#pragma clang fp contract(off)
     const double theta = kHalfPi - lat_deg * kDeg2Rad;
     return isfinite(lon_deg) && theta >= 0.0 && theta <= 3.14159265358979323846 + 1e-5;
 }

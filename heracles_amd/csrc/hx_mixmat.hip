@@ -201,6 +201,14 @@ int launch_gauss_legendre(int n, double *d_x, double *d_w)
     return HX_OK;
 }
 
+template <class T>
+static int upload_vec(DevBuf &b, const std::vector<T> &v)
+{
+    HX_TRY(b.alloc(sizeof(T) * (v.empty() ? 1 : v.size())));
+    if (!v.empty()) HX_HIP(hipMemcpy(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    return HX_OK;
+}
+
 struct GLCache {
     int n = 0;
     DevBuf x, w;
@@ -216,52 +224,101 @@ static int gl_nodes_device(int n, GLCache &c)
     return HX_OK;
 }
 
+// Everything of a mixing-matrix build that does not depend on the mask: Gauss-Legendre nodes, the Wigner-d tables
+// T_ab[l][k] = d^l_ab(x_k) of the products asked for, the tile list and the column scaling (2 l2 + 1) / 2.  One context
+// serves any number of masks: per mask only the node weights s_k = w_k xi(x_k) and one GEMM per product remain
+// (the reference calls convolvecl once per (field pair, bin pair), heracles/twopoint.py:354-397, rebuilding all of it).
+struct MixCtx {
+    int l1max = -1, l2max = -1, l3max = -1, L = 0, n = 0, kpad = 0, rows_pad = 0;
+    GLCache gl;
+    DevBuf s, d_tiles, d_cs;
+    size_t ntiles = 0;
+    DevBuf T[4];            // (0,0), (2,0), (2,2), (2,-2)
+    bool have[4] = {false, false, false, false};
+};
+static const int kAB[4][2] = {{0, 0}, {2, 0}, {2, 2}, {2, -2}};
+
+static int mix_ctx_init(MixCtx &c, int l1max, int l2max, int l3max)
+{
+    hipStream_t st = rt().stream;
+    c.l1max = l1max; c.l2max = l2max; c.l3max = l3max;
+    c.L = std::max(l1max, l2max);
+    c.n = (l1max + l2max + l3max) / 2 + 1;
+    c.kpad = (c.n + GK - 1) / GK * GK;
+    c.rows_pad = (c.L + 1 + GB - 1) / GB * GB;
+    HX_TRY(gl_nodes_device(c.n, c.gl));
+    HX_TRY(c.s.alloc(sizeof(double) * c.kpad));
+    std::vector<int2> tiles;
+    const int nb = c.rows_pad / GB;
+    for (int i = 0; i < nb; ++i)
+        for (int j = i; j < nb; ++j) tiles.push_back(make_int2(i, j));
+    c.ntiles = tiles.size();
+    HX_TRY(upload_vec(c.d_tiles, tiles));
+    std::vector<double> cs(c.rows_pad, 0.0);
+    for (int l = 0; l <= c.L; ++l) cs[l] = (2.0 * l + 1.0) / 2.0;
+    HX_TRY(upload_vec(c.d_cs, cs));
+    (void)st;
+    return HX_OK;
+}
+
+static int mix_ctx_table(MixCtx &c, int t)
+{
+    if (c.have[t]) return HX_OK;
+    hipStream_t st = rt().stream;
+    std::vector<double4> coef;
+    wigner_coefs(c.L, kAB[t][0], kAB[t][1], coef);
+    DevBuf d_coef;
+    HX_TRY(upload_vec(d_coef, coef));
+    HX_TRY(c.T[t].alloc(sizeof(double) * (size_t)c.rows_pad * c.kpad));
+    HX_HIP(hipMemsetAsync(c.T[t].p, 0, sizeof(double) * (size_t)c.rows_pad * c.kpad, st));
+    {
+        ProfScope ps("wigner_tables");
+        hipLaunchKernelGGL(k_wigner_table, dim3((c.n + 63) / 64), dim3(64), 0, st, c.L, kAB[t][0], kAB[t][1], c.n,
+                           c.gl.x.as<double>(), d_coef.as<double4>(), c.T[t].as<double>(), (long long)c.kpad, 1LL);
+    }
+    HX_HIP(hipStreamSynchronize(st));  // d_coef dies with this scope
+    c.have[t] = true;
+    return HX_OK;
+}
+
+// node weights of one mask spectrum (device, l3max + 1 values)
+static int mix_ctx_mask(MixCtx &c, const double *d_cl)
+{
+    hipStream_t st = rt().stream;
+    HX_HIP(hipMemsetAsync(c.s.p, 0, sizeof(double) * c.kpad, st));
+    hipLaunchKernelGGL(k_weight_xi, dim3((c.n + 255) / 256), dim3(256), 0, st, c.l3max, c.n, c.gl.x.as<double>(), c.gl.w.as<double>(),
+                       d_cl, c.s.as<double>());
+    HX_HIP(hipGetLastError());
+    return HX_OK;
+}
+
+// G^{(ab)} of the current mask into d_out (device, (l1max + 1) x (l2max + 1), ld = l2max + 1)
+static int mix_ctx_product(MixCtx &c, int t, double *d_out)
+{
+    HX_TRY(mix_ctx_table(c, t));
+    ProfScope ps("mixmat_gemm");
+    hipLaunchKernelGGL(k_mixmat_gemm, dim3((unsigned)c.ntiles), dim3(256), 0, rt().stream, c.T[t].as<double>(), c.kpad,
+                       c.s.as<double>(), c.d_tiles.as<int2>(), c.l1max + 1, c.l2max + 1, c.d_cs.as<double>(), d_out,
+                       (long long)(c.l2max + 1));
+    HX_HIP(hipGetLastError());
+    return HX_OK;
+}
+
 // Build G^{(ab)} for all requested (a,b) into out matrices (device), (n1 x n2) each, ld = n2.
 static int mixmat_core(const double *d_cl, int l1max, int l2max, int l3max, int nprod,
                        const int (*ab)[2], double *const *d_out)
 {
-    hipStream_t st = rt().stream;
-    const int L = std::max(l1max, l2max);
-    const int n = (l1max + l2max + l3max) / 2 + 1;
-    const int kpad = (n + GK - 1) / GK * GK;
-    const int rows_pad = (L + 1 + GB - 1) / GB * GB;
-    static thread_local GLCache gl;
-    HX_TRY(gl_nodes_device(n, gl));
-    DevBuf s, T, d_coef, d_tiles, d_cs;
-    HX_TRY(s.alloc(sizeof(double) * kpad));
-    HX_HIP(hipMemsetAsync(s.p, 0, sizeof(double) * kpad, st));
-    hipLaunchKernelGGL(k_weight_xi, dim3((n + 255) / 256), dim3(256), 0, st, l3max, n, gl.x.as<double>(), gl.w.as<double>(), d_cl, s.as<double>());
-    HX_TRY(T.alloc(sizeof(double) * (size_t)rows_pad * kpad));
-    std::vector<int2> tiles;
-    const int nb = rows_pad / GB;
-    for (int i = 0; i < nb; ++i)
-        for (int j = i; j < nb; ++j) tiles.push_back(make_int2(i, j));
-    HX_TRY(d_tiles.alloc(sizeof(int2) * tiles.size()));
-    HX_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice, st));
-    std::vector<double> cs(rows_pad, 0.0);
-    for (int l = 0; l <= L; ++l) cs[l] = (2.0 * l + 1.0) / 2.0;
-    HX_TRY(d_cs.alloc(sizeof(double) * rows_pad));
-    HX_HIP(hipMemcpyAsync(d_cs.p, cs.data(), sizeof(double) * rows_pad, hipMemcpyHostToDevice, st));
-    HX_TRY(d_coef.alloc(sizeof(double4) * (L + 1)));
-    std::vector<double4> coef;
+    MixCtx c;
+    HX_TRY(mix_ctx_init(c, l1max, l2max, l3max));
+    HX_TRY(mix_ctx_mask(c, d_cl));
     for (int p = 0; p < nprod; ++p) {
-        wigner_coefs(L, ab[p][0], ab[p][1], coef);
-        HX_HIP(hipMemcpyAsync(d_coef.p, coef.data(), sizeof(double4) * (L + 1), hipMemcpyHostToDevice, st));
-        HX_HIP(hipMemsetAsync(T.p, 0, sizeof(double) * (size_t)rows_pad * kpad, st));
-        {
-            ProfScope ps("wigner_tables");
-            hipLaunchKernelGGL(k_wigner_table, dim3((n + 63) / 64), dim3(64), 0, st, L, ab[p][0], ab[p][1], n,
-                               gl.x.as<double>(), d_coef.as<double4>(), T.as<double>(), (long long)kpad, 1LL);
-        }
-        {
-            ProfScope ps("mixmat_gemm");
-            hipLaunchKernelGGL(k_mixmat_gemm, dim3((unsigned)tiles.size()), dim3(256), 0, st, T.as<double>(), kpad,
-                               s.as<double>(), d_tiles.as<int2>(), l1max + 1, l2max + 1, d_cs.as<double>(), d_out[p],
-                               (long long)(l2max + 1));
-        }
-        HX_HIP(hipStreamSynchronize(st));  // coef (host vector) is reused next iteration
+        int t = -1;
+        for (int k = 0; k < 4; ++k)
+            if (kAB[k][0] == ab[p][0] && kAB[k][1] == ab[p][1]) t = k;
+        if (t < 0) return fail(HX_ERR_UNSUPPORTED, "mixmat: product (%d,%d) not supported", ab[p][0], ab[p][1]);
+        HX_TRY(mix_ctx_product(c, t, d_out[p]));
     }
-    HX_HIP(hipGetLastError());
+    HX_HIP(hipStreamSynchronize(rt().stream));  // the context (tables, weights) dies with this scope
     return HX_OK;
 }
 
@@ -368,6 +425,116 @@ extern "C" int hx_mixmat_eb(const double *cl, int ncl, int l1max, int l2max, int
     hipLaunchKernelGGL(k_eb_combine, dim3(1024), dim3(256), 0, rt().stream, (long long)sz, vo.as<double>(),
                        vo.as<double>() + sz, vo.as<double>() + 2 * sz);
     HX_HIP(hipGetLastError());
+    HX_TRY(vo.finish());
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    return HX_OK;
+}
+
+// Mixing matrices of nmask mask spectra for one (l1max, l2max, l3max): nodes, Wigner-d tables and tile list are built once,
+// then every mask costs its node weights and one GEMM per product.  Replaces the serial loop of convolvecl calls in
+// heracles.twopoint.mixing_matrices (heracles/twopoint.py:354-397).
+//   cls   [nmask][ncl] (host or device), zero-padded / truncated to l3max + 1 like hx_mixmat
+//   kinds [nmask] bit mask: 1 spin (0,0) -> out00[k], 2 spin (0,2) / (2,0) -> out02[k], 4 spin (2,2) -> outeb[k] (3 matrices)
+//   out*  [nmask] pointers (host or device; entries of kinds not asked for are ignored and may be NULL)
+extern "C" int hx_mixmat_batch(int nmask, const double *cls, int ncl, int l1max, int l2max, int l3max, const int *kinds,
+                               double *const *out00, double *const *out02, double *const *outeb)
+{
+    HX_TRY(ensure_ready());
+    if (nmask < 0 || (nmask > 0 && (!cls || !kinds)) || ncl < 1 || l1max < 0 || l2max < 0 || l3max < 0)
+        return fail(HX_ERR_ARG, "hx_mixmat_batch: bad argument");
+    if (nmask == 0) return HX_OK;
+    for (int k = 0; k < nmask; ++k)
+        if ((kinds[k] & ~7) || ((kinds[k] & 1) && (!out00 || !out00[k])) || ((kinds[k] & 2) && (!out02 || !out02[k])) ||
+            ((kinds[k] & 4) && (!outeb || !outeb[k])))
+            return fail(HX_ERR_ARG, "hx_mixmat_batch: mask %d: kinds=%d without an output buffer", k, kinds[k]);
+    const size_t sz = (size_t)(l1max + 1) * (l2max + 1);
+    MixCtx c;
+    HX_TRY(mix_ctx_init(c, l1max, l2max, l3max));
+    const bool cls_dev = is_device_ptr(cls);
+    DevBuf d_cl;
+    for (int k = 0; k < nmask; ++k) {
+        if (!kinds[k]) continue;
+        HX_TRY(stage_cl(cls + (size_t)k * ncl, ncl, l3max, d_cl));
+        (void)cls_dev;
+        HX_TRY(mix_ctx_mask(c, d_cl.as<double>()));
+        if (kinds[k] & 1) {
+            OutView vo;
+            HX_TRY(vo.bind(out00[k], sizeof(double) * sz));
+            HX_TRY(mix_ctx_product(c, 0, vo.as<double>()));
+            HX_TRY(vo.finish());
+            HX_HIP(hipStreamSynchronize(rt().stream));
+        }
+        if (kinds[k] & 2) {
+            OutView vo;
+            HX_TRY(vo.bind(out02[k], sizeof(double) * sz));
+            HX_TRY(mix_ctx_product(c, 1, vo.as<double>()));
+            HX_TRY(vo.finish());
+            HX_HIP(hipStreamSynchronize(rt().stream));
+        }
+        if (kinds[k] & 4) {
+            OutView vo;
+            HX_TRY(vo.bind(outeb[k], sizeof(double) * 3 * sz));
+            HX_TRY(mix_ctx_product(c, 2, vo.as<double>()));
+            HX_TRY(mix_ctx_product(c, 3, vo.as<double>() + 2 * sz));
+            hipLaunchKernelGGL(k_eb_combine, dim3(1024), dim3(256), 0, rt().stream, (long long)sz, vo.as<double>(),
+                               vo.as<double>() + sz, vo.as<double>() + 2 * sz);
+            HX_HIP(hipGetLastError());
+            HX_TRY(vo.finish());
+            HX_HIP(hipStreamSynchronize(rt().stream));
+        }
+    }
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    return HX_OK;
+}
+
+// ---- the same as an object: tables built once, masks streamed through (the outputs of a 13-bin job do not fit in memory
+// at once; the reference's `out` mapping may write each matrix to disk as it arrives, heracles/twopoint.py:393-397) ----
+struct hx_mixctx {
+    hx::MixCtx c;
+};
+
+extern "C" hx_mixctx *hx_mixctx_create(int l1max, int l2max, int l3max)
+{
+    if (ensure_ready() != HX_OK) return nullptr;
+    if (l1max < 0 || l2max < 0 || l3max < 0) {
+        set_error("hx_mixctx_create: bad argument");
+        return nullptr;
+    }
+    hx_mixctx *x = new hx_mixctx;
+    if (mix_ctx_init(x->c, l1max, l2max, l3max) != HX_OK || hipStreamSynchronize(rt().stream) != hipSuccess) {
+        delete x;
+        return nullptr;
+    }
+    return x;
+}
+
+extern "C" void hx_mixctx_destroy(hx_mixctx *x)
+{
+    if (!x) return;
+    if (rt().ready) (void)hipStreamSynchronize(rt().stream);
+    delete x;
+}
+
+// kind 1: spin (0,0) -> out (l1max+1, l2max+1); 2: spin (0,2)/(2,0) -> the same shape; 4: spin (2,2) -> out (3, l1max+1, l2max+1)
+extern "C" int hx_mixctx_apply(hx_mixctx *x, const double *cl, int ncl, int kind, double *out)
+{
+    HX_TRY(ensure_ready());
+    if (!x || !cl || !out || ncl < 1 || (kind != 1 && kind != 2 && kind != 4)) return fail(HX_ERR_ARG, "hx_mixctx_apply: bad argument");
+    MixCtx &c = x->c;
+    const size_t sz = (size_t)(c.l1max + 1) * (c.l2max + 1);
+    DevBuf d_cl;
+    HX_TRY(stage_cl(cl, ncl, c.l3max, d_cl));
+    HX_TRY(mix_ctx_mask(c, d_cl.as<double>()));
+    OutView vo;
+    HX_TRY(vo.bind(out, sizeof(double) * sz * (kind == 4 ? 3 : 1)));
+    if (kind == 4) {
+        HX_TRY(mix_ctx_product(c, 2, vo.as<double>()));
+        HX_TRY(mix_ctx_product(c, 3, vo.as<double>() + 2 * sz));
+        hipLaunchKernelGGL(k_eb_combine, dim3(1024), dim3(256), 0, rt().stream, (long long)sz, vo.as<double>(),
+                           vo.as<double>() + sz, vo.as<double>() + 2 * sz);
+        HX_HIP(hipGetLastError());
+    } else
+        HX_TRY(mix_ctx_product(c, kind == 1 ? 0 : 1, vo.as<double>()));
     HX_TRY(vo.finish());
     HX_HIP(hipStreamSynchronize(rt().stream));
     return HX_OK;

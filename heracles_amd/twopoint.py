@@ -96,32 +96,41 @@ def _pixwin_for(md, i, s, lmax, pixwin):
     return pw0 if s == 0 else pw2
 
 
+def _bias_profile(shape, md, bias, pixwin):
+    """The additive term of one spectrum block as an array of the block's shape: `bias` from l = max|spin| on (below
+    that the harmonic space of the field is empty), on the EE and BB diagonal only for a spin-2 x spin-2 block, and
+    divided by the pixel window of every HEALPix side whose window was deconvolved (heracles/twopoint.py:126-165)."""
+    spins = (md.get("spin_1", 0), md.get("spin_2", 0))
+    first = max(abs(sp) for sp in spins)
+    nl = shape[-1]
+    profile = np.zeros(nl)
+    profile[first:] = bias
+    for side, sp in enumerate(spins, start=1):
+        window = _pixwin_for(md, side, sp, nl - 1, pixwin)
+        if window is not None:
+            profile[first:] /= window[first:]
+    term = np.zeros(shape)
+    if all(spins):
+        if tuple(shape[:2]) != (2, 2):
+            raise AssertionError("a spin-2 x spin-2 block must have shape (2, 2, ...)")
+        term[0, 0] = profile
+        term[1, 1] = profile
+    else:
+        term[...] = profile
+    return term
+
+
 def _debias_cl(cl, bias=None, md=None, *, inplace=False, pixwin=None):
     """Remove additive bias from a spectrum block (heracles/twopoint.py:104-170)."""
-    if md is None:
-        md = cl.dtype.metadata or {}
+    meta = (cl.dtype.metadata or {}) if md is None else md
+    target = cl
     if not inplace:
-        cl = cl.copy()
-        update_metadata(cl, **md)
-    if bias is None:
-        bias = md.get("bias")
-        if bias is None:
-            return cl
-    spin1, spin2 = md.get("spin_1", 0), md.get("spin_2", 0)
-    lmin = max(abs(spin1), abs(spin2))
-    lmax = cl.shape[-1] - 1
-    bl = np.zeros(cl.shape)
-    if spin1 != 0 and spin2 != 0:
-        assert cl.shape[:2] == (2, 2)
-        bl[[0, 1], [0, 1], ..., lmin:] = bias
-    else:
-        bl[..., lmin:] = bias
-    for i, s in (1, spin1), (2, spin2):
-        pw = _pixwin_for(md, i, s, lmax, pixwin)
-        if pw is not None:
-            bl[..., lmin:] /= pw[lmin:]
-    cl[:] -= bl
-    return cl
+        target = cl.copy()
+        update_metadata(target, **meta)
+    amount = meta.get("bias") if bias is None else bias
+    if amount is not None:
+        target[:] -= _bias_profile(target.shape, meta, amount, pixwin)
+    return target
 
 
 def debias_cls(cls, bias=None, *, inplace=False, pixwin=None):
@@ -293,43 +302,116 @@ class _NoProgress:
         return nullcontext()
 
 
-def mixing_matrices(fields, cls, *, l1max=None, l2max=None, l3max=None, bins=None, weights=None,
-                    out=None, progress=None):
-    """Mixing matrices for fields from mask spectra: heracles/twopoint.py:316-401."""
-    if out is None:
-        out = TocDict()
-    if progress is None:
-        progress = _NoProgress()
-    masks = {}
-    for key, field in fields.items():
+def mixing_requests(fields, cls):
+    """What heracles.twopoint.mixing_matrices computes, as a list ((f1, f2, i1, i2), mask-cl key, (spin1, spin2)) in the
+    order the reference produces it (heracles/twopoint.py:341-371): every field pair whose masks name a given mask
+    spectrum, each unordered (field, bin) combination once."""
+    users = {}
+    for name, field in fields.items():
         if field.mask is not None:
-            masks.setdefault(field.mask, {})[key] = field
-    done = set()
-    current, total = 0, len(cls)
-    for (k1, k2, i1, i2), cl in cls.items():
-        current += 1
-        progress.update(current, total)
-        try:
-            fields1, fields2 = masks[k1], masks[k2]
-        except KeyError:
+            users.setdefault(field.mask, []).append(name)
+    taken, todo = set(), []
+    for ck in cls:
+        m1, m2, i1, i2 = ck
+        if m1 not in users or m2 not in users:
             continue
-        for f1, f2 in product(fields1, fields2):
-            if (f1, f2, i1, i2) in done or (f2, f1, i2, i1) in done:
+        for f1, f2 in product(users[m1], users[m2]):
+            if (f1, f2, i1, i2) in taken or (f2, f1, i2, i1) in taken:
                 continue
-            done.add((f1, f2, i1, i2))
-            with progress.task(f"({f1}, {f2}, {i1}, {i2})"):
-                spin1, spin2 = fields1[f1].spin, fields2[f2].spin
-                fn = mixmat if (spin1 == 0 or spin2 == 0) else mixmat_eb
-                mm = fn(np.asarray(cl), l1max=l1max, l2max=l2max, l3max=l3max, spin=(spin1, spin2))
-                ell = np.arange(mm.shape[-2])
-                mm = Result(mm, spin=(spin1, spin2), ell=ell, axis=-2)
-                if bins is not None:
-                    from .core import HAVE_HERACLES
+            taken.add((f1, f2, i1, i2))
+            todo.append(((f1, f2, i1, i2), ck, (fields[f1].spin, fields[f2].spin)))
+    return todo
 
-                    if not HAVE_HERACLES:
-                        raise NotImplementedError("binning needs heracles.result.binned")
-                    from heracles.result import binned
 
-                    mm = binned(mm, bins, weights)
-                out[f1, f2, i1, i2] = mm
+class MixmatContext:
+    """Mask-independent part of a mixing-matrix build (Gauss-Legendre nodes, Wigner-d tables, GEMM tiles) for one
+    (l1max, l2max, l3max): built once on the GPU, then every mask spectrum costs its node weights and one GEMM per
+    product (hx_mixctx_*)."""
+
+    KIND = {"00": 1, "02": 2, "22": 4}
+
+    def __init__(self, l1max, l2max, l3max):
+        _lib.ensure_init()
+        self.l1max, self.l2max, self.l3max = int(l1max), int(l2max), int(l3max)
+        self._h = _lib.load().hx_mixctx_create(self.l1max, self.l2max, self.l3max)
+        if not self._h:
+            raise _lib.HxError(-1, _lib.load().hx_last_error().decode(errors="replace"))
+
+    def __call__(self, cl, spin):
+        s1, s2 = (abs(int(v)) for v in spin)
+        if (s1, s2) == (0, 0):
+            kind = 1
+        elif sorted((s1, s2)) == [0, 2]:
+            kind = 2
+        elif (s1, s2) == (2, 2):
+            kind = 4
+        else:
+            raise NotImplementedError(f"mixing matrix for spin {tuple(spin)} not supported")
+        cl = np.ascontiguousarray(np.asarray(cl, dtype=np.float64))
+        shape = (self.l1max + 1, self.l2max + 1)
+        out = np.empty((3,) + shape if kind == 4 else shape)
+        _lib.check(_lib.load().hx_mixctx_apply(self._h, _lib.ptr(cl), cl.shape[0], kind, _lib.ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().hx_mixctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def mixing_matrices(fields, cls, *, l1max=None, l2max=None, l3max=None, bins=None, weights=None,
+                    out=None, progress=None, context=None):
+    """Mixing matrices for fields from mask spectra (heracles/twopoint.py:316-401): same keys, order, spin dispatch and
+    Result wrapping; the arithmetic goes through ONE MixmatContext per distinct (l1max, l2max, l3max), so the tables
+    are built once for the whole job instead of once per matrix.  `context` (a callable (cl, l1max, l2max, l3max, spin)
+    -> array) replaces the GPU path, e.g. to record the requests."""
+    out = TocDict() if out is None else out
+    progress = _NoProgress() if progress is None else progress
+    todo = mixing_requests(fields, cls)
+    pending = {}
+    for target, ck, spin in todo:
+        pending.setdefault(ck, []).append((target, spin))
+    contexts = {}
+
+    def compute(cl, spin):
+        _, a, b, c = _mm_args(cl, l1max, l2max, l3max)
+        if context is not None:
+            return context(cl, a, b, c, spin)
+        if (a, b, c) not in contexts:
+            contexts[a, b, c] = MixmatContext(a, b, c)
+        return contexts[a, b, c](cl, spin)
+
+    try:
+        for n, ck in enumerate(cls, start=1):
+            progress.update(n, len(cls))
+            for target, spin in pending.get(ck, ()):
+                with progress.task(f"({target[0]}, {target[1]}, {target[2]}, {target[3]})"):
+                    mm = compute(np.asarray(cls[ck]), spin)
+                    # second to last axis is the OUTPUT multipole (heracles/twopoint.py:391-393)
+                    mm = Result(mm, spin=spin, ell=np.arange(mm.shape[-2]), axis=-2)
+                    if bins is not None:
+                        from .core import HAVE_HERACLES
+
+                        if not HAVE_HERACLES:
+                            raise NotImplementedError("binning needs heracles.result.binned")
+                        from heracles.result import binned
+
+                        mm = binned(mm, bins, weights)
+                    out[target] = mm
+    finally:
+        for ctx in contexts.values():
+            ctx.close()
     return out

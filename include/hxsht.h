@@ -113,6 +113,19 @@ int hx_wigner_d_table(int lmax, int a, int b, int n, const double *x, double *ou
 int hx_mixmat(const double *cl, int ncl, int l1max, int l2max, int l3max, int s1, int s2,
               double *out);
 int hx_mixmat_eb(const double *cl, int ncl, int l1max, int l2max, int l3max, double *out);
+/* The loop of heracles/twopoint.py:354-397 (one convolvecl call per mask pair and spin combination) as one call:
+ * Gauss-Legendre nodes, Wigner-d tables and the GEMM tile list are built ONCE per (l1max, l2max, l3max); every mask then
+ * costs its node weights and one GEMM per product.
+ *   cls   [nmask][ncl] mask spectra; kinds [nmask] bit mask: 1 -> spin (0,0) into out00[k]; 2 -> spin (0,2)/(2,0) into
+ *   out02[k]; 4 -> spin (2,2) into outeb[k] (3 matrices as hx_mixmat_eb).  Output pointers host or device. */
+/* The same as an object, for jobs whose matrices do not fit in memory together: create once, stream masks through.
+ * kind 1: spin (0,0), 2: spin (0,2)/(2,0) -> out (l1max+1, l2max+1); 4: spin (2,2) -> out (3, l1max+1, l2max+1). */
+typedef struct hx_mixctx hx_mixctx;
+hx_mixctx *hx_mixctx_create(int l1max, int l2max, int l3max);
+int hx_mixctx_apply(hx_mixctx *ctx, const double *cl, int ncl, int kind, double *out);
+void hx_mixctx_destroy(hx_mixctx *ctx);
+int hx_mixmat_batch(int nmask, const double *cls, int ncl, int l1max, int l2max, int l3max, const int *kinds,
+                    double *const *out00, double *const *out02, double *const *outeb);
 
 /* Replaces heracles.transforms._cl2corr / _corr2cl (heracles/transforms.py:115-204) for
  * nspec spectra at once: cls [nspec][lmax+1][4] <-> corrs [nspec][lmax+1][4].          */

@@ -138,3 +138,46 @@ def test_dict_transforms_and_naturalspice_golden(golden):
         for k in d:
             ref = golden[f"ns/{tag}/{key_str(k)}"]
             np.testing.assert_allclose(res[k].array, ref, rtol=1e-6, atol=1e-9 * np.abs(ref).max())
+
+
+def test_mixing_matrices_batched_context(oracle):
+    """The driver through ONE MixmatContext per (l1max, l2max, l3max): every matrix equals the single-call kernels and
+    the 3j oracle; hx_mixmat_batch (several masks, one call) gives the same."""
+    import ctypes
+    import types
+
+    import heracles_amd as hx
+    from heracles_amd import _lib, twopoint as tp
+
+    L = 24
+    rng = np.random.default_rng(12)
+    cls = {("V", "V", 0, 0): rng.uniform(0.1, 1.0, L + 1) / (1.0 + np.arange(L + 1)) ** 2,
+           ("V", "W", 0, 1): rng.uniform(0.1, 1.0, L + 1) / (1.0 + np.arange(L + 1)),
+           ("W", "W", 1, 1): rng.uniform(0.1, 1.0, L + 1)}
+    flds = {"P": types.SimpleNamespace(mask="V", spin=0), "G": types.SimpleNamespace(mask="W", spin=2),
+            "K": types.SimpleNamespace(mask="W", spin=0)}
+    mms = hx.mixing_matrices(flds, cls, l1max=20, l2max=22, l3max=L)
+    assert list(mms) == [t for t, _, _ in tp.mixing_requests(flds, cls)] and len(mms) == 6
+    for (f1, f2, i1, i2), res in mms.items():
+        spin = (flds[f1].spin, flds[f2].spin)
+        cl = cls[flds[f1].mask, flds[f2].mask, i1, i2]
+        ref = (oracle.mixmat_eb if all(spin) else oracle.mixmat)(cl, l1max=20, l2max=22, l3max=L, **({} if all(spin) else {"spin": spin}))
+        np.testing.assert_allclose(np.asarray(res.array), ref, rtol=1e-11, atol=1e-13 * np.abs(ref).max())
+        single = (hx.mixmat_eb if all(spin) else hx.mixmat)(cl, l1max=20, l2max=22, l3max=L, spin=spin)
+        np.testing.assert_array_equal(np.asarray(res.array), single)
+    # the one-call batch over three masks
+    stack = np.ascontiguousarray(np.stack(list(cls.values())))
+    n = 3
+    o00 = [np.empty((21, 23)) for _ in range(n)]
+    o02 = [np.empty((21, 23)) for _ in range(n)]
+    oeb = [np.empty((3, 21, 23)) for _ in range(n)]
+    kinds = (ctypes.c_int * n)(1 | 2 | 4, 2, 4)
+    arr = lambda bufs: (ctypes.c_void_p * n)(*[b.ctypes.data for b in bufs])  # noqa: E731
+    _lib.check(_lib.load().hx_mixmat_batch(n, _lib.ptr(stack), L + 1, 20, 22, L, kinds, arr(o00), arr(o02), arr(oeb)))
+    for k, cl in enumerate(cls.values()):
+        if kinds[k] & 1:
+            np.testing.assert_array_equal(o00[k], hx.mixmat(cl, l1max=20, l2max=22, l3max=L, spin=(0, 0)))
+        if kinds[k] & 2:
+            np.testing.assert_array_equal(o02[k], hx.mixmat(cl, l1max=20, l2max=22, l3max=L, spin=(2, 0)))
+        if kinds[k] & 4:
+            np.testing.assert_array_equal(oeb[k], hx.mixmat_eb(cl, l1max=20, l2max=22, l3max=L))

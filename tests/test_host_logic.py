@@ -140,28 +140,27 @@ def test_debias_healpix_pixwin_rule():
     np.testing.assert_array_equal(cls[3][0, 2:], -7.89 / pw0[2:])
 
 
-def test_mixing_matrices_driver_vs_reference(monkeypatch, golden):
+def test_mixing_matrices_driver_vs_reference(golden):
+    """Keys, order, spin dispatch and arguments of the reference's loop (golden: the call list its mocked convolvecl
+    functions saw, tests/test_twopoint.py:316-383) -- here the requests reach ONE context per (l1max, l2max, l3max)."""
     calls = []
 
-    def fake(name):
-        def f(cl, l1max=None, l2max=None, l3max=None, spin=None):
-            calls.append((name, tuple(spin), l1max, l2max, l3max))
-            n = len(cl)
-            return np.zeros((n, n)) if name == "mixmat" else np.zeros((3, n, n))
+    def recorder(cl, l1max, l2max, l3max, spin):
+        name = "mixmat" if 0 in spin else "mixmat_eb"
+        calls.append((name, tuple(spin), l1max, l2max, l3max))
+        n = len(cl)
+        return np.zeros((n, n)) if name == "mixmat" else np.zeros((3, n, n))
 
-        return f
-
-    monkeypatch.setattr(tp, "mixmat", fake("mixmat"))
-    monkeypatch.setattr(tp, "mixmat_eb", fake("mixmat_eb"))
     cl = np.arange(21.0)
     mm_cls = {("VIS", "VIS", 0, 1): cl, ("VIS", "WHT", 0, 1): cl, ("WHT", "VIS", 0, 1): cl,
               ("WHT", "WHT", 0, 1): cl, ("X", "Y", 0, 1): cl, ("WHT", "WHT", 1, 1): cl}
     flds = {"POS": types.SimpleNamespace(mask="VIS", spin=0), "SHE": types.SimpleNamespace(mask="WHT", spin=2),
             "POS2": types.SimpleNamespace(mask="VIS", spin=0), "NOMASK": types.SimpleNamespace(mask=None, spin=0)}
-    mms = tp.mixing_matrices(flds, mm_cls, l1max=10, l2max=12, l3max=20)
+    mms = tp.mixing_matrices(flds, mm_cls, l1max=10, l2max=12, l3max=20, context=recorder)
     assert [key_str(k) for k in mms] == list(golden["mm/keys"])
     assert [repr(c) for c in calls] == list(golden["mm/calls"])
     assert [repr(v.axis) for v in mms.values()] == list(golden["mm/axis"])
+    assert [key_str(t) for t, _, _ in tp.mixing_requests(flds, mm_cls)] == list(golden["mm/keys"])
 
 
 def test_core_helpers():

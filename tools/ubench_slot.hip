@@ -31,12 +31,12 @@ __global__ __launch_bounds__(256, 1) void k_slot(double *out, unsigned long long
 #pragma unroll
             for (int g = 0; g < (NBX > 0 ? NBX : 1); ++g) frx[sp][pos][g] = src[(lane * 41 + sp * 7 + pos + g) & 4095];
         }
-    double4_t acc[NG > 0 ? NG : 1][2];
-    double accx[NBX > 0 ? NBX : 1][2];
+    double4_t acc[NG > 0 ? NG : 1][4];
+    double accx[NBX > 0 ? NBX : 1][4];
 #pragma unroll
-    for (int g = 0; g < (NG > 0 ? NG : 1); ++g) acc[g][0] = acc[g][1] = (double4_t){0, 0, 0, 0};
+    for (int g = 0; g < (NG > 0 ? NG : 1); ++g) acc[g][0] = acc[g][1] = acc[g][2] = acc[g][3] = (double4_t){0, 0, 0, 0};
 #pragma unroll
-    for (int g = 0; g < (NBX > 0 ? NBX : 1); ++g) accx[g][0] = accx[g][1] = 0;
+    for (int g = 0; g < (NBX > 0 ? NBX : 1); ++g) accx[g][0] = accx[g][1] = accx[g][2] = accx[g][3] = 0;
     double vc = src[lane] * 1e-3, vp = src[lane + 64] * 1e-3, tq = 0.9, xx = 0.3 + 1e-3 * lane;
     const double *tm = &tileA[w][0];
     double *tr = &tileB[w][0];
@@ -58,12 +58,13 @@ __global__ __launch_bounds__(256, 1) void k_slot(double *out, unsigned long long
 #pragma unroll
             for (int pos = 0; pos < 2; ++pos) {
                 const double a = pos ? aq[sp].y : aq[sp].x;
-                if (NG > 0) acc[0][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[sp][pos][0], acc[0][pos], 0, 0, 0);
+                const int AI = (F & 128) ? pos + 2 * (sp & 1) : pos;
+                if (NG > 0) acc[0][AI] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[sp][pos][0], acc[0][AI], 0, 0, 0);
                 if (F & 64) {
 #pragma unroll
-                    for (int g = 1; g < NG; ++g) acc[g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[sp][pos][g], acc[g][pos], 0, 0, 0);
+                    for (int g = 1; g < NG; ++g) acc[g][AI] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[sp][pos][g], acc[g][AI], 0, 0, 0);
 #pragma unroll
-                    for (int g = 0; g < NBX; ++g) accx[g][pos] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[sp][pos][g], accx[g][pos], 0, 0, 0);
+                    for (int g = 0; g < NBX; ++g) accx[g][AI] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[sp][pos][g], accx[g][AI], 0, 0, 0);
                 }
                 if (!(F & 32)) __builtin_amdgcn_sched_barrier(0);
                 const double cur = vc;
@@ -77,9 +78,9 @@ __global__ __launch_bounds__(256, 1) void k_slot(double *out, unsigned long long
                 if (!(F & 32)) __builtin_amdgcn_sched_barrier(0);
                 if (!(F & 64)) {
 #pragma unroll
-                    for (int g = 1; g < NG; ++g) acc[g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[sp][pos][g], acc[g][pos], 0, 0, 0);
+                    for (int g = 1; g < NG; ++g) acc[g][AI] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[sp][pos][g], acc[g][AI], 0, 0, 0);
 #pragma unroll
-                    for (int g = 0; g < NBX; ++g) accx[g][pos] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[sp][pos][g], accx[g][pos], 0, 0, 0);
+                    for (int g = 0; g < NBX; ++g) accx[g][AI] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[sp][pos][g], accx[g][AI], 0, 0, 0);
                 }
                 if (!(F & 32)) __builtin_amdgcn_sched_barrier(0);
             }
@@ -90,9 +91,9 @@ __global__ __launch_bounds__(256, 1) void k_slot(double *out, unsigned long long
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     double r = vc + vp + tq;
 #pragma unroll
-    for (int g = 0; g < (NG > 0 ? NG : 1); ++g) r += acc[g][0][0] + acc[g][0][1] + acc[g][0][2] + acc[g][0][3] + acc[g][1][0] + acc[g][1][1] + acc[g][1][2] + acc[g][1][3];
+    for (int g = 0; g < (NG > 0 ? NG : 1); ++g) for (int q = 0; q < 4; ++q) r += acc[g][q][0] + acc[g][q][1] + acc[g][q][2] + acc[g][q][3];
 #pragma unroll
-    for (int g = 0; g < (NBX > 0 ? NBX : 1); ++g) r += accx[g][0] + accx[g][1];
+    for (int g = 0; g < (NBX > 0 ? NBX : 1); ++g) r += accx[g][0] + accx[g][1] + accx[g][2] + accx[g][3];
     out[blockIdx.x * 256 + threadIdx.x] = r + tr[lane];
     if (lane == 0) cyc[blockIdx.x * 4 + w] = t1 - t0;
 }
@@ -347,6 +348,10 @@ int main()
     CK(hipMemcpy(d_src, src.data(), sizeof(double) * 4096, hipMemcpyHostToDevice));
 #define R(NG, NBX, F, PF, L) if (run<NG, NBX, F, PF>(L, d_out, d_cyc, d_src, cus)) return 1
     R(1, 1, 0, 2, "MFMA only");
+    R(1, 1, 128, 2, "MFMA only, 4 accumulators");
+    R(1, 0, 128, 2, "MFMA only, 4 accumulators");
+    R(2, 0, 128, 2, "MFMA only, 4 accumulators");
+    R(1, 1, 64, 2, "MFMA only, quad right behind");
     R(1, 1, 1, 2, "+ A reads");
     R(1, 1, 3, 2, "+ coefficient reads");
     R(1, 1, 7, 2, "+ tile store");
