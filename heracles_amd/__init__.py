@@ -7,8 +7,9 @@ include/hxsht.h).  There is no CPU fallback.
 
 from . import _lib
 from ._lib import HxError, device_count, init, synchronize
-from .core import Result, TocDict, toc_match, update_metadata
+from .core import DeviceArray, Result, TocDict, toc_match, update_metadata
 from .discrete import HipDiscreteMapper, alm_resample
+from .jackknife import RegionAlms, jackknife_cls, region_alms
 from .mapper import HipHealpixMapper
 from .sht import Plan, get_plan
 from .transforms import cl2corr, corr2cl, gauss_legendre, wigner_d_table
@@ -28,5 +29,6 @@ __all__ = [
     "HipHealpixMapper", "HipDiscreteMapper", "alm_resample", "Plan", "get_plan", "HxError", "init", "device_count", "synchronize",
     "alm2cl", "alm2cl_pairs", "alm2lmax", "angular_power_spectra", "debias_cls",
     "mixing_matrices", "mixmat", "mixmat_eb", "cl2corr", "corr2cl", "gauss_legendre",
-    "wigner_d_table", "naturalspice", "Result", "TocDict", "toc_match", "update_metadata",
+    "wigner_d_table", "naturalspice", "Result", "TocDict", "toc_match", "update_metadata", "DeviceArray",
+    "jackknife_cls", "region_alms", "RegionAlms",
 ]

@@ -129,3 +129,29 @@ if HAVE_HERACLES:  # pragma: no cover
     toc_match = _toc_match  # noqa: F811
     update_metadata = _update_metadata  # noqa: F811
     Result = _Result  # noqa: F811
+
+
+class DeviceArray:
+    """A device-resident array (a contiguous torch CUDA tensor) dressed like the numpy arrays the two-point
+    drivers receive: ``shape`` and ``dtype`` (with the Heracles metadata dict attached, which a torch tensor
+    cannot carry).  ``angular_power_spectra`` hands its rows to the all-pairs kernel as device pointers."""
+
+    def __init__(self, tensor, metadata=None):
+        self.tensor = tensor
+        self.shape = tuple(tensor.shape)
+        kind = np.complex128 if tensor.is_complex() else np.float64
+        self.dtype = np.dtype(kind, metadata=dict(metadata or {}))
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def rows(self):
+        """1-D views, one per component."""
+        flat = self.tensor.reshape(-1, self.shape[-1])
+        return [flat[k] for k in range(flat.shape[0])]
+
+    def numpy(self):
+        out = self.tensor.cpu().numpy()
+        update_metadata(out, **(self.dtype.metadata or {}))
+        return out

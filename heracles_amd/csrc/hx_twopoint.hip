@@ -201,3 +201,83 @@ extern "C" int hx_alm_resample(int lmax_in, int lmax_out, int ncomp, const doubl
     return finish_call();
 }
 
+
+// ---- jackknife helpers (heracles/dices/jackknife.py:222-233, :253-263): delete-k alms and region maps in HBM ----------
+namespace hx {
+// out = full - sum_i subs[i]  (complex values as interleaved doubles; nsub <= 4)
+struct SubList {
+    const double2 *p[4];
+};
+__global__ __launch_bounds__(256) void k_alm_subtract(long long n, const double2 *__restrict__ full, int nsub, SubList subs,
+                                                      double2 *__restrict__ out)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long st = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += st) {
+        double2 v = full[i];
+        for (int k = 0; k < nsub; ++k) {
+            const double2 s = subs.p[k][i];
+            v.x -= s.x;
+            v.y -= s.y;
+        }
+        out[i] = v;
+    }
+}
+
+// out[c][p] = maps[c][p] if region[p] == k else 0  (region map as doubles, the type the reference compares with float(jk))
+__global__ __launch_bounds__(256) void k_region_maps(long long npix, int ncomp, const double *__restrict__ maps,
+                                                     const double *__restrict__ region, double k, double *__restrict__ out)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long st = (long long)gridDim.x * blockDim.x;
+    for (; i < npix; i += st) {
+        const bool in = region[i] == k;
+        for (int c = 0; c < ncomp; ++c) out[(long long)c * npix + i] = in ? maps[(long long)c * npix + i] : 0.0;
+    }
+}
+}  // namespace hx
+
+// out = full - sum of nsub arrays, n complex values each (host or device pointers; out may alias full)
+extern "C" int hx_alm_subtract(int64_t n, const double *full, int nsub, const double *const *subs, double *out)
+{
+    using namespace hx;
+    HX_TRY(ensure_ready());
+    if (n < 0 || nsub < 0 || nsub > 4 || (n > 0 && (!full || !out || (nsub > 0 && !subs))))
+        return fail(HX_ERR_ARG, "hx_alm_subtract: bad arguments (at most 4 arrays to subtract)");
+    if (n == 0) return HX_OK;
+    InView vf, vs[4];
+    OutView vo;
+    HX_TRY(vf.bind(full, sizeof(double2) * n));
+    SubList sl;
+    for (int k = 0; k < 4; ++k) sl.p[k] = nullptr;
+    for (int k = 0; k < nsub; ++k) {
+        if (!subs[k]) return fail(HX_ERR_ARG, "hx_alm_subtract: null array %d", k);
+        HX_TRY(vs[k].bind(subs[k], sizeof(double2) * n));
+        sl.p[k] = vs[k].as<double2>();
+    }
+    HX_TRY(vo.bind(out, sizeof(double2) * n));
+    hipLaunchKernelGGL(k_alm_subtract, dim3(4096), dim3(256), 0, rt().stream, (long long)n, vf.as<double2>(), nsub, sl, vo.as<double2>());
+    HX_HIP(hipGetLastError());
+    HX_TRY(vo.finish());
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    return HX_OK;
+}
+
+// maps restricted to jackknife region k: out[c][p] = maps[c][p] where region[p] == k, else 0
+extern "C" int hx_region_maps(int64_t npix, int ncomp, const double *maps, const double *region, double k, double *out)
+{
+    using namespace hx;
+    HX_TRY(ensure_ready());
+    if (npix < 0 || ncomp < 0 || (npix > 0 && ncomp > 0 && (!maps || !region || !out))) return fail(HX_ERR_ARG, "hx_region_maps: bad arguments");
+    if (npix == 0 || ncomp == 0) return HX_OK;
+    InView vm, vr;
+    OutView vo;
+    HX_TRY(vm.bind(maps, sizeof(double) * npix * ncomp));
+    HX_TRY(vr.bind(region, sizeof(double) * npix));
+    HX_TRY(vo.bind(out, sizeof(double) * npix * ncomp));
+    hipLaunchKernelGGL(k_region_maps, dim3(4096), dim3(256), 0, rt().stream, (long long)npix, ncomp, vm.as<double>(), vr.as<double>(), k, vo.as<double>());
+    HX_HIP(hipGetLastError());
+    HX_TRY(vo.finish());
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    return HX_OK;
+}

@@ -16,7 +16,7 @@ from itertools import combinations_with_replacement, product
 import numpy as np
 
 from . import _lib
-from .core import Result, TocDict, toc_match, update_metadata
+from .core import DeviceArray, Result, TocDict, toc_match, update_metadata
 
 logger = logging.getLogger(__name__)
 
@@ -94,6 +94,19 @@ def _pixwin_for(md, i, s, lmax, pixwin):
 
     pw0, pw2 = pixel_window(nside, lmax, pixwin)
     return pw0 if s == 0 else pw2
+
+
+def _auto_bias(md, both_spin2):
+    """Additive bias of an auto-spectrum from the catalogue statistics the field attached to its maps
+    (fsky * <mu^2> / density, halved per E/B component for a spin-2 field; heracles/twopoint.py:260-269);
+    None when any of the three is absent."""
+    try:
+        product_ = md["fsky"] * md["musq"] / md["dens"]
+    except (KeyError, TypeError):
+        return None
+    if md["fsky"] is None or md["musq"] is None or md["dens"] is None:
+        return None
+    return 0.5 * product_ if both_spin2 else product_
 
 
 def _bias_profile(shape, md, bias, pixwin):
@@ -194,9 +207,12 @@ def angular_power_spectra(alms, alms2=None, *, lmax=None, debias=True, bins=None
         comps, index, plist, owners = [], {}, [], []
 
         def comp_ids(arr, comps=comps, index=index):
-            a2 = np.ascontiguousarray(arr, dtype=np.complex128).reshape(-1, arr.shape[-1])
+            if isinstance(arr, DeviceArray):
+                a2 = arr.rows()  # device pointers: the alms never leave HBM
+            else:
+                a2 = np.ascontiguousarray(arr, dtype=np.complex128).reshape(-1, arr.shape[-1])
             ids = []
-            for row in range(a2.shape[0]):
+            for row in range(len(a2)):
                 key = (id(arr), row)
                 if key not in index:
                     index[key] = len(comps)
@@ -214,29 +230,20 @@ def angular_power_spectra(alms, alms2=None, *, lmax=None, debias=True, bins=None
         for n, start, na, nb in owners:
             key, alm1, alm2 = todo[n]
             results[n] = block[start : start + na * nb].reshape(*alm1.shape[:-1], *alm2.shape[:-1], lo + 1).copy()
-    # pass 3: metadata, bias, wrapping -- per pair, as the reference
+    # pass 3: metadata, shot-noise bias and wrapping of every block (heracles/twopoint.py:247-287)
     for (key, alm1, alm2), cl in zip(todo, results):
         k1, k2, i1, i2 = key
-        md1 = alm1.dtype.metadata or {}
-        md2 = alm2.dtype.metadata or {}
-        s1, s2 = md1.get("spin", None), md2.get("spin", None)
-        if s1 is None or s2 is None:
+        sides = (alm1.dtype.metadata or {}, alm2.dtype.metadata or {})
+        if any("spin" not in side for side in sides):
             raise ValueError(f"missing spin metadata for {k1} or {k2}")
-        md = {}
-        for k, v in md1.items():
-            md[f"{k}_1"] = v
-        for k, v in md2.items():
-            md[f"{k}_2"] = v
-        bias = None
-        if k1 == k2 and i1 == i2:
-            _fsky, _musq, _dens = md1.get("fsky"), md1.get("musq"), md1.get("dens")
-            if _fsky is not None and _musq is not None and _dens is not None:
-                factor = 0.5 if s1 == s2 == 2 else 1.0
-                bias = factor * _fsky * _musq / _dens
-        if bias is not None:
-            md["bias"] = bias
-        if debias and bias is not None:
-            _debias_cl(cl, bias, md, inplace=True, pixwin=pixwin)
+        s1, s2 = sides[0]["spin"], sides[1]["spin"]
+        md = {f"{name}_{n}": value for n, side in enumerate(sides, start=1) for name, value in side.items()}
+        if (k1, i1) == (k2, i2):
+            bias = _auto_bias(sides[0], both_spin2=(s1 == 2 and s2 == 2))
+            if bias is not None:
+                md["bias"] = bias
+                if debias:
+                    _debias_cl(cl, bias, md, inplace=True, pixwin=pixwin)
         update_metadata(cl, **md)
         res = Result(cl, spin=(s1, s2), axis=-1)
         if bins is not None:

@@ -113,6 +113,12 @@ int hx_wigner_d_table(int lmax, int a, int b, int n, const double *x, double *ou
 int hx_mixmat(const double *cl, int ncl, int l1max, int l2max, int l3max, int s1, int s2,
               double *out);
 int hx_mixmat_eb(const double *cl, int ncl, int l1max, int l2max, int l3max, double *out);
+/* ---- jackknife loop in HBM (heracles/dices/jackknife.py:93-248, "next" row) ------------------------------------
+ * Region maps (jackknife.py:253-263: every pixel outside region k set to zero) and delete-k alms (jackknife.py:222-233,
+ * :298-304: full alms minus the sum of the deleted regions' alms) without leaving the device.                      */
+int hx_region_maps(int64_t npix, int ncomp, const double *maps, const double *region, double k, double *out);
+int hx_alm_subtract(int64_t n, const double *full, int nsub, const double *const *subs, double *out);
+
 /* The loop of heracles/twopoint.py:354-397 (one convolvecl call per mask pair and spin combination) as one call:
  * Gauss-Legendre nodes, Wigner-d tables and the GEMM tile list are built ONCE per (l1max, l2max, l3max); every mask then
  * costs its node weights and one GEMM per product.
