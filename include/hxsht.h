@@ -113,6 +113,15 @@ int hx_wigner_d_table(int lmax, int a, int b, int n, const double *x, double *ou
 int hx_mixmat(const double *cl, int ncl, int l1max, int l2max, int l3max, int s1, int s2,
               double *out);
 int hx_mixmat_eb(const double *cl, int ncl, int l1max, int l2max, int l3max, double *out);
+/* ---- FITS wire format of maps and alms (heracles/io.py:128-218, "next" row) ------------------------------------
+ * Payload conversion between a FITS binary table of 'D' columns (row-major, big-endian) and the component-major
+ * native arrays of the path, one pass on the GPU; `table` / `array` host or device.
+ *   table element (row, c1, c2) <-> array[c1*s1 + c2*s2 + row*srow]
+ *   maps  (io.py:128-168, ncols columns):      nc1 = ncols, nc2 = 1, s1 = nrows, srow = 1
+ *   alms  (io.py:189-218, columns real, imag): nc1 = 2, nc2 = r, s1 = 1, s2 = 2*nrows, srow = 2  (complex128 (r, nrows)) */
+int hx_fits_unpack_f64(int64_t nrows, int nc1, int nc2, int64_t s1, int64_t s2, int64_t srow, const void *table, double *array);
+int hx_fits_pack_f64(int64_t nrows, int nc1, int nc2, int64_t s1, int64_t s2, int64_t srow, const double *array, void *table);
+
 /* ---- jackknife loop in HBM (heracles/dices/jackknife.py:93-248, "next" row) ------------------------------------
  * Region maps (jackknife.py:253-263: every pixel outside region k set to zero) and delete-k alms (jackknife.py:222-233,
  * :298-304: full alms minus the sum of the deleted regions' alms) without leaving the device.                      */
