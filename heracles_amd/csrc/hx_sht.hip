@@ -265,6 +265,131 @@ __global__ __launch_bounds__(1024) void k_ring_subdft(PlanDev P, const int *__re
 }
 
 // =====================================================================================
+// 1b. rings whose Bluestein convolution does not fit LDS (nside 8192: cap rings with 4096 < n < 8192 need M = 16384 points
+//     = 256 KiB): the length-M cyclic convolution as an EVEN and an ODD half of C = M / 2 points each
+//         X[2k]   = FFT_C( x[j] + x[j + C] )[k],      X[2k+1] = FFT_C( (x[j] - x[j + C]) W_M^j )[k]         (forward, DIF)
+//         y[j]    = IFFT_C(Y_even)[j] + W_M^-j IFFT_C(Y_odd)[j],   j < C                                      (inverse, DIT)
+//     The input has n <= C non-zero points (x[j + C] = 0) and only y[0..n) is wanted, so each half is exactly the in-LDS
+//     pipeline of the other rings (FFT_C -> filter -> IFFT_C) on one C-point buffer; the even half's result waits in
+//     registers while the odd half runs.  The filter spectra are stored as [even bins | odd bins].
+// =====================================================================================
+constexpr int SPLIT_JMAX = 8;  // values of j per thread of the split kernels (n <= C = 8 x 1024 threads at most)
+
+__global__ __launch_bounds__(1024) void k_init_bhat_split(PlanDev P, const int *__restrict__ rp_list, int C,
+                                                          double2 *__restrict__ bhat)
+{
+    extern __shared__ double2 buf[];
+    const int rp = rp_list[blockIdx.x];
+    const int n = P.nsub[rp], M = 2 * C;
+    double2 *out = bhat + P.bhat_off[rp];
+    // filter b[j] = chirp(j) for j < n, b[M - j] = chirp(j), 0 elsewhere; halves b0 = b[0..C), b1 = b[C..M)
+    auto b_at = [&](int j) {  // 0 <= j < M
+        const int jj = j < n ? j : (M - j < n ? M - j : -1);
+        return jj < 0 ? make_double2(0.0, 0.0) : expipi((double)chirp_num(jj, n) / (double)n);
+    };
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < C; j += blockDim.x) {
+            const double2 b0 = b_at(j), b1 = b_at(j + C);
+            buf[j] = half == 0 ? cadd(b0, b1) : cmul(csub(b0, b1), P.tw[j]);  // tw[j] = W_M^j (twN = M)
+        }
+        __syncthreads();
+        lds_fft_dif(buf, C, P.tw, P.twN);
+        for (int j = threadIdx.x; j < C; j += blockDim.x) out[half * C + j] = buf[j];
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_ring_subdft_split(PlanDev P, const int *__restrict__ rp_list, int C,
+                                                            const double *__restrict__ maps, const double *__restrict__ pixw,
+                                                            const double2 *__restrict__ zin, double2 *__restrict__ Y)
+{
+    extern __shared__ double2 buf[];
+    const int rp = rp_list[blockIdx.y];
+    const int c = blockIdx.z;
+    const int n = P.nsub[rp];
+    const long long sN = P.startN[rp], sS = P.startS[rp];
+    const int M = 2 * C;
+    const bool plain = fft_size_for(n) == n;  // a power of two (n == C): one plain FFT, no convolution
+    const double *mp = maps + (long long)c * P.npix;
+    const double2 *zp = zin + (long long)c * P.ny + sN;
+    const double2 *bh = P.bhat + (plain ? 0 : P.bhat_off[rp]);
+    const double inv = 1.0 / M;
+    __shared__ double2 tw_hi[TW_HI_MAX], tw_lo[64];
+    const TwFactored twf = load_tw_factored(tw_hi, tw_lo, P.tw, P.twN);
+    auto z_at = [&](int j, int q) {  // packed ring value z_q[j] = z[j + q n]
+        if (MODE == 0) {
+            const long long iN = sN + j + (long long)q * n;
+            double fn = mp[iN];
+            if (pixw) fn *= pixw[iN];
+            double fs = 0.0;
+            if (sS >= 0) {
+                const long long iS = sS + j + (long long)q * n;
+                fs = mp[iS];
+                if (pixw) fs *= pixw[iS];
+            }
+            return make_double2(fn, fs);
+        }
+        return zp[j + (long long)q * n];
+    };
+    for (int r = 0; r < 4; ++r) {
+        // a0[j] = t_r[j] exp(-i pi (j r + 2 j^2) / 2n), kept in registers for both halves
+        double2 a0[SPLIT_JMAX], ye[SPLIT_JMAX];
+#pragma unroll
+        for (int u = 0; u < SPLIT_JMAX; ++u) {
+            const int j = threadIdx.x + u * blockDim.x;
+            a0[u] = make_double2(0.0, 0.0);
+            if (j < n) {
+                const double2 t = dif4_combine(z_at(j, 0), z_at(j, 1), z_at(j, 2), z_at(j, 3), r);
+                const unsigned qn = load_phase_num(j, r, n, !plain);
+                a0[u] = qn ? cmul(t, expipi(-(double)qn / (2.0 * n))) : t;
+            }
+        }
+        if (plain) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < SPLIT_JMAX; ++u) {
+                const int j = threadIdx.x + u * blockDim.x;
+                if (j < n) buf[j] = a0[u];
+            }
+            __syncthreads();
+            lds_fft_dif(buf, n, twf, P.twN);
+            double2 *outp = Y + (long long)c * P.ny + sN + (long long)r * n;
+            const int pbits = ilog2(n);
+            for (int k = threadIdx.x; k < n; k += blockDim.x) outp[k] = buf[bitrev(k, pbits)];
+            continue;
+        }
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();  // the previous pass has been read out of buf
+#pragma unroll
+            for (int u = 0; u < SPLIT_JMAX; ++u) {
+                const int j = threadIdx.x + u * blockDim.x;
+                if (j < C) buf[j] = (j < n) ? (half == 0 ? a0[u] : cmul(a0[u], twf[j])) : make_double2(0.0, 0.0);
+            }
+            __syncthreads();
+            lds_fft_dif(buf, C, twf, P.twN);
+            for (int j = threadIdx.x; j < C; j += blockDim.x) buf[j] = cmul(buf[j], bh[half * C + j]);
+            __syncthreads();
+            lds_fft_dit_inv(buf, C, twf, P.twN);
+#pragma unroll
+            for (int u = 0; u < SPLIT_JMAX; ++u) {
+                const int k = threadIdx.x + u * blockDim.x;
+                if (k < n) {
+                    if (half == 0) ye[u] = buf[k];
+                    else ye[u] = cadd(ye[u], cmulc(buf[k], twf[k]));  // + W_M^-k y_odd[k]
+                }
+            }
+        }
+        double2 *out = Y + (long long)c * P.ny + sN + (long long)r * n;
+#pragma unroll
+        for (int u = 0; u < SPLIT_JMAX; ++u) {
+            const int k = threadIdx.x + u * blockDim.x;
+            if (k < n) out[k] = cscale(cmul(ye[u], expipi(-(double)chirp_num(k, n) / (double)n)), inv);
+        }
+    }
+}
+
+// =====================================================================================
 // synthesis: Fsyn -> ring spectra -> pixels (the Legendre part lives in hx_analysis.hip)
 // =====================================================================================
 // Fsyn[rp][m][N/S][16] -> conj(Z) spectra of the packed ring pair z = f_N + i f_S.
@@ -367,6 +492,17 @@ PlanDev hx_plan::dev() const
     return P;
 }
 
+// Longest FFT done in LDS (points; 8192 = 128 KiB of the CU's 160).  Lowering it (hx_set_max_lds_fft, a power of two >= 16)
+// sends smaller rings through the split kernels -- the way the tests exercise them without an nside-8192 map.
+static int g_lds_fft_cap = 8192;
+static int lds_fft_cap() { return g_lds_fft_cap; }
+extern "C" int hx_set_max_lds_fft(int points)
+{
+    if (points < 16 || points > 8192 || (points & (points - 1))) return fail(HX_ERR_ARG, "hx_set_max_lds_fft: a power of two in [16, 8192]");
+    g_lds_fft_cap = points;
+    return HX_OK;
+}
+
 extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
 {
     if (ensure_ready() != HX_OK) return nullptr;
@@ -402,29 +538,35 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
         maxM = std::max(maxM, fft_size_for(nsub[rp]));
     }
     pl->ny = sN[pl->nrp - 1] + 4LL * nsub[pl->nrp - 1];
-    if ((size_t)maxM * sizeof(double2) > 160 * 1024) {
-        set_error("hx_plan_create: nside=%d needs an in-LDS FFT of %d points (> 8192); unsupported", nside, maxM);
+    // in-LDS FFT length limit (8192 points = 128 KiB); Bluestein rings of twice that run as two halves (split kernels)
+    const int cap = lds_fft_cap();
+    if (maxM > 2 * cap || (maxM > cap && nside > 0 && [&] { for (int rp = 0; rp < pl->nrp; ++rp) if (fft_size_for(nsub[rp]) > cap && fft_size_for(nsub[rp]) == nsub[rp]) return true; return false; }())) {
+        set_error("hx_plan_create: nside=%d needs an in-LDS FFT of %d points (limit %d, %d for Bluestein rings); unsupported", nside, maxM, cap, 2 * cap);
         delete pl;
         return nullptr;
     }
+    pl->fft_cap = cap;
     {
-        // FFT-size classes: ring pairs grouped by in-LDS FFT length, longest rings first
-        std::map<int, std::vector<int>> byM;
-        for (int rp = pl->nrp - 1; rp >= 0; --rp) byM[fft_size_for(nsub[rp])].push_back(rp);
+        // FFT-size classes: ring pairs grouped by in-LDS FFT length, longest rings first; rings beyond the limit form
+        // the split class (M = 2 x cap)
+        // (rings of more than RING_JMAX x 1024 pixels per sub-DFT -- n = 8192 at nside 8192 -- cannot keep their pixels in
+        // registers: they go through the kernel that re-reads them per sub-DFT, like the split rings)
+        std::map<std::pair<int, int>, std::vector<int>> byM;
+        for (int rp = pl->nrp - 1; rp >= 0; --rp) byM[{fft_size_for(nsub[rp]), nsub[rp] > RING_JMAX * 1024 ? 1 : 0}].push_back(rp);
         std::vector<int> list;
         for (auto it = byM.rbegin(); it != byM.rend(); ++it) {
             hx_plan::FftClass c;
-            c.M = it->first; c.first = (int)list.size(); c.count = (int)it->second.size();
+            c.M = it->first.first; c.big = it->first.second; c.first = (int)list.size(); c.count = (int)it->second.size();
             list.insert(list.end(), it->second.begin(), it->second.end());
             pl->fft_classes.push_back(c);
         }
         if (upload(pl->fft_rp_list, list) != HX_OK) { delete pl; return nullptr; }
     }
     pl->twN = std::max(maxM, 2);
-    pl->lds_fft = (size_t)maxM * sizeof(double2);
+    pl->lds_fft = (size_t)std::min(maxM, cap) * sizeof(double2);
     pl->h_sth = sth; pl->h_z = z; pl->h_nsub = nsub;
     // Bluestein tables: one spectrum per distinct non-power-of-two sub-length
-    std::vector<int> blu_list;
+    std::vector<int> blu_list, blu_split;
     long long btot = 0;
     {
         std::map<int, long long> off_of_n;
@@ -435,7 +577,7 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
             if (it == off_of_n.end()) {
                 it = off_of_n.emplace(n, btot).first;
                 btot += M;
-                blu_list.push_back(rp);
+                (M > cap ? blu_split : blu_list).push_back(rp);
             }
             boff[rp] = it->second;
         }
@@ -480,11 +622,21 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
     // 3 KiB of the 160 KiB are the static factored-twiddle tables of k_ring_subdft
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_bhat_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft_split<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft_split<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     if (!blu_list.empty()) {
         DevBuf d_list;
         if (upload(d_list, blu_list) != HX_OK) { delete pl; return nullptr; }
         hipLaunchKernelGGL(k_init_bhat, dim3((unsigned)blu_list.size()), dim3(512), pl->lds_fft, st, pl->dev(),
                            d_list.as<int>(), pl->bhat.as<double2>());
+        (void)hipStreamSynchronize(st);
+    }
+    if (!blu_split.empty()) {
+        DevBuf d_list;
+        if (upload(d_list, blu_split) != HX_OK) { delete pl; return nullptr; }
+        hipLaunchKernelGGL(k_init_bhat_split, dim3((unsigned)blu_split.size()), dim3(std::min(1024, std::max(64, cap / 4))), (size_t)cap * sizeof(double2), st,
+                           pl->dev(), d_list.as<int>(), cap, pl->bhat.as<double2>());
         (void)hipStreamSynchronize(st);
     }
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
@@ -530,6 +682,12 @@ template <int MODE>
 static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, const double2 *zin, double2 *Y)
 {
     for (const auto &c : pl->fft_classes) {
+        if (c.M > pl->fft_cap || c.big) {  // Bluestein convolution of 2 x cap points in two halves / plain FFT of > 4096 points
+            const int C = std::min(c.M, pl->fft_cap), threads = std::min(1024, std::max(64, C / SPLIT_JMAX));
+            hipLaunchKernelGGL(k_ring_subdft_split<MODE>, dim3(1, c.count, nb), dim3(threads), (size_t)C * sizeof(double2), rt().stream,
+                               pl->dev(), pl->fft_rp_list.as<int>() + c.first, C, d_maps, d_pw, zin, Y);
+            continue;
+        }
         // one radix-4 butterfly per thread and pass (M/4 threads); n <= M <= RING_JMAX * threads
         const int threads = std::min(1024, std::max(256, c.M / 4));  // M/8 threads (two butterflies each): 23.0 vs 21.0 ms
         hipLaunchKernelGGL(k_ring_subdft<MODE>, dim3(1, c.count, nb), dim3(threads), (size_t)c.M * sizeof(double2), rt().stream,

@@ -133,6 +133,7 @@ inline int upload(DevBuf &b, const std::vector<T> &v)
 struct hx_plan {
     int nside = 0, lmax = 0, max_comp = 0;
     int nrp = 0, nrp_pad = 0, twN = 1;
+    int fft_cap = 8192;   // longest in-LDS FFT of this plan
     int last_chunks = 0;  // m-chunks of the most recent analysis sweep (hx_plan_last_chunks)
     long long npix = 0, ny = 0, nlm = 0;
     size_t lds_fft = 0;
@@ -146,7 +147,7 @@ struct hx_plan {
         std::vector<long long> rows_before_m; // partial rows of all tasks with smaller m (size lmax+2)
         hx::DevBuf d_tasks, d_of_m;
     } ts[3];  // spin 0, spin 2, spin 0 with half-size work-groups
-    struct FftClass { int M, first, count; };
+    struct FftClass { int M, first, count, big; };
     std::vector<FftClass> fft_classes;   // ring pairs grouped by in-LDS FFT length
     hx::DevBuf fft_rp_list;
     hx::DevBuf Y, F, partial, d_dbg, resid, resid_maps, Fsyn;

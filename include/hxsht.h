@@ -59,6 +59,9 @@ int hx_profile_get(const char *name, int *launches, double *total_ms);
  * heracles/io.py:377.  A plan owns ring tables, recursion tables, Bluestein tables and
  * device scratch for up to max_comp map components per call. */
 hx_plan *hx_plan_create(int nside, int lmax, int max_comp);
+/* Longest ring FFT kept in LDS by plans created afterwards (power of two in [16, 8192], default 8192); Bluestein rings of up to
+ * twice that run as two half-length passes.  A tuning / test knob: results do not depend on it beyond rounding. */
+int hx_set_max_lds_fft(int points);
 void hx_plan_destroy(hx_plan *plan);
 int64_t hx_plan_scratch_bytes(const hx_plan *plan);
 /* HBM the analysis may use for the operands and ring-group partial sums of ONE m-chunk (bytes; a chunk always

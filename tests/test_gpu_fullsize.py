@@ -156,3 +156,66 @@ def test_alm2cl_full_size_against_numpy(plan):
         ref = torch.zeros(LMAX + 1, dtype=torch.float64, device="cuda").index_add_(0, idx_l, prod)
         ref = (ref / (2.0 * torch.arange(LMAX + 1, device="cuda") + 1.0)).cpu().numpy()
         np.testing.assert_allclose(np.asarray(cls[k]), ref, rtol=1e-11, atol=1e-14)
+
+
+def test_nside_8192_against_oracle_on_sampled_m(oracle):
+    """/root/reference/examples/heracles.cfg configures maps up to nside 8192 (lmax 8000): the cap rings with
+    4096 < n < 8192 take the split Bluestein path (two 8192-point halves of the 16384-point convolution).  The oracle's
+    own map2alm with its Legendre stage restricted to every 1000th m must agree on those m, spin 0 and spin 2; the
+    synthesis of a few m agrees with the closed form on rings of the split class."""
+    import torch
+    import heracles_amd as hx
+    from helpers import lambda_lm_column
+
+    nside, lmax = 8192, 8000
+    npix, nlm = 12 * nside * nside, (lmax + 1) * (lmax + 2) // 2
+    hx.sht.clear_plans()  # the nside-4096 tables are not needed any more
+    torch.cuda.empty_cache()
+    plan = hx.Plan(nside, lmax)
+    try:
+        for spin in (0, 2):
+            nc = 1 if spin == 0 else 2
+            g = torch.Generator(device="cuda").manual_seed(81 + spin)
+            x = torch.randn((nc, npix), dtype=torch.float64, device="cuda", generator=g)
+            b = torch.empty((nc, nlm), dtype=torch.complex128, device="cuda")
+            plan.map2alm(x, spin, out=b, niter=0)
+            stride = 1000
+            oracle.set_mstride(stride)
+            try:
+                ref = oracle.map2alm(x.cpu().numpy(), nside, lmax, spin=spin)
+            finally:
+                oracle.set_mstride(1)
+            got = b.cpu().numpy()
+            scale = np.abs(got).max()
+            for m in range(0, lmax + 1, stride):
+                base = m * (2 * lmax + 1 - m) // 2
+                sl = slice(base + m, base + lmax + 1)
+                assert np.abs(got[:, sl] - ref[:, sl]).max() <= 2e-10 * scale, (spin, m)
+            del x, b, ref, got
+            torch.cuda.empty_cache()
+        # synthesis: rings 5000 (n = 5000, split class), 8191 and the equator against sum_l a_lm lambda_lm e^{i m phi}
+        rng = np.random.default_rng(7)
+        ms = [0, 3, 1500, 7000]
+        alm = np.zeros(nlm, dtype=np.complex128)
+        for m in ms:
+            base = m * (2 * lmax + 1 - m) // 2
+            v = rng.standard_normal(lmax + 1 - m) + 1j * rng.standard_normal(lmax + 1 - m) * (m > 0)
+            alm[base + m : base + lmax + 1] = v / np.sqrt(1.0 + np.arange(m, lmax + 1))
+        y = torch.empty((1, npix), dtype=torch.float64, device="cuda")
+        plan.alm2map(torch.as_tensor(alm[None]).cuda(), 0, out=y)
+        rings = (4100, 5000, 8191, 16384, 4 * nside - 5000)
+        info = [oracle.ring_info(nside, r) for r in rings]
+        zs, sths = np.array([i[2] for i in info]), np.array([i[3] for i in info])
+        for k, (sp, nphi, z, sth, phi0) in enumerate(info):
+            got = y[0, sp : sp + nphi].cpu().numpy()
+            phi = phi0 + 2 * np.pi * np.arange(nphi) / nphi
+            exp = np.zeros(nphi)
+            for m in ms:
+                lam = lambda_lm_column(m, lmax, zs[k : k + 1], sths[k : k + 1])[:, 0]
+                base = m * (2 * lmax + 1 - m) // 2
+                a = alm[base + m : base + lmax + 1]
+                fm = complex(np.sum(a.real * lam), np.sum(a.imag * lam))
+                exp += (1.0 if m == 0 else 2.0) * np.real(fm * np.exp(1j * m * phi))
+            assert np.abs(got - exp).max() <= 1e-9 * max(np.abs(exp).max(), 1.0), rings[k]
+    finally:
+        plan.close()

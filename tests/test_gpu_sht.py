@@ -228,3 +228,36 @@ def test_map2alm_m_chunked_batches_medium(oracle, spin, ncomp):
         base = m * (2 * lmax + 1 - m) // 2
         err = np.abs(out[:, base + m : base + lmax + 1] - ref[:, base + m : base + lmax + 1]).max()
         assert err <= TOL * scale, (m, err / scale)
+
+
+@pytest.mark.parametrize("nside,cap", [(64, 64), (32, 32), (48, 64)])
+def test_split_bluestein_rings(oracle, nside, cap):
+    """Rings whose Bluestein convolution exceeds the in-LDS FFT limit (nside 8192: 4096 < n < 8192 needs 16384 points)
+    run as an even and an odd half-length pass.  The limit is lowered (hx_set_max_lds_fft) so that the cap rings of a
+    small map take that path: analysis and synthesis against the oracle, and bit-equality of nothing -- only rounding
+    differs from the unsplit plan."""
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(nside + cap)
+    lmax = 3 * nside // 2 + 5
+    maps0 = rng.standard_normal((3, 12 * nside**2))
+    maps2 = rng.standard_normal((4, 12 * nside**2))
+    ref_plan = hx.Plan(nside, lmax)
+    a0_ref, a2_ref = ref_plan.map2alm(maps0, 0), ref_plan.map2alm(maps2, 2)
+    ref_plan.close()
+    L = hx._lib.load()
+    hx._lib.check(L.hx_set_max_lds_fft(cap))
+    try:
+        plan = hx.Plan(nside, lmax)
+        a0, a2 = plan.map2alm(maps0, 0), plan.map2alm(maps2, 2)
+        back = plan.alm2map(a0, 0)
+        plan.close()
+    finally:
+        hx._lib.check(L.hx_set_max_lds_fft(8192))
+    close(a0, oracle.map2alm(maps0, nside, lmax, spin=0))
+    close(a2, oracle.map2alm(maps2, nside, lmax, spin=2))
+    close(a0, a0_ref, 1e-12)
+    close(a2, a2_ref, 1e-12)
+    close(back, oracle.alm2map(a0, nside, lmax), 1e-11)
+    with pytest.raises(hx.HxError):
+        hx._lib.check(L.hx_set_max_lds_fft(100))
