@@ -508,7 +508,9 @@ struct PipeCfg {
 __device__ __host__ inline int pipe_rho(int q, int k) { return 4 * q + k; }
 __device__ __host__ inline int pipe_tile_idx(int c, int r) { return c * 32 + ((r ^ (c & 7)) * 2); }
 
-template <int SPIN, int NG, int NBX>
+// NSUB: 32-l blocks per flush (their D tiles stay in registers): one work-group reduction and one pair of barriers per
+// NSUB * 32 l
+template <int SPIN, int NG, int NBX, int NSUB = 2>
 __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const double2 *__restrict__ coefn,
                                                           const double *__restrict__ alphan)
 {
@@ -516,12 +518,14 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     constexpr int NW = C::NW, NOP = C::NOP, NCH = C::NCH;
     constexpr int NPAIR = 16;                  // slot pairs per stage: spin 0 q = 0..15, spin 2 (q = 0..7, op); a pair = positions 0, 1
     constexpr int NGA = NG > 0 ? NG : 1, NXA = NBX > 0 ? NBX : 1;
-    constexpr int DQ0 = NG * 512;              // first double of the 4-column blocks in a wave's D staging area
-    static_assert(NG >= 1 && NG * 512 + NBX * 128 <= 2048, "D tiles of a wave must fit its second tile");
+    constexpr int DQ0 = NG * 512;              // first double of the 4-column blocks in a sub-block's D staging area
+    constexpr int DSZ = NG * 512 + NBX * 128;  // doubles of one sub-block's D staging area
+    constexpr int NCR = 3 * NSUB, NAR = 2 * NSUB;  // blocks in the coefficient / alpha rings
+    static_assert(NG >= 1 && NSUB * DSZ <= 2048, "D tiles of a wave must fit its second tile");
     __shared__ double tileA[NW][2048];         // set 0, 64 KiB
     __shared__ double tileB[NW][2048];         // set 1; doubles as the D staging area of the flush
-    __shared__ double2 coefs[3][2][LBLK];      // recursion coefficients of blocks b, b + 1, b + 2; [1] = sign of q' flipped (spin 2)
-    __shared__ double alphas[2][LBLK];         // output scalings alpha_l of blocks b, b + 1
+    __shared__ double2 coefs[NCR][2][LBLK];    // recursion coefficients, block j in slot j % NCR; [1] = sign of q' flipped (spin 2)
+    __shared__ double alphas[NAR][LBLK];       // output scalings alpha_l, block j in slot j % NAR
     const PlanDev &P = A.P;
     const LegTask task = A.tasks[blockIdx.x];
     const int m = task.m, lmax = P.lmax;
@@ -602,11 +606,13 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     const double csign = (SPIN == 2 && (threadIdx.x & 1) && (threadIdx.x >> 6) == 1) ? -1.0 : 1.0;
     if (threadIdx.x < 128) {
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb)
+        for (int bb = 0; bb <= NSUB; ++bb)
             (&coefs[bb][threadIdx.x >> 6][0].x)[threadIdx.x & 63] =
                 csign * reinterpret_cast<const double *>(coefn + cb + l0 + bb * LBLK + coff)[threadIdx.x & 63];
-    } else if (threadIdx.x < 160)
-        alphas[0][threadIdx.x - 128] = alphan[cb + l0 + (threadIdx.x - 128)];
+    } else if (threadIdx.x < 160) {
+#pragma unroll
+        for (int bb = 0; bb < NSUB; ++bb) alphas[bb][threadIdx.x - 128] = alphan[cb + l0 + bb * LBLK + (threadIdx.x - 128)];
+    }
     __syncthreads();
 
     // ---- one recursion step of chain c of set S; the caller stores the value it returns (the one BEFORE the step) ----
@@ -630,8 +636,8 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         vc[S][c] = vn;
         return cur;
     };
-    double4_t acc[NGA][2];
-    double accx[NXA][2];
+    double4_t accs[NSUB][NGA][2];
+    double accxs[NSUB][NXA][2];
     // ---- a stage: MFMAs of set SM (if MF) and the recursion of the other set (mode RM).
     // FP64 vector instructions and FP64 MFMAs share one execution resource: a vector FMA placed between the MFMAs of the
     // same wave costs ~17 cycles of matrix-pipe time (4 alone), from another wave of the SIMD it is starved (tools/ubench_slot.hip,
@@ -653,7 +659,9 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
 #endif
     constexpr int PF = 2, HB = 8, PPB = HB / 2, NHB = LBLK / HB;  // (16 steps per block need 96 more registers than the wave has)
     double2 cq[HB];
-    auto stage = [&](auto SMM, auto MFF, auto RMM, const double2 *cf_rec, const double2 *cf_next) __attribute__((always_inline)) {
+    auto stage = [&](auto SUBB, auto SMM, auto MFF, auto RMM, const double2 *cf_rec, const double2 *cf_next) __attribute__((always_inline)) {
+        double4_t (&acc)[NGA][2] = accs[decltype(SUBB)::value];
+        double (&accx)[NXA][2] = accxs[decltype(SUBB)::value];
         constexpr int SM = decltype(SMM)::value, SR = 1 - SM, RM = (HX_PIPE_ABL & 2) ? 0 : decltype(RMM)::value;
         constexpr bool MF = decltype(MFF)::value && !(HX_PIPE_ABL & 1);
         using ISR = std::integral_constant<int, SR>;
@@ -746,17 +754,17 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     using BT = std::integral_constant<bool, true>;
     using BF = std::integral_constant<bool, false>;
     // dispatch on (MFMA of set SM wanted, recursion mode of the other set)
-    auto run_stage = [&](auto SMM, bool mf, int rm, const double2 *cf_rec, const double2 *cf_next) __attribute__((always_inline)) {
+    auto run_stage = [&](auto SUBB, auto SMM, bool mf, int rm, const double2 *cf_rec, const double2 *cf_next) __attribute__((always_inline)) {
         if (mf) {
-            if (rm == 3) stage(SMM, BT{}, I3{}, cf_rec, cf_next);
-            else if (rm == 2) stage(SMM, BT{}, I2{}, cf_rec, cf_next);
-            else if (rm == 1) stage(SMM, BT{}, I1{}, cf_rec, cf_next);
-            else stage(SMM, BT{}, I0{}, cf_rec, cf_next);
+            if (rm == 3) stage(SUBB, SMM, BT{}, I3{}, cf_rec, cf_next);
+            else if (rm == 2) stage(SUBB, SMM, BT{}, I2{}, cf_rec, cf_next);
+            else if (rm == 1) stage(SUBB, SMM, BT{}, I1{}, cf_rec, cf_next);
+            else stage(SUBB, SMM, BT{}, I0{}, cf_rec, cf_next);
         } else {
-            if (rm == 3) stage(SMM, BF{}, I3{}, cf_rec, cf_next);
-            else if (rm == 2) stage(SMM, BF{}, I2{}, cf_rec, cf_next);
-            else if (rm == 1) stage(SMM, BF{}, I1{}, cf_rec, cf_next);
-            else stage(SMM, BF{}, I0{}, cf_rec, cf_next);
+            if (rm == 3) stage(SUBB, SMM, BF{}, I3{}, cf_rec, cf_next);
+            else if (rm == 2) stage(SUBB, SMM, BF{}, I2{}, cf_rec, cf_next);
+            else if (rm == 1) stage(SUBB, SMM, BF{}, I1{}, cf_rec, cf_next);
+            else stage(SUBB, SMM, BF{}, I0{}, cf_rec, cf_next);
         }
     };
 
@@ -770,55 +778,66 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         for (int k = 0; k < HB; ++k) cq[k] = coefs[0][chalf][k];
         const int rm = set_mode(I0{});
         tl_live[0] = rm >= 2 || (HX_PIPE_ABL & 2);
-        run_stage(I1{}, false, rm, &coefs[0][0][0], &coefs[0][0][0]);  // "MFMA set 1" off: only the recursion of set 0
+        run_stage(I0{}, I1{}, false, rm, &coefs[0][0][0], &coefs[0][0][0]);  // "MFMA set 1" off: only the recursion of set 0
     }
     // flush roles of this thread: D values arrive as 16-byte chunks (col, chunk c): rows (c >> 1) + 8 (c & 1) and + 4
     const int fcol = threadIdx.x & 15, fch = (threadIdx.x >> 4) & 7, fpos = (threadIdx.x >> 7) & 1;
     const int frow = (fch >> 1) + 8 * (fch & 1);
-    // Global loads of the hand-over (threads < 128: a coefficient double of block b + 2; threads 128..159: alpha_l of
-    // block b + 1) are issued inside the flush of block b - 1, IN FRONT of its partial-sum stores, and stored to LDS in the
-    // flush of block b: vmcnt retires in order, so a load issued behind the stores could not be waited for without
-    // waiting for those stores to reach HBM, and a use right behind the load would expose its latency.  The reduction
-    // itself reads alpha_l from LDS: no vector-memory wait inside the flush.
-    double hpre = 0.0;
-    auto prefetch = [&](int bn) __attribute__((always_inline)) {  // for the flush of block bn
-        const int lbn = l0 + bn * LBLK;
-        double v = 0.0;
-        if (threadIdx.x < 128) v = reinterpret_cast<const double *>(coefn + cb + lbn + 2 * LBLK + coff)[threadIdx.x & 63];
-        else if (threadIdx.x < 160) v = alphan[cb + lbn + LBLK + (threadIdx.x - 128)];
-        return v;
+    // Global loads of the hand-over (threads < 128: coefficient doubles; threads 128..159: alpha_l) are issued inside the
+    // flush BEFORE the one that stores them to LDS, and IN FRONT of that flush's partial-sum stores: vmcnt retires in order,
+    // so a load issued behind the stores could not be waited for without waiting for those stores to reach HBM, and a use
+    // right behind the load would expose its latency.  The reduction itself reads alpha_l from LDS: no vector-memory wait
+    // inside the flush.  A flush that closes blocks b .. b + NSUB - 1 stores the coefficients of blocks b + NSUB + 1 .. b + 2 NSUB
+    // and the alphas of blocks b + NSUB .. b + 2 NSUB - 1.
+    double hpre[NSUB];
+    auto prefetch = [&](int b0) __attribute__((always_inline)) {  // for the flush that closes blocks b0 ..
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+            hpre[u] = 0.0;
+            if (threadIdx.x < 128) hpre[u] = reinterpret_cast<const double *>(coefn + cb + l0 + (b0 + NSUB + 1 + u) * LBLK + coff)[threadIdx.x & 63];
+            else if (threadIdx.x < 160) hpre[u] = alphan[cb + l0 + (b0 + NSUB + u) * LBLK + (threadIdx.x - 128)];
+        }
     };
-    hpre = prefetch(0);
+    prefetch(0);
     // partial rows this thread writes: (group columns) rows 2 frow + fpos and + 8 of the block; (extra blocks) rows 2 qrow, + 1
     const int qrow = threadIdx.x / (4 * NXA), qcol = threadIdx.x % (4 * NXA);
     double *pgrp = A.partial + (task.pout - A.row0 + 2 * frow + fpos) * A.ncol + fcol;
     double *pquad = A.partial + (task.pout - A.row0 + 2 * qrow) * A.ncol + NG * NCOL + qcol;
-    for (int b = 0; b < nblk; ++b) {
+    auto block = [&](auto SUBB, int bb) __attribute__((always_inline)) {
+        constexpr int SUB = decltype(SUBB)::value;
 #pragma unroll
-        for (int g = 0; g < NGA; ++g) acc[g][0] = acc[g][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        for (int g = 0; g < NGA; ++g) accs[SUB][g][0] = accs[SUB][g][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int g = 0; g < NXA; ++g) accx[g][0] = accx[g][1] = 0.0;
-        const double2 *cf_b = &coefs[b % 3][0][0], *cf_n = &coefs[(b + 1) % 3][0][0];
-        // stage (b, 0): MFMA(set 0, block b) || recursion(set 1, block b)
+        for (int g = 0; g < NXA; ++g) accxs[SUB][g][0] = accxs[SUB][g][1] = 0.0;
+        const double2 *cf_b = &coefs[bb % NCR][0][0], *cf_n = &coefs[(bb + 1) % NCR][0][0];
+        // stage (bb, 0): MFMA(set 0, block bb) || recursion(set 1, block bb)
         {
             const int rm = set_mode(I1{});
-            run_stage(I0{}, tl_live[0], rm, cf_b, cf_n);
+            run_stage(SUBB, I0{}, tl_live[0], rm, cf_b, cf_n);
             HX_STAMP(kind_of(tl_live[0], rm));
             tl_live[1] = rm >= 2 || (HX_PIPE_ABL & 2);
         }
-        // stage (b, 1): MFMA(set 1, block b) || recursion(set 0, block b + 1)
+        // stage (bb, 1): MFMA(set 1, block bb) || recursion(set 0, block bb + 1)
         {
-            const int rm = b + 1 < nblk ? set_mode(I0{}) : 0;
-            run_stage(I1{}, tl_live[1], rm, cf_n, cf_n);
+            const int rm = bb + 1 < nblk ? set_mode(I0{}) : 0;
+            run_stage(SUBB, I1{}, tl_live[1], rm, cf_n, cf_n);
             HX_STAMP(kind_of(tl_live[1], rm));
             tl_live[0] = rm >= 2 || (HX_PIPE_ABL & 2);
         }
+    };
+    for (int b = 0; b < nblk; b += NSUB) {
+        block(I0{}, b);
+        if (NSUB > 1 && b + 1 < nblk) block(std::integral_constant<int, NSUB - 1>{}, b + 1);
         if (HX_PIPE_ABL & 4) {
             double chk = 0.0;  // keeps every accumulator alive
 #pragma unroll
-            for (int g = 0; g < NGA; ++g) chk += acc[g][0][0] + acc[g][0][1] + acc[g][0][2] + acc[g][0][3] + acc[g][1][0] + acc[g][1][1] + acc[g][1][2] + acc[g][1][3];
+            for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
-            for (int g = 0; g < NXA; ++g) chk += accx[g][0] + accx[g][1];
+                for (int g = 0; g < NGA; ++g)
+                    chk += accs[sub][g][0][0] + accs[sub][g][0][1] + accs[sub][g][0][2] + accs[sub][g][0][3] + accs[sub][g][1][0] + accs[sub][g][1][1] + accs[sub][g][1][2] + accs[sub][g][1][3];
+#pragma unroll
+                for (int g = 0; g < NXA; ++g) chk += accxs[sub][g][0] + accxs[sub][g][1];
+            }
             if (chk == 1.2345e-300) A.partial[0] = 1.0;
             continue;
         }
@@ -826,47 +845,60 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         // D of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4 reg, col = lane&15.  Staging of (group g, position p): column-major,
         // 16-byte chunk c = 2 (lane>>4) + (reg>>1) of column col at  (g 2 + p) 256 + col 16 + (c ^ (col & 7)) 2  (128-bit stores,
         // conflict-free through the swizzle);  D of v_mfma_f64_4x4x4_4b: lane (i = lane>>4, blk = (lane>>2)&3, j = lane&3) =
-        // row 4 blk + i, column j: both positions in one 16-byte store at  DQ0 + ((row 4 NBX + 4 x + j) 2)
-        double *dt = &tileB[w][0];
+        // row 4 blk + i, column j: both positions in one 16-byte store at  DQ0 + ((row 4 NBX + 4 x + j) 2); sub-block sub at + sub DSZ
+        const bool two = NSUB > 1 && b + 1 < nblk;
 #pragma unroll
-        for (int g = 0; g < NG; ++g)
+        for (int sub = 0; sub < NSUB; ++sub) {
+            double *dt = &tileB[w][0] + sub * DSZ;
 #pragma unroll
-            for (int pos = 0; pos < 2; ++pos)
+            for (int g = 0; g < NG; ++g)
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    *reinterpret_cast<double2 *>(dt + (g * 2 + pos) * 256 + ai * 16 + (((2 * ak + h) ^ (ai & 7)) * 2)) =
-                        make_double2(acc[g][pos][2 * h], acc[g][pos][2 * h + 1]);
+                for (int pos = 0; pos < 2; ++pos)
 #pragma unroll
-        for (int g = 0; g < NBX; ++g)
-            *reinterpret_cast<double2 *>(dt + DQ0 + ((4 * ((lane >> 2) & 3) + ak) * 4 * NBX + 4 * g + (lane & 3)) * 2) =
-                make_double2(accx[g][0], accx[g][1]);
-        if (threadIdx.x < 128) (&coefs[(b + 2) % 3][threadIdx.x >> 6][0].x)[threadIdx.x & 63] = csign * hpre;
-        else if (threadIdx.x < 160) alphas[(b + 1) & 1][threadIdx.x - 128] = hpre;
+                    for (int h = 0; h < 2; ++h)
+                        *reinterpret_cast<double2 *>(dt + (g * 2 + pos) * 256 + ai * 16 + (((2 * ak + h) ^ (ai & 7)) * 2)) =
+                            make_double2(accs[sub][g][pos][2 * h], accs[sub][g][pos][2 * h + 1]);
+#pragma unroll
+            for (int g = 0; g < NBX; ++g)
+                *reinterpret_cast<double2 *>(dt + DQ0 + ((4 * ((lane >> 2) & 3) + ak) * 4 * NBX + 4 * g + (lane & 3)) * 2) =
+                    make_double2(accxs[sub][g][0], accxs[sub][g][1]);
+        }
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+            if (threadIdx.x < 128) (&coefs[(b + NSUB + 1 + u) % NCR][threadIdx.x >> 6][0].x)[threadIdx.x & 63] = csign * hpre[u];
+            else if (threadIdx.x < 160) alphas[(b + NSUB + u) % NAR][threadIdx.x - 128] = hpre[u];
+        }
         lds_barrier();
         HX_STAMP(5);
-        hpre = prefetch(b + 1);
-        const double *alb = alphas[b & 1];
-        // (rows of a task are padded to whole 32-l blocks: no bounds tests)
+        prefetch(b + NSUB);
+        // (rows of a task are padded to whole 32-l blocks: no bounds tests within a block)
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            double2 s4[NW];
+        for (int sub = 0; sub < NSUB; ++sub) {
+            if (sub > 0 && !two) break;
+            const double *alb = alphas[(b + sub) % NAR];
+            const double *dt0 = &tileB[0][0] + sub * DSZ;
+            const long long rsub = (long long)sub * LBLK * A.ncol;
 #pragma unroll
-            for (int ww = 0; ww < NW; ++ww)
-                s4[ww] = *reinterpret_cast<const double2 *>(&tileB[ww][0] + (g * 2 + fpos) * 256 + fcol * 16 + ((fch ^ (fcol & 7)) * 2));
-            const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
-            pgrp[g * NCOL] = sx * alb[2 * frow + fpos];
-            pgrp[g * NCOL + 8 * (long long)A.ncol] = sy * alb[2 * frow + 8 + fpos];
+            for (int g = 0; g < NG; ++g) {
+                double2 s4[NW];
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww)
+                    s4[ww] = *reinterpret_cast<const double2 *>(dt0 + ww * 2048 + (g * 2 + fpos) * 256 + fcol * 16 + ((fch ^ (fcol & 7)) * 2));
+                const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
+                pgrp[rsub + g * NCOL] = sx * alb[2 * frow + fpos];
+                pgrp[rsub + g * NCOL + 8 * (long long)A.ncol] = sy * alb[2 * frow + 8 + fpos];
+            }
+            if (NBX > 0 && threadIdx.x < 64 * NBX) {
+                double2 s4[NW];
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(dt0 + ww * 2048 + DQ0 + threadIdx.x * 2);
+                const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
+                pquad[rsub] = sx * alb[2 * qrow];
+                pquad[rsub + A.ncol] = sy * alb[2 * qrow + 1];
+            }
         }
-        if (NBX > 0 && threadIdx.x < 64 * NBX) {
-            double2 s4[NW];
-#pragma unroll
-            for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(&tileB[ww][0] + DQ0 + threadIdx.x * 2);
-            const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
-            pquad[0] = sx * alb[2 * qrow];
-            pquad[A.ncol] = sy * alb[2 * qrow + 1];
-        }
-        pgrp += (long long)LBLK * A.ncol;
-        pquad += (long long)LBLK * A.ncol;
+        pgrp += (long long)NSUB * LBLK * A.ncol;
+        pquad += (long long)NSUB * LBLK * A.ncol;
         HX_STAMP(7);
         lds_barrier();  // D tiles consumed: tileB may be overwritten by the recursion of the next stage
         HX_STAMP(6);
@@ -1282,6 +1314,19 @@ static int build_task_set(hx_plan *pl, int spin, int nw, hx_plan::TaskSet &ts)
     return HX_OK;
 }
 
+// 32-l blocks per flush of the pipelined kernel: two for spin 2 (-0.7 %), one for spin 0 (two spill 16 registers: +5.7 %);
+// measured on one device, HX_PIPE_NSUB = 1 / 2 overrides (a tuning knob, read once: every partial row is the same
+// fixed-order sum either way, the results are bit-identical)
+static int pipe_nsub(int spin)
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("HX_PIPE_NSUB");
+        v = e ? atoi(e) : 0;
+    }
+    return v == 1 || v == 2 ? v : (spin ? 2 : 1);
+}
+
 template <int SPIN>
 static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int nb, const SweepShape &sh, const double *d_rw,
                         const double *d_fl, int add, double2 *d_alms)
@@ -1330,12 +1375,16 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
             hipLaunchKernelGGL((k_legendre_analysis<SPIN, -1, 0, QSUB, QNW>), grid, dim3(QNW * 64), 0, st, A, cn, al);
         else if (sh.quad == 2)  // 140 VGPRs: two half-size groups do not fit a CU (104 vs 91 ms)
             hipLaunchKernelGGL((k_legendre_analysis<SPIN, -2, 0, QSUB>), grid, block, 0, st, A, cn, al);
+        else if (sh.ng == 1 && sh.nbx == 0 && pipe_nsub(SPIN) == 2)
+            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 0, 2>), grid, pblock, 0, st, A, cn, al);
         else if (sh.ng == 1 && sh.nbx == 0)
-            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 0>), grid, pblock, 0, st, A, cn, al);
+            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 0, 1>), grid, pblock, 0, st, A, cn, al);
+        else if (sh.ng == 1 && sh.nbx == 1 && pipe_nsub(SPIN) == 2)
+            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 1, 2>), grid, pblock, 0, st, A, cn, al);
         else if (sh.ng == 1 && sh.nbx == 1)
-            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 1>), grid, pblock, 0, st, A, cn, al);
+            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 1, 1>), grid, pblock, 0, st, A, cn, al);
         else if (sh.ng == 2 && sh.nbx == 0)
-            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 2, 0>), grid, pblock, 0, st, A, cn, al);
+            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 2, 0, 1>), grid, pblock, 0, st, A, cn, al);  // a second accumulator set spills 20-76 registers
         else
             return fail(HX_ERR_ARG, "legendre analysis: no kernel for %d groups + %d blocks", sh.ng, sh.nbx);
 #if defined(HX_DIAG) && (HX_PIPE_ABL & 8)

@@ -132,8 +132,9 @@ extern "C" int hx_measure_peaks(double *out4)
     }
     unsigned long long *d_clk = reinterpret_cast<unsigned long long *>(mf_src.as<double>() + 2048);
     const int miters = 4000;
-    HX_TRY(best_ms([&] { hipLaunchKernelGGL(k_peak_mfma, dim3(cus), dim3(256), 0, st, small.as<double>(), miters, mf_src.as<double>(), d_clk); }, ms));
-    out4[2] = (double)cus * 4 * miters * 16.0 * 2048.0 / (ms * 1e-3) / 1e12;
+    // two blocks of four waves per CU (a grid of one block per CU is not guaranteed to land one on each)
+    HX_TRY(best_ms([&] { hipLaunchKernelGGL(k_peak_mfma, dim3(2 * cus), dim3(256), 0, st, small.as<double>(), miters, mf_src.as<double>(), d_clk); }, ms));
+    out4[2] = (double)2 * cus * 4 * miters * 16.0 * 2048.0 / (ms * 1e-3) / 1e12;
     {
         unsigned long long hclk[2] = {0, 1};
         HX_HIP(hipMemcpy(hclk, d_clk, sizeof(hclk), hipMemcpyDeviceToHost));
