@@ -112,7 +112,11 @@ class ShardedTwoPoint:
         """(world * ncomp_max, nlm) complex128: slice r * ncomp_max ... holds the alms of rank r's maps."""
         import torch
 
-        if self._buf is None or (device is not None and self._buf.device != torch.device(device)):
+        if self._buf is not None and device is not None:
+            want = torch.device(device)
+            if want.type != self._buf.device.type or (want.index is not None and want.index != self._buf.device.index):
+                self._buf = None  # asked for another device
+        if self._buf is None:
             self._buf = torch.zeros((self.world * self.ncomp_max, self.nlm), dtype=torch.complex128, device=device)
         return self._buf
 

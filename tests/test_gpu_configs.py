@@ -100,3 +100,71 @@ def test_config3_mixing_matrix_lmax4096(oracle):
     ident = hx.mixmat(one, spin=(0, 0))
     np.testing.assert_allclose(np.diag(ident), 1.0, atol=1e-11)
     assert np.abs(ident - np.diag(np.diag(ident))).max() <= 1e-11
+
+
+def test_config2_full_job_dealt_to_8_ranks(oracle):
+    """BASELINE configs[2] in full: 10 bins x (Positions, Shears) at nside 2048 / lmax 3072, dealt to 8 ranks the way
+    bench.py --scaling strong deals them (cost-balanced maps, tiled pair split).  The 8 ranks run one after the other on
+    the one GPU of the test box and write into ONE buffer (which is what the all-gather produces); their Cl rows
+    together must equal the single-rank job, and the alms of a spin-0 and a spin-2 map agree with the oracle on every
+    96th m whatever sweep shape their owner ran them in."""
+    import torch
+    import heracles_amd as hx
+    from heracles_amd.distributed import ShardedTwoPoint
+    from heracles_amd.twopoint import alm2cl_pairs
+
+    nside, lmax, nbins, stride = 2048, 3072, 10, 96
+    npix = 12 * nside * nside
+    plan = hx.get_plan(nside, lmax)
+    nlm = plan.nlm
+    spins = [0] * nbins + [2] * nbins
+
+    def map_of(g):
+        gen = torch.Generator(device="cuda").manual_seed(5200 + g)
+        return torch.randn(((2,) if spins[g] else ()) + (npix,), dtype=torch.float64, device="cuda", generator=gen)
+
+    def transform_local(work):
+        a0, a2 = work.local_alm_views("cuda")
+        m0 = [map_of(g) for g in work.local_maps if spins[g] == 0]
+        m2 = [map_of(g) for g in work.local_maps if spins[g] == 2]
+        if m0:
+            plan.map2alm(torch.stack(m0), 0, out=a0)
+        if m2:
+            plan.map2alm(torch.stack(m2).view(2 * len(m2), npix), 2, out=a2.view(2 * len(m2), nlm))
+
+    single = ShardedTwoPoint(spins, 1, 0, nlm, lmax)
+    transform_local(single)
+    ref_rows = single.all_pairs_cl()
+    assert ref_rows.shape == (10 * 11 // 2 + 4 * 10 * 11 // 2 + 2 * 100, lmax + 1)
+    ref_alm = {g: single.buffer()[single.comps_of_map[g]].cpu().numpy() for g in (0, 13)}
+    del single
+    torch.cuda.empty_cache()
+
+    world = 8
+    ranks = [ShardedTwoPoint(spins, world, r, nlm, lmax) for r in range(world)]
+    shared = ranks[0].buffer("cuda")
+    rows = np.full_like(ref_rows, np.nan)
+    for w in ranks:
+        w._buf = shared
+        transform_local(w)
+    comps = [shared[k] for k in range(shared.shape[0])]
+    for w in ranks:
+        assert 2 <= len(w.local_maps) <= 3
+        rows[w.rows_of[w.rank]] = alm2cl_pairs(comps, w.my_cpairs, lmax)
+    assert not np.isnan(rows).any()
+    # other sweep shapes per owner (2-3 maps instead of 10): rounding differs, nothing else
+    np.testing.assert_allclose(rows, ref_rows, rtol=1e-9, atol=1e-13 * np.abs(ref_rows).max())
+    for g in (0, 13):
+        got = shared[ranks[0].comps_of_map[g]].cpu().numpy()
+        assert np.abs(got - ref_alm[g]).max() <= 1e-11 * np.abs(got).max()
+        m_host = map_of(g).cpu().numpy().reshape(-1, npix)
+        oracle.set_mstride(stride)
+        try:
+            ref = oracle.map2alm(m_host, nside, lmax, spin=spins[g])
+        finally:
+            oracle.set_mstride(1)
+        scale = np.abs(got).max()
+        for m in range(0, lmax + 1, stride):
+            base = m * (2 * lmax + 1 - m) // 2
+            sl = slice(base + m, base + lmax + 1)
+            assert np.abs(got[:, sl] - ref[:, sl]).max() <= 1e-10 * scale, (g, m)
