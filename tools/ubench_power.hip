@@ -143,6 +143,46 @@ int run_r1(const char *label, int bpc, double *d_out, Stamp *d_st, int cus)
     return 0;
 }
 
+// pure 16x16x4 stream on NACC accumulators in rotation (dependent-accumulate latency): 64 MFMAs per loop iteration
+template <int NACC>
+__global__ __launch_bounds__(256) void k_nacc(double *out, Stamp *st, int iters, const double *__restrict__ src)
+{
+    double4_t c[NACC];
+#pragma unroll
+    for (int u = 0; u < NACC; ++u) c[u] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a[u] = src[(threadIdx.x * 8 + u) & 4095]; b[u] = src[(threadIdx.x * 8 + u + 77) & 4095]; }
+    Stamp s;
+    s.t0 = __builtin_amdgcn_s_memtime(); s.r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 64; ++u) c[u % NACC] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u & 7], b[(u >> 3) & 7], c[u % NACC], 0, 0, 0);
+    }
+    s.t1 = __builtin_amdgcn_s_memtime(); s.r1 = __builtin_amdgcn_s_memrealtime();
+    double r = 0;
+#pragma unroll
+    for (int u = 0; u < NACC; ++u) r += c[u][0] + c[u][1] + c[u][2] + c[u][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) st[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 2047] = s;
+}
+
+template <int NACC>
+int run_nacc(double *d_out, Stamp *d_st, const double *d_src, int cus)
+{
+    const int iters = 1000;
+    for (int rep = 0; rep < 100; ++rep) hipLaunchKernelGGL((k_nacc<NACC>), dim3(cus), dim3(256), 0, 0, d_out, d_st, iters, d_src);
+    CK(hipDeviceSynchronize());
+    std::vector<Stamp> h(2048);
+    CK(hipMemcpy(h.data(), d_st, sizeof(Stamp) * 2048, hipMemcpyDeviceToHost));
+    std::vector<double> ticks;
+    for (int i = 0; i < cus * 4 && i < 2048; ++i) ticks.push_back((double)(h[i].t1 - h[i].t0) / (64.0 * iters));
+    std::sort(ticks.begin(), ticks.end());
+    printf("16x16x4 stream on %d accumulator(s) in rotation, one wave per SIMD: %6.1f ticks per MFMA\n", NACC, ticks[ticks.size() / 2]);
+    fflush(stdout);
+    return 0;
+}
+
 struct Res { double tf, ticks_per_mfma, ghz, ms; };
 
 template <int MODE, int NMF, int SLEEP>
@@ -188,6 +228,8 @@ int main()
     srand(50);
     for (auto &v : src) v = (rand() / (double)RAND_MAX - 0.5) * 1e-3;
     CK(hipMemcpy(d_src, src.data(), sizeof(double) * 4096, hipMemcpyHostToDevice));
+    if (run_nacc<1>(d_out, d_st, d_src, cus) || run_nacc<2>(d_out, d_st, d_src, cus) || run_nacc<3>(d_out, d_st, d_src, cus) ||
+        run_nacc<4>(d_out, d_st, d_src, cus) || run_nacc<8>(d_out, d_st, d_src, cus)) return 1;
     for (int bpc : {1, 2, 4}) {
         if (run_r1<1>("round-1 probe: one operand pair", bpc, d_out, d_st, cus)) return 1;
         if (run_r1<0>("round-1 probe: rotating operand pairs", bpc, d_out, d_st, cus)) return 1;

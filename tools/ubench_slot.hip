@@ -304,6 +304,94 @@ int runb(const char *label, double *d_out, unsigned long long *d_cyc, const doub
     return 0;
 }
 
+
+// MFMA-only, ordering experiment: within a block of PPB slot pairs, all MFMAs that accumulate into the SAME register run
+// back to back (ORD 1: group g / position p major; ORD 0: pair major, as k_slot)
+template <int NG, int NBX, int ORD, int PPB>
+__global__ __launch_bounds__(256, 1) void k_order(double *out, unsigned long long *cyc, int iters, const double *__restrict__ src)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double fr[16][2][NG > 0 ? NG : 1], frx[16][2][NBX > 0 ? NBX : 1], aq[16][2];
+#pragma unroll
+    for (int sp = 0; sp < 16; ++sp)
+#pragma unroll
+        for (int pos = 0; pos < 2; ++pos) {
+            aq[sp][pos] = src[(lane * 31 + sp * 3 + pos) & 4095];
+#pragma unroll
+            for (int g = 0; g < (NG > 0 ? NG : 1); ++g) fr[sp][pos][g] = src[(lane * 37 + sp * 5 + pos + g * 3) & 4095];
+#pragma unroll
+            for (int g = 0; g < (NBX > 0 ? NBX : 1); ++g) frx[sp][pos][g] = src[(lane * 41 + sp * 7 + pos + g) & 4095];
+        }
+    double4_t acc[NG > 0 ? NG : 1][2];
+    double accx[NBX > 0 ? NBX : 1][2];
+#pragma unroll
+    for (int g = 0; g < (NG > 0 ? NG : 1); ++g) acc[g][0] = acc[g][1] = (double4_t){0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < (NBX > 0 ? NBX : 1); ++g) accx[g][0] = accx[g][1] = 0;
+    const unsigned long long ts = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int blk = 0; blk < 16 / PPB; ++blk) {
+            if (ORD == 0) {
+#pragma unroll
+                for (int j = 0; j < PPB; ++j)
+#pragma unroll
+                    for (int pos = 0; pos < 2; ++pos) {
+                        const int sp = blk * PPB + j;
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acc[g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[sp][pos], fr[sp][pos][g], acc[g][pos], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < NBX; ++g) accx[g][pos] = __builtin_amdgcn_mfma_f64_4x4x4f64(aq[sp][pos], frx[sp][pos][g], accx[g][pos], 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int pos = 0; pos < 2; ++pos) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+#pragma unroll
+                        for (int j = 0; j < PPB; ++j) {
+                            const int sp = blk * PPB + j;
+                            acc[g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[sp][pos], fr[sp][pos][g], acc[g][pos], 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int g = 0; g < NBX; ++g)
+#pragma unroll
+                        for (int j = 0; j < PPB; ++j) {
+                            const int sp = blk * PPB + j;
+                            accx[g][pos] = __builtin_amdgcn_mfma_f64_4x4x4f64(aq[sp][pos], frx[sp][pos][g], accx[g][pos], 0, 0, 0);
+                        }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long te = __builtin_amdgcn_s_memtime();
+    double r = 0;
+#pragma unroll
+    for (int g = 0; g < (NG > 0 ? NG : 1); ++g) r += acc[g][0][0] + acc[g][0][1] + acc[g][0][2] + acc[g][0][3] + acc[g][1][0] + acc[g][1][1] + acc[g][1][2] + acc[g][1][3];
+#pragma unroll
+    for (int g = 0; g < (NBX > 0 ? NBX : 1); ++g) r += accx[g][0] + accx[g][1];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+    if (lane == 0) cyc[blockIdx.x * 4 + w] = te - ts;
+}
+
+template <int NG, int NBX, int ORD, int PPB>
+int runo(double *d_out, unsigned long long *d_cyc, const double *d_src, int cus)
+{
+    const int iters = 2000;
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k_order<NG, NBX, ORD, PPB>), dim3(cus), dim3(256), 0, 0, d_out, d_cyc, iters, d_src);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(cus * 4);
+    CK(hipMemcpy(h.data(), d_cyc, sizeof(unsigned long long) * cus * 4, hipMemcpyDeviceToHost));
+    std::sort(h.begin(), h.end());
+    const double ideal = 2.0 * (NG * 64.0 + NBX * 16.0);
+    const double per = (double)h[h.size() / 2] / (iters * 16.0);
+    printf("ORDER NG %d NBX %d  %s, blocks of %d pairs: %7.1f cycles per pair (MFMA alone %5.0f)  %5.1f %%\n", NG, NBX,
+           ORD ? "accumulator-major" : "pair-major       ", PPB, per, ideal, 100.0 * ideal / per);
+    fflush(stdout);
+    return 0;
+}
+
 template <int NG, int NBX, int MODE, int PF>
 int runp(const char *label, double *d_out, unsigned long long *d_cyc, const double *d_src, int cus)
 {
@@ -372,6 +460,10 @@ int main()
     R(0, 0, 31, 2, "recursion alone");
     R(0, 0, 31, 4, "recursion alone PF 4");
     R(0, 0, 24, 2, "FMAs alone");
+    if (runo<1, 1, 0, 4>(d_out, d_cyc, d_src, cus) || runo<1, 1, 1, 4>(d_out, d_cyc, d_src, cus) || runo<1, 1, 1, 8>(d_out, d_cyc, d_src, cus) ||
+        runo<1, 1, 1, 16>(d_out, d_cyc, d_src, cus) || runo<2, 0, 0, 4>(d_out, d_cyc, d_src, cus) || runo<2, 0, 1, 4>(d_out, d_cyc, d_src, cus) ||
+        runo<1, 0, 0, 4>(d_out, d_cyc, d_src, cus) || runo<1, 0, 1, 4>(d_out, d_cyc, d_src, cus) || runo<0, 2, 0, 4>(d_out, d_cyc, d_src, cus) ||
+        runo<0, 2, 1, 4>(d_out, d_cyc, d_src, cus)) return 1;
 #define RB(NG, NBX, HB, PF, L) if (runb<NG, NBX, HB, PF>(L, d_out, d_cyc, d_src, cus)) return 1
     RB(1, 1, 16, 2, "");
     RB(1, 1, 32, 2, "");
