@@ -526,6 +526,12 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     __shared__ double tileB[NW][2048];         // set 1; doubles as the D staging area of the flush
     __shared__ double2 coefs[NCR][2][LBLK];    // recursion coefficients, block j in slot j % NCR; [1] = sign of q' flipped (spin 2)
     __shared__ double alphas[NAR][LBLK];       // output scalings alpha_l, block j in slot j % NAR
+    // Spin 2, one column group, one block per flush: the D tiles are staged in an area of their own (20 KiB beside the
+    // 128 KiB of tiles), so that the waves need not meet again after the reduction: its LDS reads, additions and partial-sum
+    // stores ride in the first stage of the next block (DEFER: -2 % on one device; the spin-0 kernel has no 16 registers
+    // to carry the operands across a vector block: 49 spilled, +20 %).
+    constexpr bool DEFER = SPIN == 2 && NG == 1 && NSUB == 1 && !(HX_PIPE_ABL & 64);
+    __shared__ double dstage[DEFER ? NW * DSZ : 2];
     const PlanDev &P = A.P;
     const LegTask task = A.tasks[blockIdx.x];
     const int m = task.m, lmax = P.lmax;
@@ -636,6 +642,49 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         vc[S][c] = vn;
         return cur;
     };
+    // flush roles of this thread: D values arrive as 16-byte chunks (col, chunk c): rows (c >> 1) + 8 (c & 1) and + 4
+    const int fcol = threadIdx.x & 15, fch = (threadIdx.x >> 4) & 7, fpos = (threadIdx.x >> 7) & 1;
+    const int frow = (fch >> 1) + 8 * (fch & 1);
+    // partial rows this thread writes: (group columns) rows 2 frow + fpos and + 8 of the block; (extra blocks) rows 2 qrow, + 1
+    const int qrow = threadIdx.x / (4 * NXA), qcol = threadIdx.x % (4 * NXA);
+    double *pgrp = A.partial + (task.pout - A.row0 + 2 * frow + fpos) * A.ncol + fcol;
+    double *pquad = A.partial + (task.pout - A.row0 + 2 * qrow) * A.ncol + NG * NCOL + qcol;
+    // deferred reduction (DEFER): operands of the group columns, then of the 4-column blocks, in the same registers
+    double2 s4[NW];
+    bool pend = false;
+    int pend_slot = 0;
+    double al0 = 0.0, al1 = 0.0;  // alpha_l of the two rows, read with the operands
+    auto red_issue_group = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww)
+            s4[ww] = *reinterpret_cast<const double2 *>(dstage + ww * DSZ + fpos * 256 + fcol * 16 + ((fch ^ (fcol & 7)) * 2));
+        al0 = alphas[pend_slot][2 * frow + fpos];
+        al1 = alphas[pend_slot][2 * frow + 8 + fpos];
+    };
+    auto red_finish_group = [&]() __attribute__((always_inline)) {
+        const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
+        pgrp[0] = sx * al0;
+        pgrp[8 * (long long)A.ncol] = sy * al1;
+        pgrp += (long long)LBLK * A.ncol;
+    };
+    auto red_issue_quad = [&]() __attribute__((always_inline)) {
+        if (NBX > 0 && threadIdx.x < 64 * NBX) {
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(dstage + ww * DSZ + DQ0 + threadIdx.x * 2);
+            const double2 a2 = *reinterpret_cast<const double2 *>(&alphas[pend_slot][2 * qrow]);
+            al0 = a2.x;
+            al1 = a2.y;
+        }
+    };
+    auto red_finish_quad = [&]() __attribute__((always_inline)) {
+        if (NBX > 0 && threadIdx.x < 64 * NBX) {
+            const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
+            pquad[0] = sx * al0;
+            pquad[A.ncol] = sy * al1;
+        }
+        pquad += (long long)LBLK * A.ncol;
+        pend = false;
+    };
     double4_t accs[NSUB][NGA][2];
     double accxs[NSUB][NXA][2];
     // ---- a stage: MFMAs of set SM (if MF) and the recursion of the other set (mode RM).
@@ -647,7 +696,7 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     //      HB coefficients and of the A operands]                                                 (32 / HB times).
     // cq = coefficients of the next 16 recursion steps, whatever set / block they belong to. ----
 #if HX_PIPE_ABL & 8
-    // cycle accounting (diagnostic build): [0] prologue, [1] MFMA || live recursion, [2] MFMA || dead / no recursion,
+    // cycle accounting (diagnostic build): [0] prologue + MFMA || mixed recursion, [1] MFMA || all-live recursion, [2] MFMA || dead / no recursion,
     // [3] live recursion alone, [4] dead recursion alone, [5] flush up to the first barrier, [6] reduction + second barrier;
     // [8 + i] = number of intervals of kind i
     unsigned long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -692,6 +741,9 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
                     cur[k] = rec_step(ISR{}, IRM{}, SPIN == 0 ? ((kk & 1) ? NCH - 1 : 0) : 0, SPIN == 0 ? kk >> 1 : kk, cq[k]);
                 }
             }
+            // deferred reduction of the previous flush: operands were read from the staging area one matrix block ago
+            if (DEFER && SM == 0 && h == 1 && pend) red_finish_group();
+            if (DEFER && SM == 0 && h == 2 && pend) red_finish_quad();
             __builtin_amdgcn_sched_barrier(0);
 #if HX_PIPE_ABL & 16
             if (MF && RM >= 2) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); cyc_v += tn_ - tin; tin = tn_; }
@@ -728,6 +780,10 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
                         for (int g = 1; g < NG; ++g) acc[g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[SM][sp][pos][g], acc[g][pos], 0, 0, 0);
 #pragma unroll
                         for (int g = 0; g < NBX; ++g) accx[g][pos] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[SM][sp][pos][g], accx[g][pos], 0, 0, 0);
+                    }
+                    if (DEFER && SM == 0 && pos == 1 && j == PPB - 2 && pend) {
+                        if (h == 0) red_issue_group();  // into registers the stored recursion values have left
+                        if (h == 1) red_issue_quad();
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -768,7 +824,7 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         }
     };
 
-    auto kind_of = [](bool mf, int rm) __attribute__((always_inline)) { return mf ? (rm >= 2 ? 1 : 2) : (rm >= 2 ? 3 : 4); };
+    auto kind_of = [](bool mf, int rm) __attribute__((always_inline)) { return mf ? (rm == 3 ? 1 : (rm == 2 ? 0 : 2)) : (rm >= 2 ? 3 : 4); };
     (void)kind_of;
     HX_STAMP(0);
     // ---- prologue: recursion of (set 0, block 0) ----
@@ -780,9 +836,6 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         tl_live[0] = rm >= 2 || (HX_PIPE_ABL & 2);
         run_stage(I0{}, I1{}, false, rm, &coefs[0][0][0], &coefs[0][0][0]);  // "MFMA set 1" off: only the recursion of set 0
     }
-    // flush roles of this thread: D values arrive as 16-byte chunks (col, chunk c): rows (c >> 1) + 8 (c & 1) and + 4
-    const int fcol = threadIdx.x & 15, fch = (threadIdx.x >> 4) & 7, fpos = (threadIdx.x >> 7) & 1;
-    const int frow = (fch >> 1) + 8 * (fch & 1);
     // Global loads of the hand-over (threads < 128: coefficient doubles; threads 128..159: alpha_l) are issued inside the
     // flush BEFORE the one that stores them to LDS, and IN FRONT of that flush's partial-sum stores: vmcnt retires in order,
     // so a load issued behind the stores could not be waited for without waiting for those stores to reach HBM, and a use
@@ -799,10 +852,6 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         }
     };
     prefetch(0);
-    // partial rows this thread writes: (group columns) rows 2 frow + fpos and + 8 of the block; (extra blocks) rows 2 qrow, + 1
-    const int qrow = threadIdx.x / (4 * NXA), qcol = threadIdx.x % (4 * NXA);
-    double *pgrp = A.partial + (task.pout - A.row0 + 2 * frow + fpos) * A.ncol + fcol;
-    double *pquad = A.partial + (task.pout - A.row0 + 2 * qrow) * A.ncol + NG * NCOL + qcol;
     auto block = [&](auto SUBB, int bb) __attribute__((always_inline)) {
         constexpr int SUB = decltype(SUBB)::value;
 #pragma unroll
@@ -847,9 +896,10 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         // conflict-free through the swizzle);  D of v_mfma_f64_4x4x4_4b: lane (i = lane>>4, blk = (lane>>2)&3, j = lane&3) =
         // row 4 blk + i, column j: both positions in one 16-byte store at  DQ0 + ((row 4 NBX + 4 x + j) 2); sub-block sub at + sub DSZ
         const bool two = NSUB > 1 && b + 1 < nblk;
+        if (DEFER) lds_barrier();  // every wave has read the staging area of the previous flush
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
-            double *dt = &tileB[w][0] + sub * DSZ;
+            double *dt = DEFER ? dstage + w * DSZ : &tileB[w][0] + sub * DSZ;
 #pragma unroll
             for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -871,6 +921,12 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         lds_barrier();
         HX_STAMP(5);
         prefetch(b + NSUB);
+        if (DEFER) {
+            pend = true;
+            pend_slot = b % NAR;
+            HX_STAMP(7);
+            continue;
+        }
         // (rows of a task are padded to whole 32-l blocks: no bounds tests within a block)
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
@@ -902,6 +958,12 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         HX_STAMP(7);
         lds_barrier();  // D tiles consumed: tileB may be overwritten by the recursion of the next stage
         HX_STAMP(6);
+    }
+    if (DEFER && pend) {
+        red_issue_group();
+        red_finish_group();
+        red_issue_quad();
+        red_finish_quad();
     }
 #if HX_PIPE_ABL & 8
     if (lane == 0 && A.counters)
@@ -1314,9 +1376,9 @@ static int build_task_set(hx_plan *pl, int spin, int nw, hx_plan::TaskSet &ts)
     return HX_OK;
 }
 
-// 32-l blocks per flush of the pipelined kernel: two for spin 2 (-0.7 %), one for spin 0 (two spill 16 registers: +5.7 %);
-// measured on one device, HX_PIPE_NSUB = 1 / 2 overrides (a tuning knob, read once: every partial row is the same
-// fixed-order sum either way, the results are bit-identical)
+// 32-l blocks per flush of the pipelined kernel: one (the reduction of a flush then rides in the next block's first stage);
+// HX_PIPE_NSUB = 2 selects the two-block flush through the wave's second tile (a tuning knob, read once: every partial
+// row is the same fixed-order sum either way, the results are bit-identical)
 static int pipe_nsub(int spin)
 {
     static int v = -1;
@@ -1324,7 +1386,8 @@ static int pipe_nsub(int spin)
         const char *e = getenv("HX_PIPE_NSUB");
         v = e ? atoi(e) : 0;
     }
-    return v == 1 || v == 2 ? v : (spin ? 2 : 1);
+    (void)spin;
+    return v == 2 ? 2 : 1;
 }
 
 template <int SPIN>
@@ -1393,7 +1456,7 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
             HX_HIP(hipStreamSynchronize(st));
             HX_HIP(hipMemcpy(hc, pl->d_dbg.p, 144, hipMemcpyDeviceToHost));
             if (hc[9]) fprintf(stderr, "[hx] pipe spin %d: per mfma||rec stage: vector blocks %.1f cycles, matrix blocks %.1f\n", SPIN, (double)hc[16] / hc[9], (double)hc[17] / hc[9]);
-            const char *nm[8] = {"prologue", "mfma||rec", "mfma||dead", "rec alone", "dead alone", "flush->bar1", "bar2 wait", "reduce"};
+            const char *nm[8] = {"mfma||mixed", "mfma||live", "mfma||dead", "rec alone", "dead alone", "flush->bar1", "bar2 wait", "reduce"};
             double tot = 0;
             for (int i = 0; i < 8; ++i) tot += (double)hc[i];
             for (int i = 0; i < 8; ++i)
