@@ -8,7 +8,7 @@ include/hxsht.h).  There is no CPU fallback.
 from . import _lib
 from ._lib import HxError, device_count, init, synchronize
 from .core import DeviceArray, Result, TocDict, toc_match, update_metadata
-from .discrete import HipDiscreteMapper, alm_resample
+from .discrete import HipDiscreteMapper, PointSHT, alm_resample, get_point_sht
 from .jackknife import RegionAlms, jackknife_cls, region_alms
 from .mapper import HipHealpixMapper
 from .sht import Plan, get_plan
@@ -26,7 +26,7 @@ from .twopoint import (
 from .unmixing import naturalspice
 
 __all__ = [
-    "HipHealpixMapper", "HipDiscreteMapper", "alm_resample", "Plan", "get_plan", "HxError", "init", "device_count", "synchronize",
+    "HipHealpixMapper", "HipDiscreteMapper", "PointSHT", "get_point_sht", "alm_resample", "Plan", "get_plan", "HxError", "init", "device_count", "synchronize",
     "alm2cl", "alm2cl_pairs", "alm2lmax", "angular_power_spectra", "debias_cls",
     "mixing_matrices", "mixmat", "mixmat_eb", "cl2corr", "corr2cl", "gauss_legendre",
     "wigner_d_table", "naturalspice", "Result", "TocDict", "toc_match", "update_metadata", "DeviceArray",

@@ -29,6 +29,7 @@ SYMBOLS = (
     "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_set_scratch_budget", "hx_plan_last_chunks", "hx_plan_mfma_flops", "hx_plan_executed_flops", "hx_measure_peaks", "hx_measured_mfma_clock", "hx_map2alm", "hx_alm2map",
     "hx_alm2cl_pairs", "hx_gauss_legendre", "hx_wigner_d_table", "hx_mixmat",
     "hx_mixmat_eb", "hx_mixmat_batch", "hx_mixctx_create", "hx_mixctx_apply", "hx_mixctx_destroy", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_alm_resample", "hx_region_maps", "hx_alm_subtract", "hx_fits_unpack_f64", "hx_fits_pack_f64",
+    "hx_pointsht_create", "hx_pointsht_destroy", "hx_pointsht_info", "hx_pointsht_adjoint",
 )
 
 
@@ -104,6 +105,12 @@ def load():
         L.hx_alm_subtract.argtypes = [C.c_int64, dp, i, vp, dp]
         L.hx_fits_unpack_f64.argtypes = [C.c_int64, i, i, C.c_int64, C.c_int64, C.c_int64, dp, dp]
         L.hx_fits_pack_f64.argtypes = [C.c_int64, i, i, C.c_int64, C.c_int64, C.c_int64, dp, dp]
+        L.hx_pointsht_create.argtypes = [i, C.c_double]
+        L.hx_pointsht_create.restype = vp
+        L.hx_pointsht_destroy.argtypes = [vp]
+        L.hx_pointsht_destroy.restype = None
+        L.hx_pointsht_info.argtypes = [vp, C.POINTER(C.c_int)]
+        L.hx_pointsht_adjoint.argtypes = [vp, i, i, C.c_int64, dp, dp, dp]
         L.hx_timer_stop.argtypes = [C.POINTER(C.c_float)]
         L.hx_profile_get.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         _lib = L

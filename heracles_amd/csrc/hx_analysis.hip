@@ -76,6 +76,16 @@ __device__ inline double2 ring_mode(const PlanDev &P, const double2 *__restrict_
 __device__ inline void ring_modes_ns(const PlanDev &P, const double2 *__restrict__ Y, int c, int rp, int m,
                                      double w, double2 &FN, double2 &FS)
 {
+    if (P.hsrc) {
+        // equiangular rings theta_j = 2 pi (j + 1/2) / N of the point transform: the spectrum h_m is given on the full circle,
+        // lambda_lm(2 pi - theta) = (-1)^m lambda_lm(theta) (both spins) folds the second half onto the rings
+        const double2 *h = P.hsrc + (long long)c * P.hsrc_stride + (long long)m * P.hN;
+        const double sg = (m & 1) ? -w : w;
+        const double2 a = h[rp], b = h[P.hN - 1 - rp], cN = h[P.hN / 2 - 1 - rp], d = h[P.hN / 2 + rp];
+        FN = make_double2(w * a.x + sg * b.x, w * a.y + sg * b.y);
+        FS = make_double2(w * cN.x + sg * d.x, w * cN.y + sg * d.y);
+        return;
+    }
     const int n = P.nsub[rp];
     const int nphi = 4 * n;
     const int mm = m % nphi, mc = (nphi - mm) % nphi;
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double
     const int slot = threadIdx.x & 7;
     if (rp >= P.nrp_pad) return;
     const bool live = rp < P.nrp;
-    const double w = live ? (rw ? rw[rp] : 1.0) * (4.0 * M_PI / (double)P.npix) : 0.0;
+    const double w = live ? (rw ? rw[rp] : 1.0) * P.wnorm : 0.0;
     double *row = F + (((long long)blockIdx.x * P.nrp_pad + rp) * 2) * NOP * ncol;
     for (int g = 0; g < ng; ++g) {
         if (SPIN == 0) {
@@ -1498,8 +1508,10 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     if (half) HX_TRY(build_task_set(pl, 0, HX_QNW0, pl->ts[2]));
     hx_plan::TaskSet &ts = half ? pl->ts[2] : pl->ts[sidx];
     const int ncol = sh.ncol;
-    HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
-    HX_TRY(launch_ring_subdft_maps(pl, nb, d_maps, d_pw, pl->Y.as<double2>()));
+    if (pl->hsrc == nullptr) {
+        HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
+        HX_TRY(launch_ring_subdft_maps(pl, nb, d_maps, d_pw, pl->Y.as<double2>()));
+    }
 
     // budget: hx_set_scratch_budget() / HX_SCRATCH_GB, else 64 GB but never more than half of what is free on
     // the device (what this plan already holds for F / partial counts as free)

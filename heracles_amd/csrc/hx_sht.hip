@@ -93,50 +93,6 @@ __global__ void k_init_norm2(int lmax, double2 *__restrict__ coef, double *__res
     }
 }
 
-// In-LDS FFT drivers (all threads of the block participate): fused radix-4 stages, plus one
-// radix-2 stage when log2(M) is odd.  Same data layout / bit-reversed order as pure radix-2
-// (tests/csrc/test_fft_core.cpp runs this exact schedule on the host).
-template <class TW>
-__device__ inline void lds_fft_dif(double2 *buf, int M, TW tw, int twN)
-{
-    int h = M >> 1;
-    if (ilog2(M) & 1) {
-        for (int i = threadIdx.x; i < (M >> 1); i += blockDim.x) dif_butterfly(buf, i, h, tw, twN);
-        __syncthreads();
-        h >>= 1;
-    }
-    for (h >>= 1; h >= 1; h >>= 2) {
-        for (int i = threadIdx.x; i < (M >> 2); i += blockDim.x) dif4_butterfly(buf, i, h, tw, twN);
-        __syncthreads();
-    }
-}
-template <class TW>
-__device__ inline void lds_fft_dit_inv(double2 *buf, int M, TW tw, int twN)
-{
-    int h = 1;
-    for (; 4 * h <= M; h <<= 2) {
-        for (int i = threadIdx.x; i < (M >> 2); i += blockDim.x) dit4_inv_butterfly(buf, i, h, tw, twN);
-        __syncthreads();
-    }
-    if (2 * h <= M) {
-        for (int i = threadIdx.x; i < (M >> 1); i += blockDim.x) dit_inv_butterfly(buf, i, h, tw, twN);
-        __syncthreads();
-    }
-}
-
-// Fills the factored twiddle tables of TwFactored from the plan's full table (twN/2 entries).
-// LDS: hi[twN/128], lo[64].  The caller synchronises before the first butterfly.
-constexpr int TW_HI_MAX = 128;  // twN <= 16384
-__device__ inline TwFactored load_tw_factored(double2 *hi, double2 *lo, const double2 *__restrict__ tw, int twN)
-{
-    for (int i = threadIdx.x; i < (twN >= 128 ? twN / 128 : 1); i += blockDim.x) hi[i] = tw[i * 64];  // hi[0] = 1
-    for (int i = threadIdx.x; i < 64; i += blockDim.x) lo[i] = tw[i];
-    TwFactored f;
-    f.hi = hi;
-    f.lo = lo;
-    return f;
-}
-
 // Bluestein filter spectra, one block per ring pair whose sub-length is not a power of two
 // and is the first ring with that length.
 __global__ __launch_bounds__(512) void k_init_bhat(PlanDev P, const int *__restrict__ rp_list,
@@ -489,6 +445,7 @@ PlanDev hx_plan::dev() const
     P.tw = tw.as<double2>(); P.bhat = bhat.as<double2>();
     P.mfac = mfac.as<double>(); P.kfac2 = kfac2.as<double>();
     P.rec0 = nullptr; P.rec2 = nullptr;
+    P.wnorm = wnorm; P.hsrc = hsrc; P.hsrc_stride = hsrc_stride; P.hN = eqN;
     return P;
 }
 
@@ -500,6 +457,51 @@ extern "C" int hx_set_max_lds_fft(int points)
 {
     if (points < 16 || points > 8192 || (points & (points - 1))) return fail(HX_ERR_ARG, "hx_set_max_lds_fft: a power of two in [16, 8192]");
     g_lds_fft_cap = points;
+    return HX_OK;
+}
+
+// Tables that depend on the band limit only (twiddles of the in-LDS FFT, seeds and coefficients of the recursions) and the
+// kernel attributes: shared by the HEALPix plan and the equiangular plan of the point transform (hx_nufft.hip).
+static int plan_tables(hx_plan *pl)
+{
+    const int lmax = pl->lmax;
+    std::vector<double2> tw(std::max(pl->twN / 2, 64));  // load_tw_factored copies 64 entries whatever twN
+    for (int k = 0; k < (int)tw.size(); ++k) {
+        long double a = -2.0L * 3.141592653589793238462643383279502884L * k / pl->twN;
+        tw[k].x = (double)cosl(a); tw[k].y = (double)sinl(a);
+    }
+    // mfac[m] = (-1)^m sqrt((2m+1)/(4pi) prod_{k<=m} (2k-1)/(2k));  kfac2[m] = K_m 2^-(m-2)
+    std::vector<double> mfac(lmax + 1), kfac2(lmax + 3, 0.0);
+    {
+        long double p = 1.0L;
+        for (int m = 0; m <= lmax; ++m) {
+            if (m > 0) p *= (2.0L * m - 1.0L) / (2.0L * m);
+            long double v = sqrtl((2.0L * m + 1.0L) / (4.0L * 3.141592653589793238462643383279502884L) * p);
+            mfac[m] = (double)((m & 1) ? -v : v);
+        }
+        long double k = 1.0L;
+        for (int m = 2; m <= lmax + 2; ++m) {
+            if (m > 2) k *= sqrtl((2.0L * m) * (2.0L * m - 1.0L) / ((m - 2.0L) * (m + 2.0L))) / 2.0L;
+            kfac2[m] = (double)k;
+        }
+    }
+    HX_TRY(upload(pl->tw, tw));
+    HX_TRY(upload(pl->mfac, mfac));
+    HX_TRY(upload(pl->kfac2, kfac2));
+    hipStream_t st = rt().stream;
+    HX_TRY(pl->cn0.alloc(sizeof(double2) * (pl->nlm + TABLE_PAD)));
+    HX_TRY(pl->al0.alloc(sizeof(double) * (pl->nlm + TABLE_PAD)));
+    HX_HIP(hipMemsetAsync(pl->cn0.p, 0, sizeof(double2) * (pl->nlm + TABLE_PAD), st));
+    HX_HIP(hipMemsetAsync(pl->al0.p, 0, sizeof(double) * (pl->nlm + TABLE_PAD), st));
+    hipLaunchKernelGGL(k_init_norm0, dim3((2 * (lmax + 1) + 63) / 64), dim3(64), 0, st, lmax, pl->cn0.as<double2>(), pl->al0.as<double>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_bhat), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // 3 KiB of the 160 KiB are the static factored-twiddle tables of k_ring_subdft
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_bhat_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft_split<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft_split<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    HX_HIP(hipGetLastError());
     return HX_OK;
 }
 
@@ -516,6 +518,7 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
     pl->nrp = 2 * nside;
     pl->nrp_pad = (pl->nrp + 63) / 64 * 64;
     pl->nlm = (long long)(lmax + 1) * (lmax + 2) / 2;
+    pl->wnorm = 4.0 * M_PI / (double)pl->npix;
     const long long ns = nside, ncap = 2 * ns * (ns - 1);
     std::vector<double> z(pl->nrp), omz(pl->nrp), sth(pl->nrp), rw(pl->nrp, 1.0);
     std::vector<int> nsub(pl->nrp), shifted(pl->nrp);
@@ -582,49 +585,14 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
             boff[rp] = it->second;
         }
     }
-    std::vector<double2> tw(pl->twN / 2);
-    for (int k = 0; k < pl->twN / 2; ++k) {
-        long double a = -2.0L * 3.141592653589793238462643383279502884L * k / pl->twN;
-        tw[k].x = (double)cosl(a); tw[k].y = (double)sinl(a);
-    }
-    // mfac[m] = (-1)^m sqrt((2m+1)/(4pi) prod_{k<=m} (2k-1)/(2k));  kfac2[m] = K_m 2^-(m-2)
-    std::vector<double> mfac(lmax + 1), kfac2(lmax + 3, 0.0);
-    {
-        long double p = 1.0L;
-        for (int m = 0; m <= lmax; ++m) {
-            if (m > 0) p *= (2.0L * m - 1.0L) / (2.0L * m);
-            long double v = sqrtl((2.0L * m + 1.0L) / (4.0L * 3.141592653589793238462643383279502884L) * p);
-            mfac[m] = (double)((m & 1) ? -v : v);
-        }
-        long double k = 1.0L;
-        for (int m = 2; m <= lmax + 2; ++m) {
-            if (m > 2) k *= sqrtl((2.0L * m) * (2.0L * m - 1.0L) / ((m - 2.0L) * (m + 2.0L))) / 2.0L;
-            kfac2[m] = (double)k;
-        }
-    }
     int rc = HX_OK;
     auto chk = [&](int r) { if (rc == HX_OK) rc = r; };
     chk(upload(pl->z, z)); chk(upload(pl->omz, omz)); chk(upload(pl->sth, sth)); chk(upload(pl->rwdef, rw));
     chk(upload(pl->nsub, nsub)); chk(upload(pl->shifted, shifted));
     chk(upload(pl->startN, sN)); chk(upload(pl->startS, sS)); chk(upload(pl->bhat_off, boff));
-    chk(upload(pl->tw, tw)); chk(upload(pl->mfac, mfac)); chk(upload(pl->kfac2, kfac2));
     chk(pl->bhat.alloc(sizeof(double2) * std::max<long long>(btot, 1)));
-    if (rc != HX_OK) { delete pl; return nullptr; }
+    if (rc != HX_OK || plan_tables(pl) != HX_OK) { delete pl; return nullptr; }
     hipStream_t st = rt().stream;
-    if (pl->cn0.alloc(sizeof(double2) * (pl->nlm + TABLE_PAD)) != HX_OK || pl->al0.alloc(sizeof(double) * (pl->nlm + TABLE_PAD)) != HX_OK) {
-        delete pl;
-        return nullptr;
-    }
-    (void)hipMemsetAsync(pl->cn0.p, 0, sizeof(double2) * (pl->nlm + TABLE_PAD), st);
-    (void)hipMemsetAsync(pl->al0.p, 0, sizeof(double) * (pl->nlm + TABLE_PAD), st);
-    hipLaunchKernelGGL(k_init_norm0, dim3((2 * (lmax + 1) + 63) / 64), dim3(64), 0, st, lmax, pl->cn0.as<double2>(), pl->al0.as<double>());
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_bhat), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    // 3 KiB of the 160 KiB are the static factored-twiddle tables of k_ring_subdft
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_bhat_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft_split<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft_split<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     if (!blu_list.empty()) {
         DevBuf d_list;
         if (upload(d_list, blu_list) != HX_OK) { delete pl; return nullptr; }
@@ -644,6 +612,38 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
         delete pl;
         return nullptr;
     }
+    return pl;
+}
+
+// Plan of the Legendre stages on N / 2 equidistant rings theta_j = 2 pi (j + 1/2) / N, j < N / 2 (N a multiple of 4): ring pair
+// r < N / 4 = (theta_r, pi - theta_r), pole -> equator like the HEALPix pairs.  It has no pixels: its ring spectra h_m(theta_j)
+// come from the non-uniform Fourier stage of the point transform (hx_nufft.hip), which owns the plan.
+hx_plan *hx::plan_create_equiangular(int N, int lmax)
+{
+    if (N < 4 || (N & 3) || lmax < 0 || 2 * lmax + 1 >= N) {
+        set_error("equiangular plan: N=%d lmax=%d", N, lmax);
+        return nullptr;
+    }
+    hx_plan *pl = new hx_plan;
+    pl->nside = 0; pl->lmax = lmax; pl->max_comp = 16;
+    pl->npix = 0; pl->ny = 0;
+    pl->eqN = N;
+    pl->wnorm = 1.0 / N;
+    pl->nrp = N / 4;
+    pl->nrp_pad = (pl->nrp + 63) / 64 * 64;
+    pl->nlm = (long long)(lmax + 1) * (lmax + 2) / 2;
+    std::vector<double> z(pl->nrp), omz(pl->nrp), sth(pl->nrp), rw(pl->nrp, 1.0);
+    for (int r = 0; r < pl->nrp; ++r) {
+        const long double t = 2.0L * 3.141592653589793238462643383279502884L * (r + 0.5L) / N;
+        const long double sh = sinl(0.5L * t);
+        z[r] = (double)cosl(t); omz[r] = (double)(2.0L * sh * sh); sth[r] = (double)sinl(t);
+    }
+    pl->h_sth = sth; pl->h_z = z;
+    pl->twN = 2;
+    int rc = HX_OK;
+    auto chk = [&](int r) { if (rc == HX_OK) rc = r; };
+    chk(upload(pl->z, z)); chk(upload(pl->omz, omz)); chk(upload(pl->sth, sth)); chk(upload(pl->rwdef, rw));
+    if (rc != HX_OK || plan_tables(pl) != HX_OK || hipStreamSynchronize(rt().stream) != hipSuccess) { delete pl; return nullptr; }
     return pl;
 }
 
@@ -730,6 +730,7 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
 static int check_sht_args(hx_plan *pl, int spin, int ncomp, const void *a, const void *b)
 {
     if (!pl || !a || !b) return fail(HX_ERR_ARG, "null plan or buffer");
+    if (pl->nside < 1) return fail(HX_ERR_ARG, "not a HEALPix plan");
     if (spin != 0 && spin != 2) return fail(HX_ERR_UNSUPPORTED, "spin-%d maps not yet supported", spin);
     if (ncomp < 1 || (spin == 2 && (ncomp & 1))) return fail(HX_ERR_ARG, "bad component count %d for spin %d", ncomp, spin);
     return HX_OK;

@@ -44,6 +44,10 @@ struct PlanDev {
     const double *mfac, *kfac2;
     const double2 *rec0;
     const double4 *rec2;
+    double wnorm;              // quadrature normalisation of a ring value: 4 pi / npix (HEALPix), 1 / N (equiangular rings)
+    const double2 *hsrc;       // equiangular plan: ring spectra h_m(theta_j) [component][m][N] of the current call, else null
+    long long hsrc_stride;
+    int hN;
 };
 
 __host__ __device__ inline long long almidx(int lmax, int l, int m)
@@ -120,6 +124,54 @@ __device__ inline void spin2_seeds(int m, double sth, double omx, double kfac2m,
     snorm_small(sm);
 }
 
+#ifdef __HIPCC__
+using namespace hxfft;
+// In-LDS FFT drivers (all threads of the block participate): fused radix-4 stages, plus one
+// radix-2 stage when log2(M) is odd.  Same data layout / bit-reversed order as pure radix-2
+// (tests/csrc/test_fft_core.cpp runs this exact schedule on the host).
+template <class TW>
+__device__ inline void lds_fft_dif(double2 *buf, int M, TW tw, int twN)
+{
+    int h = M >> 1;
+    if (ilog2(M) & 1) {
+        for (int i = threadIdx.x; i < (M >> 1); i += blockDim.x) dif_butterfly(buf, i, h, tw, twN);
+        __syncthreads();
+        h >>= 1;
+    }
+    for (h >>= 1; h >= 1; h >>= 2) {
+        for (int i = threadIdx.x; i < (M >> 2); i += blockDim.x) dif4_butterfly(buf, i, h, tw, twN);
+        __syncthreads();
+    }
+}
+template <class TW>
+__device__ inline void lds_fft_dit_inv(double2 *buf, int M, TW tw, int twN)
+{
+    int h = 1;
+    for (; 4 * h <= M; h <<= 2) {
+        for (int i = threadIdx.x; i < (M >> 2); i += blockDim.x) dit4_inv_butterfly(buf, i, h, tw, twN);
+        __syncthreads();
+    }
+    if (2 * h <= M) {
+        for (int i = threadIdx.x; i < (M >> 1); i += blockDim.x) dit_inv_butterfly(buf, i, h, tw, twN);
+        __syncthreads();
+    }
+}
+
+// Fills the factored twiddle tables of TwFactored from the plan's full table (twN/2 entries).
+// LDS: hi[twN/128], lo[64].  The caller synchronises before the first butterfly.
+constexpr int TW_HI_MAX = 128;  // twN <= 16384
+__device__ inline TwFactored load_tw_factored(double2 *hi, double2 *lo, const double2 *__restrict__ tw, int twN)
+{
+    for (int i = threadIdx.x; i < (twN >= 128 ? twN / 128 : 1); i += blockDim.x) hi[i] = tw[i * 64];  // hi[0] = 1
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) lo[i] = tw[i];
+    TwFactored f;
+    f.hi = hi;
+    f.lo = lo;
+    return f;
+}
+
+#endif
+
 template <class T>
 inline int upload(DevBuf &b, const std::vector<T> &v)
 {
@@ -135,6 +187,10 @@ struct hx_plan {
     int nrp = 0, nrp_pad = 0, twN = 1;
     int fft_cap = 8192;   // longest in-LDS FFT of this plan
     int last_chunks = 0;  // m-chunks of the most recent analysis sweep (hx_plan_last_chunks)
+    int eqN = 0;          // equiangular plan (nside == 0): points of the full circle in theta
+    double wnorm = 0.0;
+    const double2 *hsrc = nullptr;  // ring spectra of the current point-transform call (equiangular plan)
+    long long hsrc_stride = 0;
     long long npix = 0, ny = 0, nlm = 0;
     size_t lds_fft = 0;
     hx::DevBuf z, omz, sth, rwdef, nsub, shifted, startN, startS, bhat_off, tw, bhat, mfac, kfac2, rec0, rec2, cn0, al0, cn2, al2;
@@ -156,6 +212,7 @@ struct hx_plan {
 
 namespace hx {
 // hx_sht.hip
+hx_plan *plan_create_equiangular(int N, int lmax);
 int ensure_rec2(hx_plan *pl);
 int launch_ring_subdft_maps(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, double2 *Y);
 // hx_analysis.hip

@@ -155,6 +155,21 @@ int hx_corr2cl(int lmax, int nspec, const double *corrs, double *cls);
  * complex, alm_out: [ncomp][nlm(lmax_out)] complex.                                             */
 int hx_alm_resample(int lmax_in, int lmax_out, int ncomp, const double *alm_in, double *alm_out);
 
+/* ---- values at arbitrary points -> alm -----------------------------------------------------------
+ * Replaces ducc0.sht.adjoint_synthesis_general(map=values, spin=spin, lmax=lmax, loc=loc, epsilon=epsilon) as called by
+ * DiscreteMapper.map_values (heracles/ducc.py:121-128):  alm[c][idx(l,m)] = sum_p map[c][p] conj(sY_lm(loc[p])), m >= 0,
+ * spin 0: every row of `map` on its own; spin 2: rows (Q, U) -> (E, B) with healpy's sign conventions (those of hx_map2alm).
+ * loc: (npoints, 2) colatitude, longitude in radians (0 <= colatitude <= pi, else HX_ERR_ARG); map: (ncomp, npoints);
+ * alm: (ncomp, nlm) complex, OVERWRITTEN (the caller adds it to its running sum, ducc.py:133); pointers host or device.
+ * The object holds the non-uniform FFT of accuracy epsilon (heracles: 1e-12 for float64 values, 1e-5 for float32,
+ * ducc.py:107-114) and the Legendre plan on equidistant rings; lmax <= 8191.  info4 = {lmax, N, n1, W}: rings on the
+ * full circle, oversampled grid points per dimension, kernel width in cells.                                           */
+typedef struct hx_pointsht hx_pointsht;
+hx_pointsht *hx_pointsht_create(int lmax, double epsilon);
+void hx_pointsht_destroy(hx_pointsht *ps);
+int hx_pointsht_info(const hx_pointsht *ps, int *info4);
+int hx_pointsht_adjoint(hx_pointsht *ps, int spin, int ncomp, int64_t npoints, const double *loc, const double *map, double *alm);
+
 /* ---- catalogue -> map accumulation (first "next" row of SURVEY.md 8f) ---------------
  * hx_ang2pix_ring replaces hp.ang2pix(nside, lon, lat, lonlat=True) at
  * heracles/healpy.py:157 (RING scheme, lon/lat in degrees, n points).

@@ -42,6 +42,11 @@ int hxo_map2alm(int nside, int lmax, int spin, int ncomp, const double *maps,
 int hxo_alm2map(int nside, int lmax, int spin, int ncomp, const double _Complex *alms,
                 double *maps, int use_fft);
 
+/* Adjoint synthesis at points (heracles/ducc.py:121-128 -> ducc0.sht.adjoint_synthesis_general): direct sum
+ * alm = sum_p values_p conj(sY_lm(theta_p, phi_p)); values[ncomp][npoints]; spin 2: rows (Q, U) -> (E, B). */
+int hxo_points2alm(int lmax, int spin, int ncomp, int64_t npoints, const double *theta, const double *phi,
+                   const double *values, double _Complex *alm);
+
 /* alm2cl (heracles/twopoint.py:63-101): one component pair; lmax1, lmax2 are the alm
  * sizes, lmax_out = number of output multipoles - 1 (<= min(lmax1,lmax2)). */
 void hxo_alm2cl(const double _Complex *alm1, int lmax1, const double _Complex *alm2,

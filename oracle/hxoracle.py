@@ -113,6 +113,19 @@ def map2alm(maps, nside, lmax, spin=0, ring_weights=None, pix_weights=None, nite
     return alms.reshape(*lead, -1)
 
 
+def points2alm(theta, phi, values, lmax, spin=0):
+    """Direct sum alm = sum_p values_p conj(sY_lm(theta_p, phi_p)) (heracles/ducc.py:121-128): values (ncomp, npoints)."""
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    phi = np.ascontiguousarray(phi, dtype=np.float64)
+    v2 = np.ascontiguousarray(values, dtype=np.float64).reshape(-1, theta.size)
+    alms = np.zeros((v2.shape[0], nlm(lmax)), dtype=np.complex128)
+    rc = lib().hxo_points2alm(C.c_int(lmax), C.c_int(spin), C.c_int(v2.shape[0]), C.c_int64(theta.size), _p(theta), _p(phi),
+                              _p(v2), _p(alms))
+    if rc != 0:
+        raise ValueError(f"hxo_points2alm failed ({rc})")
+    return alms
+
+
 def alm2map(alms, nside, lmax, spin=0, use_fft=True):
     alms = np.ascontiguousarray(alms, dtype=np.complex128)
     lead = alms.shape[:-1]
