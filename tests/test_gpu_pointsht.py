@@ -131,6 +131,22 @@ def test_long_transforms_on_sampled_m(lmax):
     assert worst_error(theta, phi, v) < 10 * lmax * 1.1e-16 / np.sin(np.pi / sht.nrings_circle)
 
 
+def test_crowded_patch_many_points():
+    """2e5 points, half of them inside one square degree: many hardware atomics on the same grid cells from all
+    compute dies (the sums must not lose updates), the rest anywhere."""
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(77)
+    lmax, n = 48, 200_000
+    theta, phi = _points(rng, n)
+    theta[: n // 2] = 1.0 + rng.uniform(0, np.radians(1.0), n // 2)
+    phi[: n // 2] = 2.0 + rng.uniform(0, np.radians(1.0), n // 2)
+    v = rng.uniform(0.5, 1.5, size=(1, n))  # no cancellation: a lost update would show
+    got = hx.PointSHT(lmax).adjoint_synthesis(np.stack([theta, phi], axis=1), v)
+    want = oracle.points2alm(theta, phi, v, lmax)
+    assert _err(got, want) < 1e-11
+
+
 def test_invalid_points_raise():
     import heracles_amd as hx
 
