@@ -24,8 +24,11 @@
 // decimation-in-frequency step over sub-transforms of 8192.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "hx_sht_common.h"
+
+#include <rocprim/rocprim.hpp>
 
 using namespace hx;
 using namespace hxfft;
@@ -34,7 +37,7 @@ struct hx_pointsht {
     int lmax = 0, N = 0, n1 = 0, W = 0, twN = 2;
     double beta = 0.0, epsilon = 0.0;
     hx_plan *eq = nullptr;
-    hx::DevBuf tw, dec_phi, fac_theta, grid, T, U, h, nbad;
+    hx::DevBuf tw, dec_phi, fac_theta, grid, T, U, h, nbad, key, key2, idx, idx2, sort_tmp;
 };
 
 namespace hx {
@@ -83,6 +86,97 @@ __global__ __launch_bounds__(256) void k_nufft_spread(long long npts, const doub
             for (int b = 0; b < NUFFT_WMAX; ++b)
                 if (a < W && b < W) unsafeAtomicAdd(row + jj[b], wi[a] * wj[b]);
         }
+    }
+}
+
+// ---- spreading through LDS tiles (large catalogues) ----------------------------------------------------------------
+// The support of a point is the W x W block of cells whose lower corner is (i0, j0) = (ceil(x - W/2), ceil(y - W/2)).  Tile
+// (ti, tj) = ((i0 + 16) / 64, (j0 + 16) / 64) owns the points whose corner lies in its 64 x 64 cells; their supports fit a
+// (64 + 15)^2 window that the work-group accumulates in LDS (hardware LDS atomics) and adds to the grid once
+// ((64 + 15)^2 = 6241 global atomics per occupied tile instead of W^2 per point).  Points are brought into tile order by
+// one radix sort of (tile, point index) per call -- the order is shared by all components.
+constexpr int NUFFT_TS = 64, NUFFT_TPAD = 16, NUFFT_TW = NUFFT_TS + NUFFT_WMAX - 1, NUFFT_TLD = NUFFT_TS + NUFFT_WMAX;
+
+__device__ inline bool nufft_corner(const double2 tp, int n1, int W, double &x, double &y, long long &i0, long long &j0)
+{
+    if (!(tp.x >= 0.0 && tp.x <= M_PI) || !isfinite(tp.y)) return false;
+    const double sc = (double)n1 / (2.0 * M_PI), hw = 0.5 * W;
+    x = tp.x * sc;
+    double ph = fmod(tp.y, 2.0 * M_PI);
+    if (ph < 0.0) ph += 2.0 * M_PI;
+    y = ph * sc;
+    i0 = (long long)ceil(x - hw);
+    j0 = (long long)ceil(y - hw);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_nufft_keys(long long npts, const double2 *__restrict__ loc, int n1, int W, int ntx,
+                                                    unsigned *__restrict__ key, unsigned *__restrict__ idx,
+                                                    unsigned long long *__restrict__ nbad)
+{
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npts; p += (long long)gridDim.x * blockDim.x) {
+        double x, y;
+        long long i0, j0;
+        unsigned k = 0xffffffffu;  // invalid points sort behind every tile
+        if (nufft_corner(loc[p], n1, W, x, y, i0, j0)) k = (unsigned)((i0 + NUFFT_TPAD) / NUFFT_TS) * (unsigned)ntx + (unsigned)((j0 + NUFFT_TPAD) / NUFFT_TS);
+        else atomicAdd(nbad, 1ULL);
+        key[p] = k;
+        idx[p] = (unsigned)p;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nufft_spread_tiles(long long npts, const double2 *__restrict__ loc,
+                                                            const double *__restrict__ val, const unsigned *__restrict__ key,
+                                                            const unsigned *__restrict__ idx, double *__restrict__ grid, int n1,
+                                                            int W, double beta, int ntx, unsigned long long *__restrict__ nbad)
+{
+    __shared__ double tile[NUFFT_TW * NUFFT_TLD];
+    __shared__ long long seg[2];
+    const unsigned me = blockIdx.x;
+    if (threadIdx.x < 2) {  // first sorted position with key >= me (+ 1)
+        const unsigned want = me + threadIdx.x;
+        long long lo = 0, hi = npts;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (key[mid] < want) lo = mid + 1;
+            else hi = mid;
+        }
+        seg[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    const long long p0 = seg[0], p1 = seg[1];
+    if (p0 == p1) return;
+    for (int c = threadIdx.x; c < NUFFT_TW * NUFFT_TLD; c += blockDim.x) tile[c] = 0.0;
+    __syncthreads();
+    const long long ti0 = (long long)(me / ntx) * NUFFT_TS - NUFFT_TPAD, tj0 = (long long)(me % ntx) * NUFFT_TS - NUFFT_TPAD;
+    const double inv_hw = 2.0 / W;
+    for (long long q = p0 + threadIdx.x; q < p1; q += blockDim.x) {
+        const unsigned p = idx[q];
+        const double v = val[p];
+        if (!isfinite(v)) {
+            atomicAdd(nbad, 1ULL);
+            continue;
+        }
+        if (v == 0.0) continue;
+        double x, y;
+        long long i0, j0;
+        nufft_corner(loc[p], n1, W, x, y, i0, j0);
+        double wj[NUFFT_WMAX];
+#pragma unroll
+        for (int b = 0; b < NUFFT_WMAX; ++b) wj[b] = b < W ? es_kernel((double)(j0 + b) - y, inv_hw, beta) : 0.0;
+        double *base = tile + (i0 - ti0) * NUFFT_TLD + (j0 - tj0);
+        for (int a = 0; a < W; ++a) {
+            const double wa = v * es_kernel((double)(i0 + a) - x, inv_hw, beta);
+#pragma unroll
+            for (int b = 0; b < NUFFT_WMAX; ++b)
+                if (b < W) atomicAdd(base + a * NUFFT_TLD + b, wa * wj[b]);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < NUFFT_TW * NUFFT_TW; c += blockDim.x) {
+        const int r = c / NUFFT_TW, cc = c % NUFFT_TW;
+        const double v = tile[r * NUFFT_TLD + cc];
+        if (v != 0.0) unsafeAtomicAdd(grid + (((ti0 + r) % n1 + n1) % n1) * (long long)n1 + (((tj0 + cc) % n1 + n1) % n1), v);
     }
 }
 
@@ -280,13 +374,40 @@ extern "C" int hx_pointsht_adjoint(hx_pointsht *ps, int spin, int ncomp, int64_t
         else if (mode == 1) hipLaunchKernelGGL(k_nufft_fft<1>, dim3(rows), dim3(threads), lds, st, a);
         else hipLaunchKernelGGL(k_nufft_fft<2>, dim3(rows), dim3(threads), lds, st, a);
     };
+    // large catalogues are spread through LDS tiles (one sort per call); HX_NUFFT_TILES = 0 / 1 forces the choice
+    bool tiles = npoints >= 300000;  // measured cross-over at lmax 6144 (tools/time_pointsht.py)
+    if (const char *e = getenv("HX_NUFFT_TILES")) tiles = atoi(e) != 0;
+    if (npoints == 0 || npoints > 0xfffffff0ll) tiles = false;
+    const int ntx = n1 / NUFFT_TS + 1, nty = (n1 / 2 + W + NUFFT_TPAD) / NUFFT_TS + 1;
+    if (tiles) {
+        ProfScope pf("nufft_sort");
+        HX_TRY(ps->key.alloc(sizeof(unsigned) * (size_t)npoints));
+        HX_TRY(ps->key2.alloc(sizeof(unsigned) * (size_t)npoints));
+        HX_TRY(ps->idx.alloc(sizeof(unsigned) * (size_t)npoints));
+        HX_TRY(ps->idx2.alloc(sizeof(unsigned) * (size_t)npoints));
+        const long long nblk = std::min<long long>((npoints + 255) / 256, 1 << 20);
+        hipLaunchKernelGGL(k_nufft_keys, dim3((unsigned)nblk), dim3(256), 0, st, (long long)npoints, vloc.as<double2>(), n1, W, ntx,
+                           ps->key.as<unsigned>(), ps->idx.as<unsigned>(), ps->nbad.as<unsigned long long>());
+        const unsigned end_bit = 32;  // all bits: invalid points carry the key 0xffffffff
+        size_t tbytes = 0;
+        HX_HIP(rocprim::radix_sort_pairs(nullptr, tbytes, ps->key.as<unsigned>(), ps->key2.as<unsigned>(), ps->idx.as<unsigned>(),
+                                         ps->idx2.as<unsigned>(), (size_t)npoints, 0u, end_bit, st));
+        HX_TRY(ps->sort_tmp.alloc(tbytes ? tbytes : 16));
+        HX_HIP(rocprim::radix_sort_pairs(ps->sort_tmp.p, tbytes, ps->key.as<unsigned>(), ps->key2.as<unsigned>(), ps->idx.as<unsigned>(),
+                                         ps->idx2.as<unsigned>(), (size_t)npoints, 0u, end_bit, st));
+    }
     for (int c0 = 0, nb = 0; c0 < ncomp; c0 += nb) {
         nb = analysis_next_batch(spin, ncomp - c0);
         for (int c = 0; c < nb; ++c) {
             {
                 ProfScope pf("nufft_spread");
                 HX_HIP(hipMemsetAsync(ps->grid.p, 0, sizeof(double) * (size_t)n1 * n1, st));
-                if (npoints > 0) {
+                if (tiles) {
+                    hipLaunchKernelGGL(k_nufft_spread_tiles, dim3((unsigned)(ntx * nty)), dim3(256), 0, st, (long long)npoints,
+                                       vloc.as<double2>(), vmap.as<double>() + (size_t)(c0 + c) * npoints, ps->key2.as<unsigned>(),
+                                       ps->idx2.as<unsigned>(), ps->grid.as<double>(), n1, W, ps->beta, ntx,
+                                       ps->nbad.as<unsigned long long>());
+                } else if (npoints > 0) {
                     const long long nblk = std::min<long long>((npoints + 255) / 256, 1 << 20);
                     hipLaunchKernelGGL(k_nufft_spread, dim3((unsigned)nblk), dim3(256), 0, st, (long long)npoints, vloc.as<double2>(),
                                        vmap.as<double>() + (size_t)(c0 + c) * npoints, ps->grid.as<double>(), n1, W, ps->beta,

@@ -147,6 +147,29 @@ def test_crowded_patch_many_points():
     assert _err(got, want) < 1e-11
 
 
+@pytest.mark.parametrize("lmax", [5, 48, 300])  # grids smaller than, comparable to and larger than one 64-cell tile
+def test_tiled_spreading_path(lmax, monkeypatch):
+    """Large catalogues are spread through LDS tiles (one sort per call); HX_NUFFT_TILES=1 forces that path here."""
+    import heracles_amd as hx
+
+    monkeypatch.setenv("HX_NUFFT_TILES", "1")
+    rng = np.random.default_rng(lmax)
+    n = 3000
+    theta, phi = _points(rng, n)
+    theta[:4] = [0.0, np.pi, 1e-7, np.pi - 1e-7]
+    phi[:4] = [0.0, 2 * np.pi - 1e-13, 6.28, 1e-9]
+    v = rng.normal(size=(4, n))
+    v[0, :10] = 0.0
+    loc = np.stack([theta, phi], axis=1)
+    sht = hx.PointSHT(lmax)
+    tol = 1e-11 if lmax < 100 else 10 * lmax * 1.1e-16 / np.sin(np.pi / sht.nrings_circle)
+    for spin in (0, 2):
+        assert _err(sht.adjoint_synthesis(loc, v, spin=spin), oracle.points2alm(theta, phi, v, lmax, spin=spin)) < tol
+    loc[7, 0] = -0.1
+    with pytest.raises(ValueError):
+        sht.adjoint_synthesis(loc, v)
+
+
 def test_invalid_points_raise():
     import heracles_amd as hx
 
