@@ -989,237 +989,6 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
 }
 
 // =====================================================================================
-// Legendre analysis, two waves per SIMD ("duo"): latency hiding by occupancy instead of software pipelining.
-// =====================================================================================
-// 8 waves per work-group, 256 registers each, ONE ring set per wave (its 16 KiB tile): per 32-l block a wave runs its 32
-// recursion steps (vector block, values into the tile), then the 16 slot pairs of MFMAs out of the tile.  The two waves of
-// a SIMD drift out of phase, so one wave's recursion, LDS waits and flush work sit under the other's matrix instructions
-// (FP64 vector work is starved while the other wave streams MFMAs and runs when that wave pauses: the pipe stays busy
-// either way -- tools/ubench_power.hip "same wave, 8 waves per CU": 92 %).  Same task list, F / partial layouts, tile
-// layout and recursion as k_legendre_pipe; one 16-column group (+ one 4-column block) -- two groups need 512 registers.
-template <int SPIN, int NG, int NBX>
-__global__ __launch_bounds__(512, 1) void k_legendre_duo(LegParams A, const double2 *__restrict__ coefn,
-                                                         const double *__restrict__ alphan)
-{
-    using C = PipeCfg<SPIN>;
-    constexpr int NW = 8, NOP = C::NOP, NCH = C::NCH, NPAIR = 16;
-    constexpr int NGA = NG, NXA = NBX > 0 ? NBX : 1;
-    constexpr int DQ0 = NG * 512, DSZ = NG * 512 + NBX * 128;
-    constexpr int NCR = 3, NAR = 2;
-    static_assert(NG == 1 && DSZ <= 2048 && NW * C::RBS == LegCfg<SPIN>::NW, "one column group; a task covers the same ring blocks");
-    __shared__ double tile[NW][2048];          // 128 KiB; doubles as the D staging area of the flush
-    __shared__ double2 coefs[NCR][2][LBLK];    // recursion coefficients, block j in slot j % NCR; [1] = sign of q' flipped (spin 2)
-    __shared__ double alphas[NAR][LBLK];
-    const PlanDev &P = A.P;
-    const LegTask task = A.tasks[blockIdx.x];
-    const int m = task.m, lmax = P.lmax;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ai = lane & 15, ak = lane >> 4;
-    const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
-    const int off = (l0 + m) & 1;
-    const long long cb = almidx(lmax, 0, m);
-    const int coff = SPIN == 0 ? 0 : 1;
-    const int nblk = (lmax - l0) / LBLK + 1;
-
-    // ring of this lane: wave w holds ring block w (spin 2) / blocks 2 w, 2 w + 1 (spin 0) of the task; waves w and w + 4 share
-    // a SIMD, i.e. a polar and an equatorial block
-    const int rbi = SPIN == 0 ? 2 * w + (lane >> 5) : w;
-    const int rpl = (task.rb0 + rbi) * RBLK + (lane & 31);
-    const bool valid = rbi < task.nrb && rpl < P.nrp;
-    const double x = valid ? P.z[rpl] : 0.0;
-    const double xx = SPIN == 0 ? x * x : x;
-
-    double fr[NPAIR][2][NGA], frx[NPAIR][2][NXA];
-#pragma unroll
-    for (int sp = 0; sp < NPAIR; ++sp) {
-        const int op = SPIN == 0 ? 0 : sp & 1, q = SPIN == 0 ? sp : sp >> 1;
-        const int rbq = SPIN == 0 ? 2 * w + (q >> 3) : w;
-        const bool on = rbq < task.nrb;
-        const long long row = (long long)(m - A.m0) * P.nrp_pad + (task.rb0 + rbq) * RBLK + pipe_rho(q & 7, ak);
-#pragma unroll
-        for (int pos = 0; pos < 2; ++pos) {
-            const double *f = A.F + ((row * 2 + (pos ^ off)) * NOP + op) * A.ncol;
-#pragma unroll
-            for (int g = 0; g < NGA; ++g) fr[sp][pos][g] = on ? f[g * NCOL + ai] : 0.0;
-#pragma unroll
-            for (int g = 0; g < NXA; ++g) frx[sp][pos][g] = (NBX > 0 && on) ? f[NG * NCOL + 4 * g + (lane & 3)] : 0.0;
-        }
-    }
-
-    double vc[NCH], vp[NCH];
-    int sc[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) { vc[c] = 0.0; vp[c] = 0.0; sc[c] = -100; }
-    if (valid) {
-        if (SPIN == 0) {
-            SVal a = spow(P.sth[rpl], m);
-            a.v *= P.mfac[m];
-            SVal b = a;
-            b.v *= sqrt(2.0 * m + 3.0) * P.z[rpl];
-            snorm_small(a);
-            snorm_small(b);
-            vc[0] = a.v; sc[0] = a.e;
-            vc[NCH - 1] = b.v; sc[NCH - 1] = b.e;
-        } else {
-            SVal sp, sm;
-            spin2_seeds(m, P.sth[rpl], P.omz[rpl], P.kfac2[m], sp, sm);
-            vc[0] = (lane >> 5) ? sm.v : sp.v;
-            sc[0] = (lane >> 5) ? sm.e : sp.e;
-        }
-    }
-    const int chalf = SPIN == 2 ? (lane >> 5) : 0;
-
-    auto lds_barrier = []() __attribute__((always_inline)) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): global stores / prefetches in flight do not hold the barrier
-        __builtin_amdgcn_s_barrier();
-    };
-    const double csign = (SPIN == 2 && (threadIdx.x & 1) && (threadIdx.x >> 6) == 1) ? -1.0 : 1.0;
-    if (threadIdx.x < 128) {
-#pragma unroll
-        for (int bb = 0; bb <= 1; ++bb)
-            (&coefs[bb][threadIdx.x >> 6][0].x)[threadIdx.x & 63] =
-                csign * reinterpret_cast<const double *>(coefn + cb + l0 + bb * LBLK + coff)[threadIdx.x & 63];
-    } else if (threadIdx.x < 160) {
-        alphas[0][threadIdx.x - 128] = alphan[cb + l0 + (threadIdx.x - 128)];
-    }
-    __syncthreads();
-
-    // one recursion step of chain c (see k_legendre_pipe): returns the value BEFORE the step
-    auto rec_step = [&](auto RMM, int c, int step, const double2 cc) __attribute__((always_inline)) {
-        constexpr int RM = decltype(RMM)::value;
-        if (RM != 3 && (step & 3) == 0) {
-            const int hc = __double2hiint(vc[c]), hp = __double2hiint(vp[c]);
-            const bool up = sc[c] < 0 && (hc & 0x7ff00000) >= 0x3ff00000;
-            const int sub = up ? (300 << 20) : 0;
-            const bool pz = up && (hp & 0x7ff00000) <= (300 << 20);
-            vc[c] = __hiloint2double(hc - sub, __double2loint(vc[c]));
-            vp[c] = pz ? 0.0 : __hiloint2double(hp - sub, __double2loint(vp[c]));
-            sc[c] += up ? 1 : 0;
-        }
-        const double cur = (RM == 3 || sc[c] == 0) ? vc[c] : 0.0;
-        const double vn = fma(fma(cc.x, xx, cc.y), vc[c], -vp[c]);
-        vp[c] = vc[c];
-        vc[c] = vn;
-        return cur;
-    };
-    constexpr int HB = 8;
-    double *tw = &tile[w][0];
-    auto recursion = [&](auto RMM, const double2 *cf) __attribute__((always_inline)) {
-        constexpr int RM = decltype(RMM)::value;
-#pragma unroll
-        for (int h = 0; h < LBLK / HB; ++h) {
-            double2 cq[HB];
-#pragma unroll
-            for (int k = 0; k < HB; ++k) cq[k] = cf[chalf * LBLK + HB * h + k];
-            double cur[HB];
-#pragma unroll
-            for (int k = 0; k < HB; ++k) {
-                const int kk = HB * h + k;
-                cur[k] = rec_step(RMM, SPIN == 0 ? ((kk & 1) ? NCH - 1 : 0) : 0, SPIN == 0 ? kk >> 1 : kk, cq[k]);
-            }
-            if (RM >= 2) {
-#pragma unroll
-                for (int j = 0; j < HB / 2; ++j)
-                    *reinterpret_cast<double2 *>(tw + pipe_tile_idx(lane, h * (HB / 2) + j)) = make_double2(cur[2 * j], cur[2 * j + 1]);
-            }
-        }
-    };
-    auto set_mode = [&]() __attribute__((always_inline)) {
-        bool dead = !valid || sc[0] < 0, live = !valid || sc[0] == 0;
-        if (NCH == 2) {
-            dead = dead && (!valid || sc[NCH - 1] < 0);
-            live = live && (!valid || sc[NCH - 1] == 0);
-        }
-        return __all(dead) ? 1 : (__all(live) ? 3 : 2);
-    };
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-
-    // flush roles: threads 0..255 reduce the group columns (16-byte chunk (col, c): rows (c >> 1) + 8 (c & 1) and + 4),
-    // threads 256 .. 256 + 64 NBX the 4-column blocks
-    const int tt = threadIdx.x & 255;
-    const bool grp = threadIdx.x < 256, quad = NBX > 0 && threadIdx.x >= 256 && tt < 64 * NBX;
-    const int fcol = tt & 15, fch = (tt >> 4) & 7, fpos = (tt >> 7) & 1;
-    const int frow = (fch >> 1) + 8 * (fch & 1);
-    const int qrow = tt / (4 * NXA), qcol = tt % (4 * NXA);
-    double *pout = grp ? A.partial + (task.pout - A.row0 + 2 * frow + fpos) * A.ncol + fcol
-                       : A.partial + (task.pout - A.row0 + 2 * qrow) * A.ncol + NG * NCOL + qcol;
-    double hpre = 0.0;
-    auto prefetch = [&](int b0) __attribute__((always_inline)) {  // for the flush that closes block b0
-        hpre = 0.0;
-        if (threadIdx.x < 128) hpre = reinterpret_cast<const double *>(coefn + cb + l0 + (b0 + 2) * LBLK + coff)[threadIdx.x & 63];
-        else if (threadIdx.x < 160) hpre = alphan[cb + l0 + (b0 + 1) * LBLK + (threadIdx.x - 128)];
-    };
-    prefetch(0);
-    for (int b = 0; b < nblk; ++b) {
-        double4_t acc[2] = {(double4_t){0.0, 0.0, 0.0, 0.0}, (double4_t){0.0, 0.0, 0.0, 0.0}};
-        double accx[NXA][2];
-#pragma unroll
-        for (int g = 0; g < NXA; ++g) accx[g][0] = accx[g][1] = 0.0;
-        const int rm = set_mode();
-        const double2 *cf = &coefs[b % NCR][0][0];
-        if (rm == 3) recursion(I3{}, cf);
-        else if (rm == 2) recursion(I2{}, cf);
-        else recursion(I1{}, cf);
-        if (rm >= 2) {
-            constexpr int PF = 2;
-            auto a_fetch = [&](int sp) __attribute__((always_inline)) {
-                const int op = SPIN == 0 ? 0 : sp & 1, q = SPIN == 0 ? sp : sp >> 1;
-                const int c = SPIN == 0 ? (q >> 3) * 32 + pipe_rho(q & 7, ak) : op * 32 + pipe_rho(q, ak);
-                return *reinterpret_cast<const double2 *>(tw + pipe_tile_idx(c, ai));
-            };
-            double2 aq[NPAIR];
-#pragma unroll
-            for (int j = 0; j < PF; ++j) aq[j] = a_fetch(j);
-#pragma unroll
-            for (int sp = 0; sp < NPAIR; ++sp) {
-                if (sp + PF < NPAIR) aq[sp + PF] = a_fetch(sp + PF);
-#pragma unroll
-                for (int pos = 0; pos < 2; ++pos) {
-                    const double a = pos ? aq[sp].y : aq[sp].x;
-                    acc[pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[sp][pos][0], acc[pos], 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < NBX; ++g) accx[g][pos] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[sp][pos][g], accx[g][pos], 0, 0, 0);
-                }
-            }
-        }
-        // ---- flush: D tiles of the 8 waves through their own tiles (consumed above), fixed order ----
-#pragma unroll
-        for (int pos = 0; pos < 2; ++pos)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                *reinterpret_cast<double2 *>(tw + pos * 256 + ai * 16 + (((2 * ak + h) ^ (ai & 7)) * 2)) = make_double2(acc[pos][2 * h], acc[pos][2 * h + 1]);
-#pragma unroll
-        for (int g = 0; g < NBX; ++g)
-            *reinterpret_cast<double2 *>(tw + DQ0 + ((4 * ((lane >> 2) & 3) + ak) * 4 * NBX + 4 * g + (lane & 3)) * 2) = make_double2(accx[g][0], accx[g][1]);
-        if (threadIdx.x < 128) (&coefs[(b + 2) % NCR][threadIdx.x >> 6][0].x)[threadIdx.x & 63] = csign * hpre;
-        else if (threadIdx.x < 160) alphas[(b + 1) % NAR][threadIdx.x - 128] = hpre;
-        lds_barrier();
-        prefetch(b + 1);
-        // (rows of a task are padded to whole 32-l blocks: no bounds tests within a block)
-        if (grp || quad) {
-            const double *alb = alphas[b % NAR];
-            const double *src = grp ? &tile[0][0] + fpos * 256 + fcol * 16 + ((fch ^ (fcol & 7)) * 2) : &tile[0][0] + DQ0 + tt * 2;
-            double2 s8[NW];
-#pragma unroll
-            for (int ww = 0; ww < NW; ++ww) s8[ww] = *reinterpret_cast<const double2 *>(src + ww * 2048);
-            const double sx = ((s8[0].x + s8[1].x) + (s8[2].x + s8[3].x)) + ((s8[4].x + s8[5].x) + (s8[6].x + s8[7].x));
-            const double sy = ((s8[0].y + s8[1].y) + (s8[2].y + s8[3].y)) + ((s8[4].y + s8[5].y) + (s8[6].y + s8[7].y));
-            if (grp) {
-                pout[0] = sx * alb[2 * frow + fpos];
-                pout[8 * (long long)A.ncol] = sy * alb[2 * frow + 8 + fpos];
-            } else {
-                pout[0] = sx * alb[2 * qrow];
-                pout[A.ncol] = sy * alb[2 * qrow + 1];
-            }
-        }
-        pout += (long long)LBLK * A.ncol;
-        lds_barrier();  // D tiles consumed: the tiles may be overwritten by the next block's recursion
-    }
-}
-
-// =====================================================================================
 // partial sums -> alm (fixed order over the ring groups of each m)
 // =====================================================================================
 template <int SPIN>
@@ -1631,17 +1400,6 @@ static int pipe_nsub(int spin)
     return v == 2 ? 2 : 1;
 }
 
-// HX_LEG_KERNEL = duo selects the two-waves-per-SIMD kernel for sweeps of one column group (experiment)
-static bool leg_duo()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("HX_LEG_KERNEL");
-        v = (e && !strcmp(e, "duo")) ? 1 : 0;
-    }
-    return v == 1;
-}
-
 template <int SPIN>
 static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int nb, const SweepShape &sh, const double *d_rw,
                         const double *d_fl, int add, double2 *d_alms)
@@ -1690,10 +1448,6 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
             hipLaunchKernelGGL((k_legendre_analysis<SPIN, -1, 0, QSUB, QNW>), grid, dim3(QNW * 64), 0, st, A, cn, al);
         else if (sh.quad == 2)  // 140 VGPRs: two half-size groups do not fit a CU (104 vs 91 ms)
             hipLaunchKernelGGL((k_legendre_analysis<SPIN, -2, 0, QSUB>), grid, block, 0, st, A, cn, al);
-        else if (sh.ng == 1 && sh.nbx == 0 && leg_duo())
-            hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 0>), grid, dim3(512), 0, st, A, cn, al);
-        else if (sh.ng == 1 && sh.nbx == 1 && leg_duo())
-            hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 1>), grid, dim3(512), 0, st, A, cn, al);
         else if (sh.ng == 1 && sh.nbx == 0 && pipe_nsub(SPIN) == 2)
             hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 0, 2>), grid, pblock, 0, st, A, cn, al);
         else if (sh.ng == 1 && sh.nbx == 0)
