@@ -49,30 +49,31 @@ def toc_match(key, include=None, exclude=None) -> bool:
     return True
 
 
+def _prefix_matches(pattern, key):
+    """A pattern is a key prefix whose ``...`` entries match anything; a non-tuple key is a one-element key."""
+    parts = key if isinstance(key, tuple) else (key,)
+    if len(pattern) > len(parts) or (not isinstance(key, tuple) and len(pattern) != 1):
+        return False
+    return all(want is ... or want == have for want, have in zip(pattern, parts))
+
+
 class TocDict(dict):
-    """dict whose lookup falls back to prefix patterns with ``...`` wildcards."""
+    """dict with the selection rule of heracles.core.TocDict (heracles/core.py:63-99): an exact key returns its value;
+    anything else is read as a prefix pattern and returns the sub-dictionary of matching keys (KeyError if empty)."""
 
     def __getitem__(self, pattern):
         try:
-            return dict.__getitem__(self, pattern)
-        except (KeyError, TypeError):
+            if dict.__contains__(self, pattern):
+                return dict.__getitem__(self, pattern)
+        except TypeError:  # unhashable pattern: can only be a selection
             pass
-        if not isinstance(pattern, tuple):
-            pattern = (pattern,)
-        if not pattern:
+        prefix = pattern if isinstance(pattern, tuple) else (pattern,)
+        if not prefix:  # the empty pattern selects everything
             return TocDict(self)
-        found = TocDict()
-        for key, value in self.items():
-            if isinstance(key, tuple):
-                if len(key) >= len(pattern) and all(
-                    p == k for p, k in zip(pattern, key) if p is not ...
-                ):
-                    found[key] = value
-            elif pattern in ((...,), (key,)):
-                found[key] = value
-        if not found:
-            raise KeyError(pattern)
-        return found
+        selected = TocDict((k, v) for k, v in self.items() if _prefix_matches(prefix, k))
+        if not selected:
+            raise KeyError(prefix)
+        return selected
 
 
 def _axis_tuple(axis, ndim, ell):

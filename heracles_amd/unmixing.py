@@ -49,35 +49,44 @@ def _pad(d, n):
     return out
 
 
+def _cutoff_exponent(wm, theta_max):
+    """log10 of the mask correlation below which it is damped: 1e-5, or its value at the Gauss-Legendre node closest
+    to ``theta_max`` degrees in the first mask spectrum (heracles/unmixing.py:83-91)."""
+    if theta_max is None:
+        return -5
+    first = next(iter(wm.values()))
+    nodes, _ = gauss_legendre(first.shape[first.axis[0]])
+    nearest = np.abs(np.degrees(np.arccos(nodes)) - theta_max).argmin()
+    return np.log10(abs(first[nearest]))
+
+
+def _damp_in_place(xi_mask, x0):
+    """xi_m <- xi_m (1 + exp(-50 (log10 |xi_m| - x0))), written through to the caller's array: the reference modifies
+    the object its lookup returns (heracles/unmixing.py:99), so a mask pair shared by two data keys is damped twice."""
+    xi_mask *= logistic(np.log10(abs(xi_mask)), x0=x0)
+    return xi_mask
+
+
 def _naturalspice(wd, wm, fields, theta_max=None):
-    masks = {k: f.mask for k, f in fields.items() if f.mask is not None}
-    if theta_max is not None:
-        first = list(wm.values())[0]
-        lmax_mask = first.shape[first.axis[0]]
-        xvals, _ = gauss_legendre(lmax_mask)
-        theta = np.arccos(xvals) * 180 / np.pi
-        i_max = np.abs(theta - theta_max).argmin()
-        x0 = np.log10(abs(first[i_max]))
-    else:
-        x0 = -5
-    out = {}
-    for key in wd:
+    """xi_d / damped xi_m for every data key (a, b, i, j) with the masks of fields a and b (heracles/unmixing.py:66-102)."""
+    mask_of = {name: f.mask for name, f in fields.items() if f.mask is not None}
+    x0 = _cutoff_exponent(wm, theta_max)
+
+    def corrected(key):
         a, b, i, j = key
-        _wm = _get_cl((masks[a], masks[b], i, j), wm).array
-        _wd = wd[key].array
-        _wm *= logistic(np.log10(abs(_wm)), x0=x0)
-        out[key] = replace(wd[key], array=(_wd / _wm))
-    return out
+        xi_mask = _damp_in_place(_get_cl((mask_of[a], mask_of[b], i, j), wm).array, x0)
+        return replace(wd[key], array=wd[key].array / xi_mask)
+
+    return {key: corrected(key) for key in wd}
 
 
 def naturalspice(d, m, fields, theta_max=None):
-    """Natural unmixing of data spectra d by mask spectra m (heracles/unmixing.py:36-64)."""
-    first_wd = list(d.values())[0]
-    first_wm = list(m.values())[0]
-    lmax = first_wd.shape[first_wd.axis[0]]
-    lmax_mask = first_wm.shape[first_wm.axis[0]]
-    d = _pad(d, lmax_mask)
-    wd = cl2corr(d)
-    wm = cl2corr(m)
-    corr = _naturalspice(wd, wm, fields, theta_max=theta_max)
-    return _pad(corr2cl(corr), lmax)
+    """Natural unmixing of data spectra d by mask spectra m (heracles/unmixing.py:36-64): both go to correlation
+    functions on the mask's band limit, the ratio comes back and is cut to the data's band limit."""
+    def band_limit(spectra):
+        first = next(iter(spectra.values()))
+        return first.shape[first.axis[0]]
+
+    n_data, n_mask = band_limit(d), band_limit(m)
+    ratio = _naturalspice(cl2corr(_pad(d, n_mask)), cl2corr(m), fields, theta_max=theta_max)
+    return _pad(corr2cl(ratio), n_data)
