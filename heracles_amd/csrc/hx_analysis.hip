@@ -62,6 +62,11 @@ struct LegParams {
     int ncol;                          // doubles per F / partial row: 16 per full group + 4 per extra block
     int ablate;                        // diagnostic only (HX_ABLATE): 1 skip MFMA, 2 skip recursion, 8 count paths
     unsigned long long *counters;
+    // pipelined kernel only: a work-group owns one m and walks its ring groups in order (tasks and of_m are then the whole
+    // lists, indexed by m), adding into ONE span of rows per m: arow[m] - arow0
+    const MTasks *__restrict__ of_m;
+    const long long *__restrict__ arow;
+    long long arow0;
 };
 
 // =====================================================================================
@@ -543,15 +548,33 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     constexpr bool DEFER = SPIN == 2 && NG == 1 && NSUB == 1 && !(HX_PIPE_ABL & 64);
     __shared__ double dstage[DEFER ? NW * DSZ : 2];
     const PlanDev &P = A.P;
-    const LegTask task = A.tasks[blockIdx.x];
-    const int m = task.m, lmax = P.lmax;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ai = lane & 15, ak = lane >> 4;
+    // One work-group per m.  The ring groups (tasks) of that m are swept one after the other, and every flush ADDS its rows
+    // into the one span of rows the m owns (global_atomic_add_f64 without return, executed in this XCD's L2):
+    // every row element is touched by one thread of one work-group only, in program order, so the sum over ring groups has
+    // a fixed order (bit-reproducible) although no partial row per ring group ever exists in HBM.
+    const int m = A.m0 + blockIdx.x, lmax = P.lmax;
+    const MTasks mt = A.of_m[m];
     const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
     const int off = (l0 + m) & 1;              // parity (l + m) & 1 of position 0
     const long long cb = almidx(lmax, 0, m);
     const int coff = SPIN == 0 ? 0 : 1;        // spin-2 coefficients are indexed by the target l
     const int nblk = (lmax - l0) / LBLK + 1;
+    const long long orow = A.arow[m] - A.arow0;
+    // (the rows are zeroed by the host before the launch: a first group that stores instead of adding needs a branch inside
+    // the stage that carries the deferred reduction -- 224 vs 229 ms per sweep of 5 spin-2 fields, same device)
+    auto put = [](double *p, double v) __attribute__((always_inline)) {
+        __builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)p, v);
+    };
+    for (int ti = 0; ti < mt.count; ++ti) {
+    const LegTask task = A.tasks[mt.first + ti];
+    // the thread index goes through an empty asm statement per ring group: everything derived from it (LDS addresses, row
+    // offsets, flush roles) is then set up per group and dies after the group's prologue, as in a kernel without this loop --
+    // hoisted out of the loop those values stay live through the stages (36 more registers spilled, measured)
+    int tid = threadIdx.x;
+    asm volatile("; ring group" : "+v"(tid));
+    const int w = tid >> 6, lane = tid & 63;
+    const int ai = lane & 15, ak = lane >> 4;
+    if (ti) __syncthreads();  // the previous ring group's last readers of the coefficient / alpha rings and of the staging area
 
     // ---- rings of this lane: ring block (within the task) of set s.  The ring blocks of a task are dealt to
     // the waves round-robin, so that every wave holds polar (late) and equatorial (early) rings alike ----
@@ -619,15 +642,15 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         __builtin_amdgcn_s_barrier();
     };
     // coefficient hand-over: thread t < 128 carries double (t & 63) of a block's 32 (p', q') pairs into table t >> 6
-    const double csign = (SPIN == 2 && (threadIdx.x & 1) && (threadIdx.x >> 6) == 1) ? -1.0 : 1.0;
-    if (threadIdx.x < 128) {
+    const double csign = (SPIN == 2 && (tid & 1) && (tid >> 6) == 1) ? -1.0 : 1.0;
+    if (tid < 128) {
 #pragma unroll
         for (int bb = 0; bb <= NSUB; ++bb)
-            (&coefs[bb][threadIdx.x >> 6][0].x)[threadIdx.x & 63] =
-                csign * reinterpret_cast<const double *>(coefn + cb + l0 + bb * LBLK + coff)[threadIdx.x & 63];
-    } else if (threadIdx.x < 160) {
+            (&coefs[bb][tid >> 6][0].x)[tid & 63] =
+                csign * reinterpret_cast<const double *>(coefn + cb + l0 + bb * LBLK + coff)[tid & 63];
+    } else if (tid < 160) {
 #pragma unroll
-        for (int bb = 0; bb < NSUB; ++bb) alphas[bb][threadIdx.x - 128] = alphan[cb + l0 + bb * LBLK + (threadIdx.x - 128)];
+        for (int bb = 0; bb < NSUB; ++bb) alphas[bb][tid - 128] = alphan[cb + l0 + bb * LBLK + (tid - 128)];
     }
     __syncthreads();
 
@@ -653,12 +676,12 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         return cur;
     };
     // flush roles of this thread: D values arrive as 16-byte chunks (col, chunk c): rows (c >> 1) + 8 (c & 1) and + 4
-    const int fcol = threadIdx.x & 15, fch = (threadIdx.x >> 4) & 7, fpos = (threadIdx.x >> 7) & 1;
+    const int fcol = tid & 15, fch = (tid >> 4) & 7, fpos = (tid >> 7) & 1;
     const int frow = (fch >> 1) + 8 * (fch & 1);
     // partial rows this thread writes: (group columns) rows 2 frow + fpos and + 8 of the block; (extra blocks) rows 2 qrow, + 1
-    const int qrow = threadIdx.x / (4 * NXA), qcol = threadIdx.x % (4 * NXA);
-    double *pgrp = A.partial + (task.pout - A.row0 + 2 * frow + fpos) * A.ncol + fcol;
-    double *pquad = A.partial + (task.pout - A.row0 + 2 * qrow) * A.ncol + NG * NCOL + qcol;
+    const int qrow = tid / (4 * NXA), qcol = tid % (4 * NXA);
+    double *pgrp = A.partial + (orow + 2 * frow + fpos) * A.ncol + fcol;
+    double *pquad = A.partial + (orow + 2 * qrow) * A.ncol + NG * NCOL + qcol;
     // deferred reduction (DEFER): operands of the group columns, then of the 4-column blocks, in the same registers
     double2 s4[NW];
     bool pend = false;
@@ -673,24 +696,24 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     };
     auto red_finish_group = [&]() __attribute__((always_inline)) {
         const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
-        pgrp[0] = sx * al0;
-        pgrp[8 * (long long)A.ncol] = sy * al1;
+        put(pgrp, sx * al0);
+        put(pgrp + 8 * (long long)A.ncol, sy * al1);
         pgrp += (long long)LBLK * A.ncol;
     };
     auto red_issue_quad = [&]() __attribute__((always_inline)) {
-        if (NBX > 0 && threadIdx.x < 64 * NBX) {
+        if (NBX > 0 && tid < 64 * NBX) {
 #pragma unroll
-            for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(dstage + ww * DSZ + DQ0 + threadIdx.x * 2);
+            for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(dstage + ww * DSZ + DQ0 + tid * 2);
             const double2 a2 = *reinterpret_cast<const double2 *>(&alphas[pend_slot][2 * qrow]);
             al0 = a2.x;
             al1 = a2.y;
         }
     };
     auto red_finish_quad = [&]() __attribute__((always_inline)) {
-        if (NBX > 0 && threadIdx.x < 64 * NBX) {
+        if (NBX > 0 && tid < 64 * NBX) {
             const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
-            pquad[0] = sx * al0;
-            pquad[A.ncol] = sy * al1;
+            put(pquad, sx * al0);
+            put(pquad + A.ncol, sy * al1);
         }
         pquad += (long long)LBLK * A.ncol;
         pend = false;
@@ -857,8 +880,8 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
 #pragma unroll
         for (int u = 0; u < NSUB; ++u) {
             hpre[u] = 0.0;
-            if (threadIdx.x < 128) hpre[u] = reinterpret_cast<const double *>(coefn + cb + l0 + (b0 + NSUB + 1 + u) * LBLK + coff)[threadIdx.x & 63];
-            else if (threadIdx.x < 160) hpre[u] = alphan[cb + l0 + (b0 + NSUB + u) * LBLK + (threadIdx.x - 128)];
+            if (tid < 128) hpre[u] = reinterpret_cast<const double *>(coefn + cb + l0 + (b0 + NSUB + 1 + u) * LBLK + coff)[tid & 63];
+            else if (tid < 160) hpre[u] = alphan[cb + l0 + (b0 + NSUB + u) * LBLK + (tid - 128)];
         }
     };
     prefetch(0);
@@ -925,8 +948,8 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         }
 #pragma unroll
         for (int u = 0; u < NSUB; ++u) {
-            if (threadIdx.x < 128) (&coefs[(b + NSUB + 1 + u) % NCR][threadIdx.x >> 6][0].x)[threadIdx.x & 63] = csign * hpre[u];
-            else if (threadIdx.x < 160) alphas[(b + NSUB + u) % NAR][threadIdx.x - 128] = hpre[u];
+            if (tid < 128) (&coefs[(b + NSUB + 1 + u) % NCR][tid >> 6][0].x)[tid & 63] = csign * hpre[u];
+            else if (tid < 160) alphas[(b + NSUB + u) % NAR][tid - 128] = hpre[u];
         }
         lds_barrier();
         HX_STAMP(5);
@@ -951,16 +974,16 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
                 for (int ww = 0; ww < NW; ++ww)
                     s4[ww] = *reinterpret_cast<const double2 *>(dt0 + ww * 2048 + (g * 2 + fpos) * 256 + fcol * 16 + ((fch ^ (fcol & 7)) * 2));
                 const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
-                pgrp[rsub + g * NCOL] = sx * alb[2 * frow + fpos];
-                pgrp[rsub + g * NCOL + 8 * (long long)A.ncol] = sy * alb[2 * frow + 8 + fpos];
+                put(pgrp + rsub + g * NCOL, sx * alb[2 * frow + fpos]);
+                put(pgrp + rsub + g * NCOL + 8 * (long long)A.ncol, sy * alb[2 * frow + 8 + fpos]);
             }
-            if (NBX > 0 && threadIdx.x < 64 * NBX) {
+            if (NBX > 0 && tid < 64 * NBX) {
                 double2 s4[NW];
 #pragma unroll
-                for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(dt0 + ww * 2048 + DQ0 + threadIdx.x * 2);
+                for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(dt0 + ww * 2048 + DQ0 + tid * 2);
                 const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
-                pquad[rsub] = sx * alb[2 * qrow];
-                pquad[rsub + A.ncol] = sy * alb[2 * qrow + 1];
+                put(pquad + rsub, sx * alb[2 * qrow]);
+                put(pquad + rsub + A.ncol, sy * alb[2 * qrow + 1]);
             }
         }
         pgrp += (long long)NSUB * LBLK * A.ncol;
@@ -986,6 +1009,7 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         atomicAdd(&A.counters[17], cyc_m);
     }
 #endif
+    }  // ring groups of this m
 }
 
 // =====================================================================================
@@ -996,12 +1020,31 @@ __global__ __launch_bounds__(256) void k_alm_reduce(PlanDev P, const LegTask *__
                                                     const MTasks *__restrict__ of_m,
                                                     const double *__restrict__ partial, long long row0, int m0,
                                                     int ncomp, int ng, int ncol, const double *__restrict__ fl, int add,
-                                                    double2 *__restrict__ alm, long long alm_stride)
+                                                    double2 *__restrict__ alm, long long alm_stride,
+                                                    const long long *__restrict__ arow)
 {
     const int m = m0 + blockIdx.x, lmax = P.lmax;
     const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
     const MTasks mt = of_m[m];
     const int nl = lmax - m + 1, nc = 8 * ng;
+    if (arow) {
+        // rows of the pipelined kernel: already summed over the ring groups, one span per m (row0 = first row of the chunk
+        // in that numbering); what is left is the change of layout (x fl)
+        const long long r0 = arow[m] - row0;
+        for (int i = threadIdx.x; i < nl * nc; i += blockDim.x) {
+            const int l = m + i / nc, c = i % nc;
+            if (c >= ncomp) continue;
+            double2 v = make_double2(0.0, 0.0);
+            if (l >= l0 && mt.count > 0) {
+                v = *reinterpret_cast<const double2 *>(partial + (r0 + (l - l0)) * ncol + (c >> 3) * NCOL + 2 * (c & 7));
+                if (fl) { v.x *= fl[l]; v.y *= fl[l]; }
+            }
+            double2 *dst = alm + (long long)c * alm_stride + almidx(lmax, l, m);
+            if (add) { const double2 o = *dst; v.x += o.x; v.y += o.y; }
+            *dst = v;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < nl * nc; i += blockDim.x) {
         const int l = m + i / nc, c = i % nc;
         if (c >= ncomp) continue;
@@ -1359,13 +1402,16 @@ static int build_task_set(hx_plan *pl, int spin, int nw, hx_plan::TaskSet &ts)
     ts.tasks.clear();
     ts.of_m.assign(lmax + 1, MTasks{0, 0});
     ts.rows_before_m.assign(lmax + 2, 0);
-    long long rows = 0;
+    ts.arow.assign(lmax + 2, 0);
+    long long rows = 0, arows = 0;
     // mlim is monotone in the ring index (pole -> equator): first active ring by bisection
     std::vector<int> mlim(pl->nrp);
     for (int rp = 0; rp < pl->nrp; ++rp) mlim[rp] = ring_mlim(lmax, spin, pl->h_sth[rp], pl->h_z[rp]);
     for (int m = 0; m <= lmax; ++m) {
         ts.rows_before_m[m] = rows;
+        ts.arow[m] = arows;
         const int l0 = spin == 0 ? m : std::max(m, 2);
+        if (l0 <= lmax) arows += (long long)LBLK * ((lmax - l0) / LBLK + 1);
         ts.of_m[m].first = (int)ts.tasks.size();
         if (l0 <= lmax) {
             int first = (int)(std::lower_bound(mlim.begin(), mlim.end(), m) - mlim.begin());
@@ -1380,8 +1426,10 @@ static int build_task_set(hx_plan *pl, int spin, int nw, hx_plan::TaskSet &ts)
         ts.of_m[m].count = (int)ts.tasks.size() - ts.of_m[m].first;
     }
     ts.rows_before_m[lmax + 1] = rows;
+    ts.arow[lmax + 1] = arows;
     HX_TRY(upload(ts.d_tasks, ts.tasks));
     HX_TRY(upload(ts.d_of_m, ts.of_m));
+    HX_TRY(upload(ts.d_arow, ts.arow));
     ts.built = true;
     return HX_OK;
 }
@@ -1424,6 +1472,9 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         A.m0 = m0; A.row0 = ts.rows_before_m[m0]; A.ng = ng; A.ncol = ncol;
         A.ablate = 0;
         A.counters = nullptr;
+        A.of_m = ts.d_of_m.as<MTasks>(); A.arow = ts.d_arow.as<long long>(); A.arow0 = ts.arow[m0];
+        if (!sh.quad) A.tasks = ts.d_tasks.as<LegTask>();  // the pipelined kernel indexes the whole list through of_m
+        if (!sh.quad) HX_HIP(hipMemsetAsync(pl->partial.p, 0, (size_t)(ts.arow[m1] - ts.arow[m0]) * ncol * sizeof(double), st));
 #if defined(HX_DIAG) && (HX_PIPE_ABL & 8)
         HX_TRY(pl->d_dbg.alloc(144));
         HX_HIP(hipMemsetAsync(pl->d_dbg.p, 0, 144, st));
@@ -1441,7 +1492,7 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         const double2 *cn = SPIN == 0 ? pl->cn0.as<double2>() : pl->cn2.as<double2>();
         const double *al = SPIN == 0 ? pl->al0.as<double>() : pl->al2.as<double>();
         constexpr int NW = LegCfg<SPIN>::NW;
-        dim3 grid((unsigned)(t1 - t0)), block(NW * 64), pblock(PipeCfg<SPIN>::NW * 64);
+        dim3 grid((unsigned)(t1 - t0)), block(NW * 64), pblock(PipeCfg<SPIN>::NW * 64), pgrid((unsigned)(m1 - m0));
         constexpr int QSUB = SPIN == 2 ? HX_QSUB2 : HX_QSUB0;
         constexpr int QNW = SPIN == 0 ? HX_QNW0 : NW;  // waves per work-group of the 4x4x4 variants
         if (sh.quad == 1)
@@ -1449,15 +1500,15 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         else if (sh.quad == 2)  // 140 VGPRs: two half-size groups do not fit a CU (104 vs 91 ms)
             hipLaunchKernelGGL((k_legendre_analysis<SPIN, -2, 0, QSUB>), grid, block, 0, st, A, cn, al);
         else if (sh.ng == 1 && sh.nbx == 0 && pipe_nsub(SPIN) == 2)
-            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 0, 2>), grid, pblock, 0, st, A, cn, al);
+            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 0, 2>), pgrid, pblock, 0, st, A, cn, al);
         else if (sh.ng == 1 && sh.nbx == 0)
-            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 0, 1>), grid, pblock, 0, st, A, cn, al);
+            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 0, 1>), pgrid, pblock, 0, st, A, cn, al);
         else if (sh.ng == 1 && sh.nbx == 1 && pipe_nsub(SPIN) == 2)
-            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 1, 2>), grid, pblock, 0, st, A, cn, al);
+            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 1, 2>), pgrid, pblock, 0, st, A, cn, al);
         else if (sh.ng == 1 && sh.nbx == 1)
-            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 1, 1>), grid, pblock, 0, st, A, cn, al);
+            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 1, 1>), pgrid, pblock, 0, st, A, cn, al);
         else if (sh.ng == 2 && sh.nbx == 0)
-            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 2, 0, 1>), grid, pblock, 0, st, A, cn, al);  // a second accumulator set spills 20-76 registers
+            hipLaunchKernelGGL((k_legendre_pipe<SPIN, 2, 0, 1>), pgrid, pblock, 0, st, A, cn, al);  // a second accumulator set spills 20-76 registers
         else
             return fail(HX_ERR_ARG, "legendre analysis: no kernel for %d groups + %d blocks", sh.ng, sh.nbx);
 #if defined(HX_DIAG) && (HX_PIPE_ABL & 8)
@@ -1486,7 +1537,8 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
     {
         ProfScope ps("alm_reduce");
         hipLaunchKernelGGL(k_alm_reduce<SPIN>, dim3(m1 - m0), dim3(256), 0, st, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
-                           pl->partial.as<double>(), ts.rows_before_m[m0], m0, nb, ng, ncol, d_fl, add, d_alms, pl->nlm);
+                           pl->partial.as<double>(), sh.quad ? ts.rows_before_m[m0] : ts.arow[m0], m0, nb, ng, ncol, d_fl, add, d_alms, pl->nlm,
+                           sh.quad ? nullptr : ts.d_arow.as<long long>());
     }
     HX_HIP(hipGetLastError());
     return HX_OK;
@@ -1525,19 +1577,21 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     }
     const double f_per_m = (double)pl->nrp_pad * 2 * nop * ncol * sizeof(double);
     const int lmax = pl->lmax;
+    // rows of the partial buffer: one span per (m, ring group) on the 4x4x4 kernels, one per m on the pipelined kernel
+    const std::vector<long long> &prow = sh.quad ? ts.rows_before_m : ts.arow;
     std::vector<std::pair<int, int>> chunks;
     size_t maxF = 16, maxP = 16;
     for (int m0 = 0; m0 <= lmax;) {
         int m1 = m0 + 1;  // a chunk holds at least one m, whatever the budget
         while (m1 <= lmax) {
             const double bytes = f_per_m * (m1 + 1 - m0) +
-                                 (double)(ts.rows_before_m[m1 + 1] - ts.rows_before_m[m0]) * ncol * sizeof(double);
+                                 (double)(prow[m1 + 1] - prow[m0]) * ncol * sizeof(double);
             if (bytes > budget) break;
             ++m1;
         }
         chunks.emplace_back(m0, m1);
         maxF = std::max(maxF, (size_t)(f_per_m * (m1 - m0)));
-        maxP = std::max(maxP, (size_t)(ts.rows_before_m[m1] - ts.rows_before_m[m0]) * ncol * sizeof(double));
+        maxP = std::max(maxP, (size_t)(prow[m1] - prow[m0]) * ncol * sizeof(double));
         m0 = m1;
     }
     HX_TRY(pl->F.alloc(maxF));

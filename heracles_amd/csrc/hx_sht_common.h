@@ -201,7 +201,8 @@ struct hx_plan {
         std::vector<hx::LegTask> tasks;       // ordered by m; tasks of one m contiguous
         std::vector<hx::MTasks> of_m;
         std::vector<long long> rows_before_m; // partial rows of all tasks with smaller m (size lmax+2)
-        hx::DevBuf d_tasks, d_of_m;
+        std::vector<long long> arow;          // the same with ONE span of rows per m (pipelined kernel: ring groups summed in place)
+        hx::DevBuf d_tasks, d_of_m, d_arow;
     } ts[3];  // spin 0, spin 2, spin 0 with half-size work-groups
     struct FftClass { int M, first, count, big; };
     std::vector<FftClass> fft_classes;   // ring pairs grouped by in-LDS FFT length

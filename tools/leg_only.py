@@ -1,4 +1,6 @@
-"""Diagnostic driver: a few spin-0 / spin-2 analysis launches at nside 2048 (for rocprofv3 --pmc)."""
+"""Diagnostic driver: one timed hx_map2alm (after two warm-up calls) with the per-family kernel times of the library's own
+HIP events.  NSIDE / LMAX / SPIN / NCOMP from the environment (defaults: nside 2048, lmax 3072, spin 0, 8 components);
+HX_LIBRARY selects another build of the library (A/B on one device)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,5 +14,8 @@ for _ in range(2):
     plan.map2alm(m, spin)
 hx._lib.profile_enable(True); hx._lib.profile_reset()
 plan.map2alm(m, spin)
-n, ms = hx._lib.profile_get("legendre_analysis")
-print("spin", spin, "legendre ms/launch", ms / n, "launches", n, "total ms", ms)
+out = []
+for fam in ("ring_fft", "fourier_combine", "legendre_analysis", "alm_reduce"):
+    n, ms = hx._lib.profile_get(fam)
+    out.append("%s %.2f ms / %d" % (fam, ms, n))
+print("spin", spin, "ncomp", m.shape[0], "|", " | ".join(out), "| lib", os.environ.get("HX_LIBRARY", "default"))
