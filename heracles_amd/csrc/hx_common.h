@@ -36,6 +36,7 @@ int fail(int code, const char *fmt, ...);
 struct Runtime {
     bool ready = false;
     int device = -1;
+    int cus = 256;  // compute units of the device (grid size of persistent kernels)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool async = false;

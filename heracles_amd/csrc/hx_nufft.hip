@@ -205,7 +205,7 @@ __device__ inline double2 rot4(double2 x, int k)  // x * (-i)^k
 // MODE 1: row m of T -> U[m][k mod N] = X[k mod n1] fac[k], |k| <= lmax
 // MODE 2: row m of U, inverse transform -> h[m][j]
 template <int MODE>
-__global__ __launch_bounds__(1024) void k_nufft_fft(NufftFft a)
+__global__ __launch_bounds__(512) void k_nufft_fft(NufftFft a)
 {
     extern __shared__ double2 buf[];
     __shared__ double2 tw_hi[TW_HI_MAX], tw_lo[64];
@@ -227,13 +227,13 @@ __global__ __launch_bounds__(1024) void k_nufft_fft(NufftFft a)
                 t = cadd(t, rot4(x, (4 / R) * q * r));
             }
             if (r && j) t = cmul(t, expipi(-2.0 * (double)(((long long)j * r) % n) / (double)n));
-            buf[j] = t;
+            buf[lds_slot(j)] = t;
         }
         __syncthreads();
         lds_fft_dif(buf, ns, twf, a.twN);
         for (int k = threadIdx.x; k < ns; k += blockDim.x) {
             const int idx = R * k + r;
-            const double2 v = buf[bitrev(k, p)];
+            const double2 v = buf[lds_slot(bitrev(k, p))];
             if (MODE == 0) {
                 if (idx <= a.lmax) a.dst[(long long)idx * a.n1 + row] = cscale(v, a.dec[idx]);
             } else if (MODE == 1) {
@@ -367,9 +367,9 @@ extern "C" int hx_pointsht_adjoint(hx_pointsht *ps, int spin, int ncomp, int64_t
     const int band = std::min(n1, n1 / 2 + W + 4);  // rows a point with 0 <= theta <= pi can touch
     a.row0 = (n1 - W / 2 - 2) % n1;
     auto launch = [&](int mode, int n, int rows) {
-        const int ns = std::min(n, NUFFT_LDS_MAX), threads = std::min(1024, std::max(64, ns / 4));
+        const int ns = std::min(n, NUFFT_LDS_MAX), threads = std::min(512, std::max(64, ns / 16));  // one radix-16 butterfly per thread and pass
         a.n = n;
-        const size_t lds = (size_t)ns * sizeof(double2);
+        const size_t lds = (size_t)lds_fft_slots(ns) * sizeof(double2);
         if (mode == 0) hipLaunchKernelGGL(k_nufft_fft<0>, dim3(rows), dim3(threads), lds, st, a);
         else if (mode == 1) hipLaunchKernelGGL(k_nufft_fft<1>, dim3(rows), dim3(threads), lds, st, a);
         else hipLaunchKernelGGL(k_nufft_fft<2>, dim3(rows), dim3(threads), lds, st, a);

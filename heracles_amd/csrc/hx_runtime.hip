@@ -301,6 +301,7 @@ int hx_init(int device)
     if (!r.t0) HX_HIP(hipEventCreate(&r.t0));
     if (!r.t1) HX_HIP(hipEventCreate(&r.t1));
     r.device = device;
+    r.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     r.ready = true;
     return HX_OK;
 }

@@ -94,7 +94,10 @@ __global__ void k_init_norm2(int lmax, double2 *__restrict__ coef, double *__res
 }
 
 // Bluestein filter spectra, one block per ring pair whose sub-length is not a power of two
-// and is the first ring with that length.
+// and is the first ring with that length.  The spectrum H (bit-reversed order, as the forward passes leave it) is stored
+// TRANSPOSED, bhat[j (M/16) + i] = H[16 i + j]: in the ring kernel the thread that owns elements 16 i .. 16 i + 15 after the
+// last forward pass multiplies them in registers, and for a fixed j consecutive threads then read consecutive entries
+// (M < 16 -- the ring of 12 pixels -- keeps the plain order).
 __global__ __launch_bounds__(512) void k_init_bhat(PlanDev P, const int *__restrict__ rp_list,
                                                    double2 *__restrict__ bhat)
 {
@@ -102,17 +105,17 @@ __global__ __launch_bounds__(512) void k_init_bhat(PlanDev P, const int *__restr
     const int rp = rp_list[blockIdx.x];
     const int n = P.nsub[rp];
     const int M = fft_size_for(n);
-    for (int j = threadIdx.x; j < M; j += blockDim.x) buf[j] = make_double2(0.0, 0.0);
+    for (int j = threadIdx.x; j < lds_fft_slots(M); j += blockDim.x) buf[j] = make_double2(0.0, 0.0);
     __syncthreads();
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         double2 c = expipi((double)chirp_num(j, n) / (double)n);
-        buf[j] = c;
-        if (j) buf[M - j] = c;
+        buf[lds_slot(j)] = c;
+        if (j) buf[lds_slot(M - j)] = c;
     }
     __syncthreads();
     lds_fft_dif(buf, M, P.tw, P.twN);
     double2 *out = bhat + P.bhat_off[rp];
-    for (int j = threadIdx.x; j < M; j += blockDim.x) out[j] = buf[j];
+    for (int e = threadIdx.x; e < M; e += blockDim.x) out[M >= 16 ? (e & 15) * (M >> 4) + (e >> 4) : e] = buf[lds_slot(e)];
 }
 
 // =====================================================================================
@@ -120,104 +123,173 @@ __global__ __launch_bounds__(512) void k_init_bhat(PlanDev P, const int *__restr
 // =====================================================================================
 // MODE 0: input = real maps (N ring -> real part, S ring -> imaginary part)
 // MODE 1: input = complex spectrum Zc[c][ny-layout natural order] (synthesis: conj trick)
-constexpr int RING_JMAX = 4;  // values of j per thread: the launch uses >= n / RING_JMAX threads
+//
+// A work item is ONE of the four length-n sub-DFTs X[4k + r] of a (ring pair, component): the group reads the 4n packed
+// pixels z_q[j] = z[j + q n], forms t_r[j] = sum_q z_q[j] (-i)^(q r) on the fly and runs one transform in a padded LDS buffer,
+// M / 16 threads, one radix-16 butterfly each per pass.  The four items of a ring pair are dealt to four work-groups of the
+// SAME XCD that run at the same time (items are numbered xcd-minor, groups are persistent and walk items b, b + G, ...), so
+// the pixels come from HBM once and from that XCD's L2 three more times -- and no thread has to keep a ring's pixels in
+// registers across four transforms, which is what held the first version at one wave per SIMD with every latency exposed
+// (256 registers of pixels beside the butterfly).  A transform is 3-4 LDS round trips (fused radix-8 / radix-16 passes); a
+// Bluestein convolution fuses the last forward pass, the filter and the first inverse pass in registers (they work on the
+// same 16 consecutive elements): 5-7 round trips for what were 13-15 with radix-4 passes and a filter pass of its own.  The
+// filter values of a thread's butterfly are requested before the forward passes.  Every phase factor exp(-i pi q / 2n) (load
+// phase, Bluestein chirps) is hi[q >> 6] lo[q & 63] from two small tables built per item in LDS: (4n / 64 + 65) sincos per
+// item instead of one per pixel.
+#if HX_FFT_ABL & 32  // cycle accounting of the ring kernel (diagnostic build): phases summed over thread 0 of every work-group
+__device__ unsigned long long g_fft_cyc[8];
+#define HX_FSTAMP(i) do { if (tid == 0) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); fcyc[i] += tn_ - flast; flast = tn_; } } while (0)
+#else
+#define HX_FSTAMP(i) do { } while (0)
+#endif
+__host__ __device__ inline int ring_ph_hi(int M) { return (4 * M) / 64 + 1; }  // entries of the coarse phase table: q >> 6 for q < 4n, n <= M
+constexpr int RING_NTMAX = 512;  // threads per group: M / 16 (one radix-16 butterfly per thread and pass), 64 at least
 
 template <int MODE>
-__global__ __launch_bounds__(1024) void k_ring_subdft(PlanDev P, const int *__restrict__ rp_list,
-                                                      const double *__restrict__ maps,
-                                                      const double *__restrict__ pixw,
-                                                      const double2 *__restrict__ zin,
-                                                      double2 *__restrict__ Y)
+__global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int *__restrict__ rp_list, int nrings, int nb, int Mclass,
+                                                            const double *__restrict__ maps,
+                                                            const double *__restrict__ pixw,
+                                                            const double2 *__restrict__ zin,
+                                                            double2 *__restrict__ Y)
 {
-    extern __shared__ double2 buf[];
-    const int rp = rp_list[blockIdx.y];          // ring pairs of one FFT-size class
-    const int c = blockIdx.z;
-    const int n = P.nsub[rp];
-    const long long sN = P.startN[rp], sS = P.startS[rp];
-    const int M = fft_size_for(n);
-    const bool blu = M != n;
-    const int p = ilog2(M);
-    const double *mp = maps + (long long)c * P.npix;
-    const double2 *zp = zin + (long long)c * P.ny + sN;
-
-    // One work-group owns the ring pair: its 4n pixels (z_q[j] = z[j + q n]) are read from HBM ONCE
-    // into registers -- the launch gives every thread at most RING_JMAX values of j -- and the four
-    // length-n sub-DFTs r = 0..3 (X[4k + r]) run back to back through the same LDS buffer.
-    double2 zq[RING_JMAX][4];
-#pragma unroll
-    for (int u = 0; u < RING_JMAX; ++u) {
-        const int j = threadIdx.x + u * blockDim.x;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            zq[u][q] = make_double2(0.0, 0.0);
-            if (j < n) {
-                if (MODE == 0) {
-                    const long long iN = sN + j + (long long)q * n;
-#if HX_FFT_ABL & 16
-                    zq[u][q] = make_double2(1.0 + j, 2.0 + q); continue;
-#endif
-                    double fn = mp[iN];
-                    if (pixw) fn *= pixw[iN];
-                    double fs = 0.0;
-                    if (sS >= 0) {
-                        const long long iS = sS + j + (long long)q * n;
-                        fs = mp[iS];
-                        if (pixw) fs *= pixw[iS];
-                    }
-                    zq[u][q] = make_double2(fn, fs);
-                } else {
-                    zq[u][q] = zp[j + (long long)q * n];
-                }
-            }
-        }
-    }
-    const double2 *bh = P.bhat + P.bhat_off[rp];
-    const double inv = 1.0 / M;
+    extern __shared__ double2 buf[];  // the padded transform buffer of the class's M, then the phase tables (4 M / 64 + 1 and 64 entries)
     __shared__ double2 tw_hi[TW_HI_MAX], tw_lo[64];
+    double2 *ph_hi = buf + lds_fft_slots(Mclass), *ph_lo = ph_hi + ring_ph_hi(Mclass);
+    const int nt = blockDim.x, nrc = nrings * nb;
+    const int nitems = ((nrc + 7) >> 3) * 32;  // (ring, component) pairs padded to whole sets of 8 (one per XCD) x 4 sub-DFTs
     const TwFactored twf = load_tw_factored(tw_hi, tw_lo, P.tw, P.twN);  // visible after the first barrier below
-    for (int r = 0; r < 4; ++r) {
-        if (r) __syncthreads();  // the previous sub-DFT has been read out of buf
-#pragma unroll
-        for (int u = 0; u < RING_JMAX; ++u) {
-            const int j = threadIdx.x + u * blockDim.x;
-            if (j < n) {
-                const double2 t = dif4_combine(zq[u][0], zq[u][1], zq[u][2], zq[u][3], r);
-                const unsigned qn = load_phase_num(j, r, n, blu);
-#if HX_FFT_ABL & 1
-                buf[j] = cmul(t, make_double2(0.5, (double)qn));
-#else
-                buf[j] = qn ? cmul(t, expipi(-(double)qn / (2.0 * n))) : t;
+    int tid = threadIdx.x;
+#if HX_FFT_ABL & 32
+    unsigned long long fcyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flast = __builtin_amdgcn_s_memtime();
 #endif
-            }
-        }
-        for (int j = n + threadIdx.x; j < M; j += blockDim.x) buf[j] = make_double2(0.0, 0.0);  // Bluestein padding
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        // item = 8 (4 s + r) + x: sub-DFT r of pair 8 s + x -- the four r of a pair in four groups of XCD x, side by side in time
+        const int r = (item >> 3) & 3, rc = ((item >> 5) << 3) + (item & 7);
+        if (rc >= nrc) continue;  // padding of the last set of 8 pairs
+        const int rp = rp_list[rc / nb], c = rc % nb;
+        const int n = P.nsub[rp];
+        const long long sN = P.startN[rp], sS = P.startS[rp];
+        const int M = fft_size_for(n), MP = lds_fft_slots(M);
+        const bool blu = M != n;
+        const int p = ilog2(M);
+        const double2 *bh = P.bhat + P.bhat_off[rp];
+        const double inv = 1.0 / M, inv4n = 0.25 / (double)n;
+        // the thread index goes through an empty asm statement per item, so that what derives from it (LDS addresses, pixel
+        // offsets) is set up per item instead of being hoisted out of this loop and kept in registers across the passes
+        asm volatile("; item" : "+v"(tid));
+        __syncthreads();  // the previous item's last readers of the phase tables and of the buffer
+        for (int a = tid; a <= (4 * n) >> 6; a += nt) ph_hi[a] = expipi(-(double)(a << 6) / (2.0 * n));
+        if (tid < 64) ph_lo[tid] = expipi(-(double)tid / (2.0 * n));
         __syncthreads();
-#if !(HX_FFT_ABL & 2)
-        lds_fft_dif(buf, M, twf, P.twN);
+        HX_FSTAMP(0);
+        auto phase = [&](unsigned q) __attribute__((always_inline)) {  // exp(-i pi q / 2n), q < 4n
+#if HX_FFT_ABL & 1
+            return make_double2(0.5, (double)q);
+#else
+            return cmul(ph_hi[q >> 6], ph_lo[q & 63]);
 #endif
+        };
+        // ---- fill: t_r[j] x load phase.  t_r = (a, c)[r & 1] +- (b, d)[r & 1] with a = z0 + z2, b = z1 + z3, c = z0 - z2,
+        // d = -i (z1 - z3); a missing southern ring (the equator) reads the northern one and selects 0 ----
+        {
+            const bool haveS = sS >= 0, pw = MODE == 0 && pixw != nullptr, odd = r & 1;
+            const double sg = (r & 2) ? -1.0 : 1.0;
+            const double *mpN = maps + (long long)c * P.npix + sN, *mpS = maps + (long long)c * P.npix + (haveS ? sS : sN);
+            const double *pwN = pixw + sN, *pwS = pixw + (haveS ? sS : sN);
+            const double2 *zp = zin + (long long)c * P.ny + sN;
+#pragma unroll 4
+            for (int j = tid; j < n; j += nt) {
+                double2 z[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = j + q * n;
+                    if (MODE == 0) {
+#if HX_FFT_ABL & 16
+                        z[q] = make_double2(1.0 + j, 2.0 + q); continue;
+#endif
+                        double fn = mpN[i], fs = mpS[i];
+                        if (pw) { fn *= pwN[i]; fs *= pwS[i]; }
+                        z[q] = make_double2(fn, haveS ? fs : 0.0);
+                    } else {
+                        z[q] = zp[i];
+                    }
+                }
+                const double2 e0 = odd ? csub(z[0], z[2]) : cadd(z[0], z[2]);
+                const double2 e1 = odd ? mul_mi(csub(z[1], z[3])) : cadd(z[1], z[3]);
+                const double2 t = make_double2(fma(sg, e1.x, e0.x), fma(sg, e1.y, e0.y));
+                // (j r + 2 j^2 [Bluestein]) mod 4n = load_phase_num(j, r, n, blu); j < 2^13: 32 bits hold it
+                const unsigned qn = mod_by_inv((unsigned)j * (unsigned)r + (blu ? 2u * (unsigned)j * (unsigned)j : 0u), 4u * (unsigned)n, inv4n);
+                buf[lds_slot(j)] = cmul(t, phase(qn));
+            }
+            if (blu)
+                for (int j = n + tid; j < M; j += nt) buf[lds_slot(j)] = make_double2(0.0, 0.0);  // Bluestein padding
+        }
+        __syncthreads();
+        HX_FSTAMP(1);
         double2 *out = Y + (long long)c * P.ny + sN + (long long)r * n;
         if (!blu) {
-            for (int k = threadIdx.x; k < n; k += blockDim.x) out[k] = buf[bitrev(k, p)];
+#if !(HX_FFT_ABL & 2)
+            lds_fft_dif(buf, M, twf, P.twN);
+#endif
+            HX_FSTAMP(2);
+            for (int k = tid; k < n; k += nt) out[k] = buf[lds_slot(bitrev(k, p))];
+            HX_FSTAMP(5);
             continue;
         }
+        if (M >= 16) {
+            // filter values of this thread's first butterfly of the fused pass: requested before the forward passes, which
+            // cover the trip to L2 / HBM (waited for inside the butterfly loop it cost 13 000 cycles per butterfly)
+            double2 bq[16];
+            const int nbf = M >> 4;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) bq[j] = bh[j * nbf + (tid < nbf ? tid : 0)];
+#if !(HX_FFT_ABL & 2)
+            lds_fft_dif(buf, M, twf, P.twN, tid, nt, true);
+#endif
+            HX_FSTAMP(2);
+            // last forward pass (h = 1: no twiddles), filter, first inverse pass on the thread's 16 consecutive elements
+#pragma unroll 1
+            for (int i = tid; i < nbf; i += nt) {
+                double2 x[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) x[j] = buf[lds_slot(16 * i) + j];
+                dif_regs<4>(x);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
 #if HX_FFT_ABL & 4
-        for (int j = threadIdx.x; j < M; j += blockDim.x) buf[j] = cmul(buf[j], make_double2(0.5, (double)j));
+                    x[j] = cmul(x[j], make_double2(0.5, (double)j));
 #else
-        for (int j = threadIdx.x; j < M; j += blockDim.x) buf[j] = cmul(buf[j], bh[j]);
+                    x[j] = cmul(x[j], bq[j]);
 #endif
-        __syncthreads();
+                }
+                if (i + nt < nbf) {  // (groups of fewer than M / 16 threads: tiny rings only)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) bq[j] = bh[j * nbf + i + nt];
+                }
+                dit_inv_regs<4>(x);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) buf[lds_slot(16 * i) + j] = x[j];
+            }
+            __syncthreads();
+            HX_FSTAMP(3);
 #if !(HX_FFT_ABL & 8)
-        lds_fft_dit_inv(buf, M, twf, P.twN);
+            lds_fft_dit_inv(buf, M, twf, P.twN, tid, nt, true);
 #endif
-        for (int k = threadIdx.x; k < n; k += blockDim.x) {
-#if HX_FFT_ABL & 1
-            const double2 cz = make_double2(0.5, (double)chirp_num(k, n));
-#else
-            const double2 cz = expipi(-(double)chirp_num(k, n) / (double)n);
-#endif
-            out[k] = cscale(cmul(buf[k], cz), inv);
+            HX_FSTAMP(4);
+        } else {
+            lds_fft_dif(buf, M, twf, P.twN, tid, nt);
+            for (int j = tid; j < M; j += nt) buf[lds_slot(j)] = cmul(buf[lds_slot(j)], bh[j]);
+            __syncthreads();
+            lds_fft_dit_inv(buf, M, twf, P.twN, tid, nt);
         }
+        for (int k = tid; k < n; k += nt)  // chirp exp(-i pi k^2 / n)
+            out[k] = cscale(cmul(buf[lds_slot(k)], phase(2u * mod_by_inv((unsigned)k * (unsigned)k, 2u * (unsigned)n, 2.0 * inv4n))), inv);
+        HX_FSTAMP(5);
     }
+#if HX_FFT_ABL & 32
+    if (tid == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_fft_cyc[i], fcyc[i]);
+#endif
 }
 
 // =====================================================================================
@@ -229,9 +301,9 @@ __global__ __launch_bounds__(1024) void k_ring_subdft(PlanDev P, const int *__re
 //     pipeline of the other rings (FFT_C -> filter -> IFFT_C) on one C-point buffer; the even half's result waits in
 //     registers while the odd half runs.  The filter spectra are stored as [even bins | odd bins].
 // =====================================================================================
-constexpr int SPLIT_JMAX = 8;  // values of j per thread of the split kernels (n <= C = 8 x 1024 threads at most)
+constexpr int SPLIT_JMAX = 16;  // values of j per thread of the split kernels (n <= C = 16 x 512 threads at most; 512 threads: 256 registers for the radix-16 passes)
 
-__global__ __launch_bounds__(1024) void k_init_bhat_split(PlanDev P, const int *__restrict__ rp_list, int C,
+__global__ __launch_bounds__(512) void k_init_bhat_split(PlanDev P, const int *__restrict__ rp_list, int C,
                                                           double2 *__restrict__ bhat)
 {
     extern __shared__ double2 buf[];
@@ -247,16 +319,16 @@ __global__ __launch_bounds__(1024) void k_init_bhat_split(PlanDev P, const int *
         __syncthreads();
         for (int j = threadIdx.x; j < C; j += blockDim.x) {
             const double2 b0 = b_at(j), b1 = b_at(j + C);
-            buf[j] = half == 0 ? cadd(b0, b1) : cmul(csub(b0, b1), P.tw[j]);  // tw[j] = W_M^j (twN = M)
+            buf[lds_slot(j)] = half == 0 ? cadd(b0, b1) : cmul(csub(b0, b1), P.tw[j]);  // tw[j] = W_M^j (twN = M)
         }
         __syncthreads();
         lds_fft_dif(buf, C, P.tw, P.twN);
-        for (int j = threadIdx.x; j < C; j += blockDim.x) out[half * C + j] = buf[j];
+        for (int j = threadIdx.x; j < C; j += blockDim.x) out[half * C + j] = buf[lds_slot(j)];
     }
 }
 
 template <int MODE>
-__global__ __launch_bounds__(1024) void k_ring_subdft_split(PlanDev P, const int *__restrict__ rp_list, int C,
+__global__ __launch_bounds__(512) void k_ring_subdft_split(PlanDev P, const int *__restrict__ rp_list, int C,
                                                             const double *__restrict__ maps, const double *__restrict__ pixw,
                                                             const double2 *__restrict__ zin, double2 *__restrict__ Y)
 {
@@ -306,13 +378,13 @@ __global__ __launch_bounds__(1024) void k_ring_subdft_split(PlanDev P, const int
 #pragma unroll
             for (int u = 0; u < SPLIT_JMAX; ++u) {
                 const int j = threadIdx.x + u * blockDim.x;
-                if (j < n) buf[j] = a0[u];
+                if (j < n) buf[lds_slot(j)] = a0[u];
             }
             __syncthreads();
             lds_fft_dif(buf, n, twf, P.twN);
             double2 *outp = Y + (long long)c * P.ny + sN + (long long)r * n;
             const int pbits = ilog2(n);
-            for (int k = threadIdx.x; k < n; k += blockDim.x) outp[k] = buf[bitrev(k, pbits)];
+            for (int k = threadIdx.x; k < n; k += blockDim.x) outp[k] = buf[lds_slot(bitrev(k, pbits))];
             continue;
         }
         for (int half = 0; half < 2; ++half) {
@@ -320,19 +392,19 @@ __global__ __launch_bounds__(1024) void k_ring_subdft_split(PlanDev P, const int
 #pragma unroll
             for (int u = 0; u < SPLIT_JMAX; ++u) {
                 const int j = threadIdx.x + u * blockDim.x;
-                if (j < C) buf[j] = (j < n) ? (half == 0 ? a0[u] : cmul(a0[u], twf[j])) : make_double2(0.0, 0.0);
+                if (j < C) buf[lds_slot(j)] = (j < n) ? (half == 0 ? a0[u] : cmul(a0[u], twf[j])) : make_double2(0.0, 0.0);
             }
             __syncthreads();
             lds_fft_dif(buf, C, twf, P.twN);
-            for (int j = threadIdx.x; j < C; j += blockDim.x) buf[j] = cmul(buf[j], bh[half * C + j]);
+            for (int j = threadIdx.x; j < C; j += blockDim.x) buf[lds_slot(j)] = cmul(buf[lds_slot(j)], bh[half * C + j]);
             __syncthreads();
             lds_fft_dit_inv(buf, C, twf, P.twN);
 #pragma unroll
             for (int u = 0; u < SPLIT_JMAX; ++u) {
                 const int k = threadIdx.x + u * blockDim.x;
                 if (k < n) {
-                    if (half == 0) ye[u] = buf[k];
-                    else ye[u] = cadd(ye[u], cmulc(buf[k], twf[k]));  // + W_M^-k y_odd[k]
+                    if (half == 0) ye[u] = buf[lds_slot(k)];
+                    else ye[u] = cadd(ye[u], cmulc(buf[lds_slot(k)], twf[k]));  // + W_M^-k y_odd[k]
                 }
             }
         }
@@ -495,7 +567,7 @@ static int plan_tables(hx_plan *pl)
     HX_HIP(hipMemsetAsync(pl->al0.p, 0, sizeof(double) * (pl->nlm + TABLE_PAD), st));
     hipLaunchKernelGGL(k_init_norm0, dim3((2 * (lmax + 1) + 63) / 64), dim3(64), 0, st, lmax, pl->cn0.as<double2>(), pl->al0.as<double>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_bhat), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    // 3 KiB of the 160 KiB are the static factored-twiddle tables of k_ring_subdft
+    // 3 KiB of the 160 KiB are the static twiddle tables of k_ring_subdft
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_bhat_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -552,10 +624,8 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
     {
         // FFT-size classes: ring pairs grouped by in-LDS FFT length, longest rings first; rings beyond the limit form
         // the split class (M = 2 x cap)
-        // (rings of more than RING_JMAX x 1024 pixels per sub-DFT -- n = 8192 at nside 8192 -- cannot keep their pixels in
-        // registers: they go through the kernel that re-reads them per sub-DFT, like the split rings)
         std::map<std::pair<int, int>, std::vector<int>> byM;
-        for (int rp = pl->nrp - 1; rp >= 0; --rp) byM[{fft_size_for(nsub[rp]), nsub[rp] > RING_JMAX * 1024 ? 1 : 0}].push_back(rp);
+        for (int rp = pl->nrp - 1; rp >= 0; --rp) byM[{fft_size_for(nsub[rp]), 0}].push_back(rp);
         std::vector<int> list;
         for (auto it = byM.rbegin(); it != byM.rend(); ++it) {
             hx_plan::FftClass c;
@@ -566,7 +636,7 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
         if (upload(pl->fft_rp_list, list) != HX_OK) { delete pl; return nullptr; }
     }
     pl->twN = std::max(maxM, 2);
-    pl->lds_fft = (size_t)std::min(maxM, cap) * sizeof(double2);
+    pl->lds_fft = (size_t)lds_fft_slots(std::min(maxM, cap)) * sizeof(double2);
     pl->h_sth = sth; pl->h_z = z; pl->h_nsub = nsub;
     // Bluestein tables: one spectrum per distinct non-power-of-two sub-length
     std::vector<int> blu_list, blu_split;
@@ -603,7 +673,7 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
     if (!blu_split.empty()) {
         DevBuf d_list;
         if (upload(d_list, blu_split) != HX_OK) { delete pl; return nullptr; }
-        hipLaunchKernelGGL(k_init_bhat_split, dim3((unsigned)blu_split.size()), dim3(std::min(1024, std::max(64, cap / 4))), (size_t)cap * sizeof(double2), st,
+        hipLaunchKernelGGL(k_init_bhat_split, dim3((unsigned)blu_split.size()), dim3(std::min(512, std::max(64, cap / 16))), (size_t)lds_fft_slots(cap) * sizeof(double2), st,
                            pl->dev(), d_list.as<int>(), cap, pl->bhat.as<double2>());
         (void)hipStreamSynchronize(st);
     }
@@ -683,15 +753,31 @@ static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, cons
 {
     for (const auto &c : pl->fft_classes) {
         if (c.M > pl->fft_cap || c.big) {  // Bluestein convolution of 2 x cap points in two halves / plain FFT of > 4096 points
-            const int C = std::min(c.M, pl->fft_cap), threads = std::min(1024, std::max(64, C / SPLIT_JMAX));
-            hipLaunchKernelGGL(k_ring_subdft_split<MODE>, dim3(1, c.count, nb), dim3(threads), (size_t)C * sizeof(double2), rt().stream,
+            const int C = std::min(c.M, pl->fft_cap), threads = std::min(512, std::max(64, C / SPLIT_JMAX));
+            hipLaunchKernelGGL(k_ring_subdft_split<MODE>, dim3(1, c.count, nb), dim3(threads), (size_t)lds_fft_slots(C) * sizeof(double2), rt().stream,
                                pl->dev(), pl->fft_rp_list.as<int>() + c.first, C, d_maps, d_pw, zin, Y);
             continue;
         }
-        // one radix-4 butterfly per thread and pass (M/4 threads); n <= M <= RING_JMAX * threads
-        const int threads = std::min(1024, std::max(256, c.M / 4));  // M/8 threads (two butterflies each): 23.0 vs 21.0 ms
-        hipLaunchKernelGGL(k_ring_subdft<MODE>, dim3(1, c.count, nb), dim3(threads), (size_t)c.M * sizeof(double2), rt().stream,
-                           pl->dev(), pl->fft_rp_list.as<int>() + c.first, d_maps, d_pw, zin, Y);
+        // M / 16 threads per group (one radix-16 butterfly per thread and pass); persistent groups, as many as the CUs hold at
+        // once: LDS (the padded buffer, the phase tables behind it, 3 KiB of twiddle tables) and 8 waves per CU, so that every wave has 256 registers
+        const int threads = std::min(RING_NTMAX, std::max(64, c.M / 16));
+        const size_t lds = (size_t)(lds_fft_slots(c.M) + ring_ph_hi(c.M) + 64) * sizeof(double2);
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(512 / threads, (160 * 1024) / (lds + 3 * 1024 + 256)));
+        const long long items = ((long long)c.count * nb + 7) / 8 * 32;
+        const unsigned groups = (unsigned)std::min<long long>(items, (long long)rt().cus * per_cu);
+        hipLaunchKernelGGL(k_ring_subdft<MODE>, dim3(groups), dim3(threads), lds, rt().stream,
+                           pl->dev(), pl->fft_rp_list.as<int>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+#if HX_FFT_ABL & 32
+        {
+            unsigned long long hc[8], z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            (void)hipStreamSynchronize(rt().stream);
+            (void)hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_fft_cyc), sizeof(hc));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fft_cyc), z8, sizeof(z8));
+            const double items = (double)c.count * nb;
+            fprintf(stderr, "[hx] fft class M %5d rings %5d: cycles (x 100 MHz ticks) per item: load+tables %.0f  fill %.0f  fwd %.0f  middle %.0f  inv %.0f  out %.0f\n", c.M, c.count,
+                    hc[0] / items, hc[1] / items, hc[2] / items, hc[3] / items, hc[4] / items, hc[5] / items);
+        }
+#endif
     }
     HX_HIP(hipGetLastError());
     return HX_OK;

@@ -126,36 +126,72 @@ __device__ inline void spin2_seeds(int m, double sth, double omx, double kfac2m,
 
 #ifdef __HIPCC__
 using namespace hxfft;
-// In-LDS FFT drivers (all threads of the block participate): fused radix-4 stages, plus one
-// radix-2 stage when log2(M) is odd.  Same data layout / bit-reversed order as pure radix-2
-// (tests/csrc/test_fft_core.cpp runs this exact schedule on the host).
+// In-LDS FFT drivers on the padded buffer of hx_fft_core.h (element e in slot lds_slot(e)): fused radix-2^K passes, K <= 4,
+// schedule fft_sched_k(log2 M, pass) (tests/csrc/test_fft_core.cpp runs this exact schedule on the host).  Thread gt of the gn threads
+// that share one transform; EVERY thread of the block must call (one __syncthreads per pass), all with the same M.
 template <class TW>
-__device__ inline void lds_fft_dif(double2 *buf, int M, TW tw, int twN)
+__device__ __forceinline__ void lds_fft_pass_dif(double2 *buf, int M, int K, int h, int gt, int gn, TW tw, int twN)
 {
-    int h = M >> 1;
-    if (ilog2(M) & 1) {
-        for (int i = threadIdx.x; i < (M >> 1); i += blockDim.x) dif_butterfly(buf, i, h, tw, twN);
-        __syncthreads();
-        h >>= 1;
+    switch (K) {
+    case 4:
+_Pragma("unroll 1")
+        for (int i = gt; i < (M >> 4); i += gn) dif_pass_butterfly<4>(buf, i, h, tw, twN); break;
+    case 3:
+_Pragma("unroll 1")
+        for (int i = gt; i < (M >> 3); i += gn) dif_pass_butterfly<3>(buf, i, h, tw, twN); break;
+    case 2:
+_Pragma("unroll 1")
+        for (int i = gt; i < (M >> 2); i += gn) dif_pass_butterfly<2>(buf, i, h, tw, twN); break;
+    default: for (int i = gt; i < (M >> 1); i += gn) dif_pass_butterfly<1>(buf, i, h, tw, twN); break;
     }
-    for (h >>= 1; h >= 1; h >>= 2) {
-        for (int i = threadIdx.x; i < (M >> 2); i += blockDim.x) dif4_butterfly(buf, i, h, tw, twN);
+}
+template <class TW>
+__device__ __forceinline__ void lds_fft_pass_dit_inv(double2 *buf, int M, int K, int h, int gt, int gn, TW tw, int twN)
+{
+    switch (K) {
+    case 4:
+_Pragma("unroll 1")
+        for (int i = gt; i < (M >> 4); i += gn) dit_inv_pass_butterfly<4>(buf, i, h, tw, twN); break;
+    case 3:
+_Pragma("unroll 1")
+        for (int i = gt; i < (M >> 3); i += gn) dit_inv_pass_butterfly<3>(buf, i, h, tw, twN); break;
+    case 2:
+_Pragma("unroll 1")
+        for (int i = gt; i < (M >> 2); i += gn) dit_inv_pass_butterfly<2>(buf, i, h, tw, twN); break;
+    default: for (int i = gt; i < (M >> 1); i += gn) dit_inv_pass_butterfly<1>(buf, i, h, tw, twN); break;
+    }
+}
+// forward passes first .. last-1 of the schedule (skip_last: the caller fuses the h = 1 pass with what follows)
+template <class TW>
+__device__ __forceinline__ void lds_fft_dif(double2 *buf, int M, TW tw, int twN, int gt, int gn, bool skip_last = false)
+{
+    const int p = ilog2(M), np = fft_sched_np(p);
+    int h = M;
+    for (int a = 0; a < np - (skip_last ? 1 : 0); ++a) {
+        const int K = fft_sched_k(p, a);
+        h >>= K;
+        lds_fft_pass_dif(buf, M, K, h, gt, gn, tw, twN);
         __syncthreads();
     }
 }
 template <class TW>
-__device__ inline void lds_fft_dit_inv(double2 *buf, int M, TW tw, int twN)
+__device__ __forceinline__ void lds_fft_dit_inv(double2 *buf, int M, TW tw, int twN, int gt, int gn, bool skip_first = false)
 {
+    const int p = ilog2(M), np = fft_sched_np(p);
     int h = 1;
-    for (; 4 * h <= M; h <<= 2) {
-        for (int i = threadIdx.x; i < (M >> 2); i += blockDim.x) dit4_inv_butterfly(buf, i, h, tw, twN);
-        __syncthreads();
-    }
-    if (2 * h <= M) {
-        for (int i = threadIdx.x; i < (M >> 1); i += blockDim.x) dit_inv_butterfly(buf, i, h, tw, twN);
-        __syncthreads();
+    for (int a = np - 1; a >= 0; --a) {
+        const int K = fft_sched_k(p, a);
+        if (!(skip_first && a == np - 1)) {
+            lds_fft_pass_dit_inv(buf, M, K, h, gt, gn, tw, twN);
+            __syncthreads();
+        }
+        h <<= K;
     }
 }
+template <class TW>
+__device__ __forceinline__ void lds_fft_dif(double2 *buf, int M, TW tw, int twN) { lds_fft_dif(buf, M, tw, twN, (int)threadIdx.x, (int)blockDim.x); }
+template <class TW>
+__device__ __forceinline__ void lds_fft_dit_inv(double2 *buf, int M, TW tw, int twN) { lds_fft_dit_inv(buf, M, tw, twN, (int)threadIdx.x, (int)blockDim.x); }
 
 // Fills the factored twiddle tables of TwFactored from the plan's full table (twN/2 entries).
 // LDS: hi[twN/128], lo[64].  The caller synchronises before the first butterfly.

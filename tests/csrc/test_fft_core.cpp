@@ -1,5 +1,5 @@
 // Host emulation of the ring sub-DFT kernel's algorithm (hx_fft_core.h): radix-4 DIF split,
-// in-place DIF FFT / Bluestein with bit-reversed spectrum, DIT inverse.  Compares against a
+// in-place DIF FFT (fused radix-2^K passes on the padded buffer) / Bluestein with bit-reversed spectrum, DIT inverse.  Compares against a
 // direct O(n^2) DFT of the full length-4n ring.  Build: g++ -O2 -std=c++17 test_fft_core.cpp
 #include <cmath>
 #include <complex>
@@ -21,27 +21,46 @@ static std::vector<double2> make_tw(int twN)
 }
 static double2 expipi(double x) /* exp(i pi x) */ { return mk(cos(M_PI * x), sin(M_PI * x)); }
 
-// same stage schedule as lds_fft_dif / lds_fft_dit_inv in hx_sht.hip: fused radix-4 stages,
-// plus one radix-2 stage when log2(M) is odd
+// same pass schedule as lds_fft_dif / lds_fft_dit_inv in hx_sht_common.h: fused radix-2^K passes (fft_sched_k) on the padded buffer
 template <class TW>
-static void fft_dif(std::vector<double2> &b, int M, TW tw, int twN)
+static void pass_dif(std::vector<double2> &b, int M, int K, int h, TW tw, int twN)
 {
-    int h = M / 2;
-    if (ilog2(M) & 1) {
-        for (int i = 0; i < M / 2; ++i) dif_butterfly(b.data(), i, h, tw, twN);
-        h >>= 1;
+    for (int i = 0; i < (M >> K); ++i) {
+        if (K == 4) dif_pass_butterfly<4>(b.data(), i, h, tw, twN);
+        else if (K == 3) dif_pass_butterfly<3>(b.data(), i, h, tw, twN);
+        else if (K == 2) dif_pass_butterfly<2>(b.data(), i, h, tw, twN);
+        else dif_pass_butterfly<1>(b.data(), i, h, tw, twN);
     }
-    for (h >>= 1; h >= 1; h >>= 2)
-        for (int i = 0; i < M / 4; ++i) dif4_butterfly(b.data(), i, h, tw, twN);
 }
 template <class TW>
-static void fft_dit_inv(std::vector<double2> &b, int M, TW tw, int twN)
+static void pass_dit_inv(std::vector<double2> &b, int M, int K, int h, TW tw, int twN)
 {
+    for (int i = 0; i < (M >> K); ++i) {
+        if (K == 4) dit_inv_pass_butterfly<4>(b.data(), i, h, tw, twN);
+        else if (K == 3) dit_inv_pass_butterfly<3>(b.data(), i, h, tw, twN);
+        else if (K == 2) dit_inv_pass_butterfly<2>(b.data(), i, h, tw, twN);
+        else dit_inv_pass_butterfly<1>(b.data(), i, h, tw, twN);
+    }
+}
+template <class TW>
+static void fft_dif(std::vector<double2> &b, int M, TW tw, int twN, bool skip_last = false)
+{
+    const int p = ilog2(M), np = fft_sched_np(p);
+    int h = M;
+    for (int a = 0; a < np - (skip_last ? 1 : 0); ++a) {
+        h >>= fft_sched_k(p, a);
+        pass_dif(b, M, fft_sched_k(p, a), h, tw, twN);
+    }
+}
+template <class TW>
+static void fft_dit_inv(std::vector<double2> &b, int M, TW tw, int twN, bool skip_first = false)
+{
+    const int p = ilog2(M), np = fft_sched_np(p);
     int h = 1;
-    for (; 4 * h <= M; h <<= 2)
-        for (int i = 0; i < M / 4; ++i) dit4_inv_butterfly(b.data(), i, h, tw, twN);
-    if (2 * h <= M)
-        for (int i = 0; i < M / 2; ++i) dit_inv_butterfly(b.data(), i, h, tw, twN);
+    for (int a = np - 1; a >= 0; --a) {
+        if (!(skip_first && a == np - 1)) pass_dit_inv(b, M, fft_sched_k(p, a), h, tw, twN);
+        h <<= fft_sched_k(p, a);
+    }
 }
 
 // emulate one (ring, r) sub-DFT: input z[4n], output Y[k] = X[4k+r], k<n
@@ -58,31 +77,47 @@ static std::vector<double2> subdft(const std::vector<double2> &z, int n, int r,
     TwFactored twf;
     twf.hi = hi.data();
     twf.lo = lo.data();
-    std::vector<double2> buf(M, mk(0, 0));
+    std::vector<double2> buf(lds_fft_slots(M), mk(0, 0));
     for (int j = 0; j < n; ++j) {
         double2 t = dif4_combine(z[j], z[j + n], z[j + 2 * n], z[j + 3 * n], r);
         unsigned q = load_phase_num(j, r, n, blu);
-        buf[j] = cmul(t, expipi(-(double)q / (2.0 * n)));
+        buf[lds_slot(j)] = cmul(t, expipi(-(double)q / (2.0 * n)));
     }
     std::vector<double2> out(n);
     if (!blu) {
         fft_dif(buf, M, twf, twN);
-        for (int k = 0; k < n; ++k) out[k] = buf[bitrev(k, p)];
+        for (int k = 0; k < n; ++k) out[k] = buf[lds_slot(bitrev(k, p))];
         return out;
     }
-    // Bluestein filter spectrum (bit-reversed order), as the init kernel builds it
-    std::vector<double2> h(M, mk(0, 0));
+    // Bluestein filter spectrum (bit-reversed order), stored transposed as the init kernel does: hT[j * (M/16) + i] = H[16 i + j]
+    std::vector<double2> h(lds_fft_slots(M), mk(0, 0));
     for (int j = 0; j < n; ++j) {
         double2 c = expipi((double)chirp_num(j, n) / n);
-        h[j] = c;
-        if (j) h[M - j] = c;
+        h[lds_slot(j)] = c;
+        if (j) h[lds_slot(M - j)] = c;
     }
     fft_dif(h, M, tw.data(), twN);
-    fft_dif(buf, M, twf, twN);
-    for (int i = 0; i < M; ++i) buf[i] = cmul(buf[i], h[i]);
-    fft_dit_inv(buf, M, twf, twN);
+    if (M >= 16) {
+        std::vector<double2> hT(M);
+        for (int e = 0; e < M; ++e) hT[(e & 15) * (M / 16) + (e >> 4)] = h[lds_slot(e)];
+        // the kernel's fused middle: last forward pass (h = 1, 16 consecutive elements), filter, first inverse pass, in registers
+        fft_dif(buf, M, twf, twN, true);
+        for (int i = 0; i < M / 16; ++i) {
+            double2 x[16];
+            for (int j = 0; j < 16; ++j) x[j] = buf[lds_slot(16 * i + j)];
+            dif_regs<4>(x);
+            for (int j = 0; j < 16; ++j) x[j] = cmul(x[j], hT[j * (M / 16) + i]);
+            dit_inv_regs<4>(x);
+            for (int j = 0; j < 16; ++j) buf[lds_slot(16 * i + j)] = x[j];
+        }
+        fft_dit_inv(buf, M, twf, twN, true);
+    } else {
+        fft_dif(buf, M, twf, twN);
+        for (int e = 0; e < M; ++e) buf[lds_slot(e)] = cmul(buf[lds_slot(e)], h[lds_slot(e)]);
+        fft_dit_inv(buf, M, twf, twN);
+    }
     for (int k = 0; k < n; ++k)
-        out[k] = cscale(cmul(buf[k], expipi(-(double)chirp_num(k, n) / n)), 1.0 / M);
+        out[k] = cscale(cmul(buf[lds_slot(k)], expipi(-(double)chirp_num(k, n) / n)), 1.0 / M);
     return out;
 }
 
@@ -91,7 +126,7 @@ int main()
     const int twN = 8192;
     auto tw = make_tw(twN);
     double worst = 0;
-    int sizes[] = {1, 2, 3, 4, 5, 7, 8, 12, 16, 31, 32, 33, 64, 100, 127, 128, 255, 256, 257, 512, 1000};
+    int sizes[] = {1, 2, 3, 4, 5, 7, 8, 12, 16, 31, 32, 33, 64, 100, 127, 128, 255, 256, 257, 512, 1000, 1024, 1500, 2048};
     for (int n : sizes) {
         int N = 4 * n;
         std::vector<double2> z(N);

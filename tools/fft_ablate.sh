@@ -4,7 +4,7 @@
 # Fourier stage of one 8-component map2alm at nside 4096.  Results are wrong by design.
 set -e
 cd "$(dirname "$0")/../heracles_amd/csrc"
-OBJS="hx_runtime.o hx_twopoint.o hx_analysis.o hx_mixmat.o hx_transforms.o hx_mapper.o hx_peaks.o"
+OBJS=$(ls *.o | grep -v "^hx_sht.o")
 mkdir -p ../../tools/bin
 for a in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DHX_FFT_ABL=$a -c hx_sht.hip -o /tmp/hx_sht_abl$a.o
