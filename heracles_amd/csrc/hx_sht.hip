@@ -144,6 +144,7 @@ __device__ unsigned long long g_fft_cyc[8];
 #endif
 __host__ __device__ inline int ring_ph_hi(int M) { return (4 * M) / 64 + 1; }  // entries of the coarse phase table: q >> 6 for q < 4n, n <= M
 constexpr int RING_NTMAX = 512;  // threads per group: M / 16 (one radix-16 butterfly per thread and pass), 64 at least
+constexpr int RING_FB = 8;       // values of j per thread whose pixel loads are in flight together (64 loads)
 
 template <int MODE>
 __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int *__restrict__ rp_list, int nrings, int nb, int Mclass,
@@ -197,29 +198,39 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
             const double *mpN = maps + (long long)c * P.npix + sN, *mpS = maps + (long long)c * P.npix + (haveS ? sS : sN);
             const double *pwN = pixw + sN, *pwS = pixw + (haveS ? sS : sN);
             const double2 *zp = zin + (long long)c * P.ny + sN;
-#pragma unroll 4
-            for (int j = tid; j < n; j += nt) {
-                double2 z[4];
+            // RING_FB values of j at a time: all their loads (8 per j) are issued before the first is used -- one trip to L2 / HBM
+            // per batch instead of one per j (out-of-range j read pixel 0 of the ring and write the spare slot of the buffer)
+            for (int u0 = 0; u0 * nt < n; u0 += RING_FB) {
+                double2 z[RING_FB][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = j + q * n;
-                    if (MODE == 0) {
+                for (int u = 0; u < RING_FB; ++u) {
+                    const int j = tid + (u0 + u) * nt, jj = j < n ? j : 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = jj + q * n;
+                        if (MODE == 0) {
 #if HX_FFT_ABL & 16
-                        z[q] = make_double2(1.0 + j, 2.0 + q); continue;
+                            z[u][q] = make_double2(1.0 + j, 2.0 + q); continue;
 #endif
-                        double fn = mpN[i], fs = mpS[i];
-                        if (pw) { fn *= pwN[i]; fs *= pwS[i]; }
-                        z[q] = make_double2(fn, haveS ? fs : 0.0);
-                    } else {
-                        z[q] = zp[i];
+                            double fn = mpN[i], fs = mpS[i];
+                            if (pw) { fn *= pwN[i]; fs *= pwS[i]; }
+                            z[u][q] = make_double2(fn, haveS ? fs : 0.0);
+                        } else {
+                            z[u][q] = zp[i];
+                        }
                     }
                 }
-                const double2 e0 = odd ? csub(z[0], z[2]) : cadd(z[0], z[2]);
-                const double2 e1 = odd ? mul_mi(csub(z[1], z[3])) : cadd(z[1], z[3]);
-                const double2 t = make_double2(fma(sg, e1.x, e0.x), fma(sg, e1.y, e0.y));
-                // (j r + 2 j^2 [Bluestein]) mod 4n = load_phase_num(j, r, n, blu); j < 2^13: 32 bits hold it
-                const unsigned qn = mod_by_inv((unsigned)j * (unsigned)r + (blu ? 2u * (unsigned)j * (unsigned)j : 0u), 4u * (unsigned)n, inv4n);
-                buf[lds_slot(j)] = cmul(t, phase(qn));
+#pragma unroll
+                for (int u = 0; u < RING_FB; ++u) {
+                    const int j = tid + (u0 + u) * nt;
+                    const double2 e0 = odd ? csub(z[u][0], z[u][2]) : cadd(z[u][0], z[u][2]);
+                    const double2 e1 = odd ? mul_mi(csub(z[u][1], z[u][3])) : cadd(z[u][1], z[u][3]);
+                    const double2 t = make_double2(fma(sg, e1.x, e0.x), fma(sg, e1.y, e0.y));
+                    // (j r + 2 j^2 [Bluestein]) mod 4n = load_phase_num(j, r, n, blu); j < 2^14: 32 bits hold it
+                    const unsigned jc = j < n ? j : 0;
+                    const unsigned qn = mod_by_inv(jc * (unsigned)r + (blu ? 2u * jc * jc : 0u), 4u * (unsigned)n, inv4n);
+                    buf[j < n ? lds_slot(j) : MP - 1] = cmul(t, phase(qn));
+                }
             }
             if (blu)
                 for (int j = n + tid; j < M; j += nt) buf[lds_slot(j)] = make_double2(0.0, 0.0);  // Bluestein padding
