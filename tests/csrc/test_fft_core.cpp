@@ -153,6 +153,19 @@ int main()
         printf("n_sub %5d  M %5d  max err %.3e (rel %.3e)\n", n, fft_size_for(n), err, err / nrm);
         worst = fmax(worst, err / nrm);
     }
+    // the kernel's phase numerators: mod_by_inv (double-precision reciprocal) against the 64-bit integer forms
+    long bad = 0;
+    for (unsigned n = 1; n <= 8192; n += (n < 300 ? 1 : 37)) {
+        const double inv4n = 0.25 / (double)n;
+        for (unsigned j = 0; j < n; j += (n < 300 ? 1 : 3))
+            for (unsigned r = 0; r < 4; ++r) {
+                if (mod_by_inv(j * r + 2u * j * j, 4u * n, inv4n) != load_phase_num(j, r, n, true)) ++bad;
+                if (mod_by_inv(j * r, 4u * n, inv4n) != load_phase_num(j, r, n, false)) ++bad;
+                if (mod_by_inv(j * j, 2u * n, 2.0 * inv4n) != chirp_num(j, n)) ++bad;
+            }
+    }
+    printf("phase numerators: %ld mismatches\n", bad);
+    if (bad) { printf("FAIL\n"); return 1; }
     if (worst > 1e-12) { printf("FAIL\n"); return 1; }
     printf("OK\n");
     return 0;
