@@ -18,6 +18,11 @@
 //                16 real columns, x NG column groups) stays in registers for the whole l sweep.
 //   flush      per 32-l block the waves' D tiles are summed through LDS in fixed order
 //                (bit-reproducible) and scaled by alpha_l into `partial`.
+// Two generations of the kernel live here: k_legendre_analysis (batches of <= 2 maps / fields, the 4x4x4 instruction; one
+// work-group per (m, ring group), one span of `partial` rows per group, summed over the groups by k_alm_reduce) and the
+// software-pipelined k_legendre_pipe (every larger batch; one work-group per m that walks its ring groups and adds them in
+// place with f64 atomics in a fixed order -- `partial` then holds ONE span of rows per m and k_alm_reduce only changes the
+// layout).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -496,7 +501,8 @@ __global__ __launch_bounds__(NWV * 64, (NWV < LegCfg<SPIN>::NW ? 2 : 1)) void k_
 //     the loop, whose out-of-order return would force lgkmcnt(0) drains of the LDS queue);
 //   * the flush combines the 4 waves' D tiles through the wave's second tile (free at that point) in a fixed
 //     order, as before.
-// Layouts of F, partial and the task list are those of the first kernel (a task = 16 / 8 blocks of 32 ring pairs).
+// Layouts of F and the task list are those of the first kernel (a task = 16 / 8 blocks of 32 ring pairs); the rows of
+// `partial` are shared by the tasks of an m (LegParams::arow).
 template <int SPIN>
 struct PipeCfg {
     static constexpr int NW = 4;                              // waves per work-group
@@ -1013,7 +1019,7 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
 }
 
 // =====================================================================================
-// partial sums -> alm (fixed order over the ring groups of each m)
+// partial sums -> alm (4x4x4 kernels: fixed order over the ring groups of each m; pipelined kernel: rows already summed)
 // =====================================================================================
 template <int SPIN>
 __global__ __launch_bounds__(256) void k_alm_reduce(PlanDev P, const LegTask *__restrict__ tasks,

@@ -3,20 +3,22 @@
 // Replaces healpy.map2alm / alm2map as called from heracles/healpy.py:183-189 (spin 0 and
 // spin 2, RING-ordered maps, mmax == lmax).
 //
-// Pipeline of one analysis batch (<= 8 map components):
+// Pipeline of one analysis sweep (<= 16 map components):
 //   1. k_ring_subdft       ring Fourier stage.  A north/south ring pair is packed as
 //                          z = f_N + i f_S and transformed as one complex DFT of length
-//                          4n, split radix-4 (DIF) into four length-n DFTs that run
-//                          entirely in LDS (plain FFT for n = 2^k, Bluestein otherwise).
+//                          4n, split radix-4 (DIF) into four length-n DFTs; a work item is ONE of
+//                          them, run entirely in LDS (fused radix-8 / radix-16 passes on a padded
+//                          buffer; plain FFT for n = 2^k, Bluestein otherwise), the four items of a
+//                          ring pair in four work-groups of one XCD so that they share its L2.
 //   2. k_fourier_combine   un-packs N/S, applies ring phase / quadrature weight, forms
 //                          the parity combinations and writes the MFMA B-operand layout
-//                          F[m][ring pair][parity][op][16 columns].
-//   3. k_legendre_analysis Legendre / Wigner-d stage: lanes = ring pairs run the
-//                          three-term recursion in l; 16 l-values x 64 rings of
-//                          lambda_lm are transposed through LDS into A-operand tiles of
-//                          v_mfma_f64_16x16x4_f64, which contracts over rings against the
-//                          F operands of 8 maps (16 real columns) held in registers.
-//   4. k_alm_reduce        fixed-order sum of the ring-group partials -> alm (x fl).
+//                          F[m][ring pair][parity][op][columns].
+//   3. k_legendre_pipe     (hx_analysis.hip) Legendre / Wigner-d stage: lanes = ring pairs run the
+//                          three-term recursion in l; tiles of lambda_lm go through LDS into A operands
+//                          of v_mfma_f64_16x16x4_f64, which contracts over rings against the F operands
+//                          held in registers; one work-group per m adds its ring groups in place.
+//   4. k_alm_reduce        rows -> alm layout (x fl); for the small-batch kernels also the fixed-order
+//                          sum of the ring-group partials.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -785,7 +787,7 @@ static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, cons
             (void)hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_fft_cyc), sizeof(hc));
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fft_cyc), z8, sizeof(z8));
             const double items = (double)c.count * nb;
-            fprintf(stderr, "[hx] fft class M %5d rings %5d: cycles (x 100 MHz ticks) per item: load+tables %.0f  fill %.0f  fwd %.0f  middle %.0f  inv %.0f  out %.0f\n", c.M, c.count,
+            fprintf(stderr, "[hx] fft class M %5d rings %5d: shader cycles per (ring pair, component): load+tables %.0f  fill %.0f  fwd %.0f  middle %.0f  inv %.0f  out %.0f\n", c.M, c.count,
                     hc[0] / items, hc[1] / items, hc[2] / items, hc[3] / items, hc[4] / items, hc[5] / items);
         }
 #endif
