@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef double double4_t __attribute__((ext_vector_type(4)));
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n",hipGetErrorString(e),__LINE__);return 1;}}while(0)
@@ -51,6 +52,32 @@ __global__ __launch_bounds__(256, 1) void k_slot(double *out, unsigned long long
         };
 #pragma unroll
         for (int sp = 0; sp < PF; ++sp) fetch(sp);
+        if (F & 256) {  // MFMAs only, per block of 4 slot pairs: the 8 16x16x4 first, then the 8 4x4x4
+#pragma unroll
+            for (int sp = PF; sp < 16; ++sp) fetch(sp);
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int sp = 4 * blk + (u >> 1), pos = u & 1;
+                    const double a = pos ? aq[sp].y : aq[sp].x;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acc[g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[sp][pos][g], acc[g][pos], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int sp = 4 * blk + (u >> 1), pos = u & 1;
+                    const double a = pos ? aq[sp].y : aq[sp].x;
+                    const int AI = (F & 128) ? pos + 2 * (sp & 1) : pos;
+#pragma unroll
+                    for (int g = 0; g < NBX; ++g) accx[g][AI] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[sp][pos][g], accx[g][AI], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            vc = vc * 1e-3 + 1e-4; vp = vp * 1e-3 + 2e-4;
+            continue;
+        }
 #pragma unroll
         for (int sp = 0; sp < 16; ++sp) {
             if (sp + PF < 16) fetch(sp + PF);
@@ -436,6 +463,11 @@ int main()
     CK(hipMemcpy(d_src, src.data(), sizeof(double) * 4096, hipMemcpyHostToDevice));
 #define R(NG, NBX, F, PF, L) if (run<NG, NBX, F, PF>(L, d_out, d_cyc, d_src, cus)) return 1
     R(1, 1, 0, 2, "MFMA only");
+    R(1, 1, 256, 2, "MFMA only, 8 x 16x16x4 then 8 x 4x4x4 per block");
+    R(1, 1, 384, 2, "the same, 4x4x4 on 4 accumulators");
+    R(1, 1, 1, 2, "MFMA + A reads");
+    R(1, 1, 257, 2, "grouped + A reads");
+    if (getenv("ORDER_ONLY")) return 0;
     R(1, 1, 128, 2, "MFMA only, 4 accumulators");
     R(1, 0, 128, 2, "MFMA only, 4 accumulators");
     R(2, 0, 128, 2, "MFMA only, 4 accumulators");
