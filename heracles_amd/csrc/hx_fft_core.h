@@ -1,5 +1,5 @@
-// hx_fft_core.h -- index math and butterflies of the in-LDS power-of-two FFT and of the
-// radix-4 DIF split / Bluestein chirp used by the ring Fourier stage.  Pure functions,
+// hx_fft_core.h -- index math and butterflies of the in-LDS power-of-two FFT (fused radix-2^K passes on a
+// padded buffer) and of the radix-4 DIF split / Bluestein chirp used by the ring Fourier stage.  Pure functions,
 // usable from device code and from the host-side emulation test (tests/csrc).
 #pragma once
 #ifdef __HIPCC__
@@ -74,76 +74,6 @@ struct TwFactored {
         return r;
     }
 };
-
-/* Gentleman-Sande (DIF) butterfly number i of the stage with half-size h.
- * tw[k] = exp(-2 pi i k / twN), k < twN/2 (a pointer to the full table or a TwFactored).  Natural-order input -> bit-reversed output
- * after stages h = M/2, M/4, ..., 1. */
-template <class TW>
-HX_HD void dif_butterfly(double2 *buf, int i, int h, TW tw, int twN)
-{
-    int t = i & (h - 1);
-    int p0 = ((i - t) << 1) + t, p1 = p0 + h;
-    double2 u = buf[p0], v = buf[p1];
-    buf[p0] = cadd(u, v);
-    double2 d = csub(u, v);
-    buf[p1] = t ? cmul(d, tw[t * (twN / (2 * h))]) : d;
-}
-
-/* Cooley-Tukey (DIT) inverse butterfly, conj twiddles: bit-reversed input -> natural
- * output after stages h = 1, 2, ..., M/2 (unnormalised inverse DFT). */
-template <class TW>
-HX_HD void dit_inv_butterfly(double2 *buf, int i, int h, TW tw, int twN)
-{
-    int t = i & (h - 1);
-    int p0 = ((i - t) << 1) + t, p1 = p0 + h;
-    double2 u = buf[p0], v = buf[p1];
-    if (t) v = cmulc(v, tw[t * (twN / (2 * h))]);
-    buf[p0] = cadd(u, v);
-    buf[p1] = csub(u, v);
-}
-
-/* Two fused Gentleman-Sande stages (half-sizes 2h and h) = one radix-4 DIF butterfly on
- * (p, p+h, p+2h, p+3h); same in-place layout and final (bit-reversed) order as the two
- * radix-2 stages.  i in [0, M/4), W = exp(-2 pi i / 4h). */
-template <class TW>
-HX_HD void dif4_butterfly(double2 *buf, int i, int h, TW tw, int twN)
-{
-    int t = i & (h - 1);
-    int p = ((i - t) << 2) + t;
-    double2 x0 = buf[p], x1 = buf[p + h], x2 = buf[p + 2 * h], x3 = buf[p + 3 * h];
-    double2 a = cadd(x0, x2), b = cadd(x1, x3), c = csub(x0, x2), d = mul_mi(csub(x1, x3));
-    double2 y0 = cadd(a, b), y1 = csub(a, b), y2 = cadd(c, d), y3 = csub(c, d);
-    if (t) {
-        double2 w1 = tw[t * (twN / (4 * h))], w2 = tw[2 * t * (twN / (4 * h))];
-        y1 = cmul(y1, w2);
-        y2 = cmul(y2, w1);
-        y3 = cmul(y3, cmul(w1, w2));
-    }
-    buf[p] = y0; buf[p + h] = y1; buf[p + 2 * h] = y2; buf[p + 3 * h] = y3;
-}
-
-/* Two fused inverse Cooley-Tukey stages (half-sizes h then 2h), conj twiddles. */
-template <class TW>
-HX_HD void dit4_inv_butterfly(double2 *buf, int i, int h, TW tw, int twN)
-{
-    int t = i & (h - 1);
-    int p = ((i - t) << 2) + t;
-    double2 x0 = buf[p], x1 = buf[p + h], x2 = buf[p + 2 * h], x3 = buf[p + 3 * h];
-    if (t) {
-        double2 w2 = tw[2 * t * (twN / (4 * h))];  /* W_{2h}^t */
-        x1 = cmulc(x1, w2);
-        x3 = cmulc(x3, w2);
-    }
-    double2 a0 = cadd(x0, x1), a1 = csub(x0, x1), a2 = cadd(x2, x3), a3 = csub(x2, x3);
-    if (t) {
-        double2 w1 = tw[t * (twN / (4 * h))];      /* W_{4h}^t */
-        a2 = cmulc(a2, w1);
-        a3 = cmulc(a3, w1);
-    }
-    a3 = mul_pi(a3);                               /* conj(W_{4h}^{t+h}) = conj(W^t) * (+i) */
-    buf[p] = cadd(a0, a2); buf[p + 2 * h] = csub(a0, a2);
-    buf[p + h] = cadd(a1, a3); buf[p + 3 * h] = csub(a1, a3);
-}
 
 /* ---- fused radix-2^K passes on the PADDED buffer (K <= 4) --------------------------------------------------------
  * Element e of a transform lives in slot e + (e >> 4) + (e >> 9) of the buffer (one empty 16-byte slot after every 16 and

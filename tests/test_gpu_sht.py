@@ -230,6 +230,30 @@ def test_map2alm_m_chunked_batches_medium(oracle, spin, ncomp):
         assert err <= TOL * scale, (m, err / scale)
 
 
+@pytest.mark.parametrize("spin,ncomp", [(0, 10), (2, 10), (2, 16)])
+def test_ring_groups_summed_in_fixed_order(spin, ncomp):
+    """The pipelined Legendre kernel adds the ring groups of an m in place with f64 atomics: one work-group per m, program
+    order -- so repeated runs agree bit for bit although several groups (nside 1024: 4 for spin 0, 8 for spin 2) and
+    hundreds of work-groups on all XCDs add into the same buffer; and the sum over groups equals the transform of the
+    northern-group and southern-group rings taken separately to rounding (linearity across the ring groups)."""
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(77 + spin + ncomp)
+    nside, lmax = 1024, 1535
+    maps = rng.standard_normal((ncomp, 12 * nside**2))
+    plan = hx.get_plan(nside, lmax)
+    a = plan.map2alm(maps, spin)
+    for _ in range(3):
+        np.testing.assert_array_equal(plan.map2alm(maps, spin), a)
+    # rings of the polar caps only / of the equatorial belt only: different ring groups carry the signal
+    ncap = 2 * nside * (nside - 1)
+    cap = np.zeros_like(maps)
+    cap[:, :ncap] = maps[:, :ncap]
+    cap[:, -ncap:] = maps[:, -ncap:]
+    b = plan.map2alm(cap, spin) + plan.map2alm(maps - cap, spin)
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+
+
 @pytest.mark.parametrize("nside,cap", [(64, 64), (32, 32), (48, 64)])
 def test_split_bluestein_rings(oracle, nside, cap):
     """Rings whose Bluestein convolution exceeds the in-LDS FFT limit (nside 8192: 4096 < n < 8192 needs 16384 points)
