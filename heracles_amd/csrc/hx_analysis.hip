@@ -77,18 +77,24 @@ struct LegParams {
 // =====================================================================================
 // Y -> F operands:  un-pack N/S, ring phase, quadrature weight, parity combinations
 // =====================================================================================
-__device__ inline double2 ring_mode(const PlanDev &P, const double2 *__restrict__ Yc, int rp, int n, int mm)
-{
-    return Yc[P.startN[rp] + (long long)(mm & 3) * n + (mm >> 2)];  // Z[mm], X[4k+r] = Y_r[k]
-}
+// What a ring pair needs at one m, whatever the component: where Z[m] and Z[-m] sit in its spectrum (X[4k+r] = Y_r[k]) and
+// the phase x quadrature weight.  One thread per ring pair of the block computes it (integer divisions, one sincospi) and
+// hands it over through LDS: done per (ring pair, m, component slot) it was half of the kernel's time (3.7e9 vector
+// instructions per spin-2 sweep, profiles/r02_pmc_summary.md).
+struct RingAtM {
+    double2 ph;        // w e^{-i m phi_0} (w = 0 for padding ring pairs)
+    long long i0, i1;  // Z[m mod nphi], Z[-m mod nphi] relative to the component's spectrum
+    int hasS;
+};
 
 // F_N(m), F_S(m) of ring pair rp for component c, including phase and quadrature weight
 __device__ inline void ring_modes_ns(const PlanDev &P, const double2 *__restrict__ Y, int c, int rp, int m,
-                                     double w, double2 &FN, double2 &FS)
+                                     const RingAtM &r, double2 &FN, double2 &FS)
 {
     if (P.hsrc) {
         // equiangular rings theta_j = 2 pi (j + 1/2) / N of the point transform: the spectrum h_m is given on the full circle,
         // lambda_lm(2 pi - theta) = (-1)^m lambda_lm(theta) (both spins) folds the second half onto the rings
+        const double w = r.ph.x;
         const double2 *h = P.hsrc + (long long)c * P.hsrc_stride + (long long)m * P.hN;
         const double sg = (m & 1) ? -w : w;
         const double2 a = h[rp], b = h[P.hN - 1 - rp], cN = h[P.hN / 2 - 1 - rp], d = h[P.hN / 2 + rp];
@@ -96,17 +102,12 @@ __device__ inline void ring_modes_ns(const PlanDev &P, const double2 *__restrict
         FS = make_double2(w * cN.x + sg * d.x, w * cN.y + sg * d.y);
         return;
     }
-    const int n = P.nsub[rp];
-    const int nphi = 4 * n;
-    const int mm = m % nphi, mc = (nphi - mm) % nphi;
     const double2 *Yc = Y + (long long)c * P.ny;
-    const double2 a = ring_mode(P, Yc, rp, n, mm), b = cconj(ring_mode(P, Yc, rp, n, mc));
+    const double2 a = Yc[r.i0], b = cconj(Yc[r.i1]);
     const double2 xn = cscale(cadd(a, b), 0.5);
     const double2 xs = mul_mi(cscale(csub(a, b), 0.5));  // (a-b)/(2i)
-    double2 ph = make_double2(w, 0.0);
-    if (P.shifted[rp]) ph = cscale(expipi(-(double)(m % (2 * nphi)) / (double)nphi), w);
-    FN = cmul(xn, ph);
-    FS = P.startS[rp] >= 0 ? cmul(xs, ph) : make_double2(0.0, 0.0);
+    FN = cmul(xn, r.ph);
+    FS = r.hasS ? cmul(xs, r.ph) : make_double2(0.0, 0.0);
 }
 
 // grid: x = m - m0, y = tiles of 32 ring pairs; block 256 = 32 ring pairs x 8 slots.
@@ -118,16 +119,35 @@ __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double
                                                          double *__restrict__ F)
 {
     constexpr int NOP = LegCfg<SPIN>::NOP;
+    __shared__ RingAtM ring_at_m[32];
     const int m = m0 + blockIdx.x;
     // ring blocks in front of the first task of this m are pruned (m beyond what their rings resolve): their rows of F are
     // never read
     const MTasks mt = of_m[m];
     if (mt.count == 0 || (int)blockIdx.y < tasks[mt.first].rb0) return;
+    if (threadIdx.x < 32) {
+        const int r = blockIdx.y * 32 + threadIdx.x;
+        RingAtM q;
+        const bool live = r < P.nrp;
+        const double w = live ? (rw ? rw[r] : 1.0) * P.wnorm : 0.0;
+        q.ph = make_double2(w, 0.0);
+        q.i0 = q.i1 = 0;
+        q.hasS = 0;
+        if (live && !P.hsrc) {
+            const int n = P.nsub[r], nphi = 4 * n;
+            const int mm = m % nphi, mc = (nphi - mm) % nphi;
+            q.i0 = P.startN[r] + (long long)(mm & 3) * n + (mm >> 2);  // Z[mm], X[4k+r] = Y_r[k]
+            q.i1 = P.startN[r] + (long long)(mc & 3) * n + (mc >> 2);
+            if (P.shifted[r]) q.ph = cscale(expipi(-(double)(m % (2 * nphi)) / (double)nphi), w);
+            q.hasS = P.startS[r] >= 0;
+        }
+        ring_at_m[threadIdx.x] = q;
+    }
+    __syncthreads();
     const int rp = blockIdx.y * 32 + (threadIdx.x >> 3);
     const int slot = threadIdx.x & 7;
-    if (rp >= P.nrp_pad) return;
     const bool live = rp < P.nrp;
-    const double w = live ? (rw ? rw[rp] : 1.0) * P.wnorm : 0.0;
+    const RingAtM ram = ring_at_m[threadIdx.x >> 3];
     double *row = F + (((long long)blockIdx.x * P.nrp_pad + rp) * 2) * NOP * ncol;
     for (int g = 0; g < ng; ++g) {
         if (SPIN == 0) {
@@ -136,7 +156,7 @@ __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double
             double2 s = make_double2(0.0, 0.0), d = s;
             if (live && c < ncomp) {
                 double2 fn, fs;
-                ring_modes_ns(P, Y, c, rp, m, w, fn, fs);
+                ring_modes_ns(P, Y, c, rp, m, ram, fn, fs);
                 s = cadd(fn, fs);
                 d = csub(fn, fs);
             }
@@ -148,8 +168,8 @@ __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double
             double4 o0 = make_double4(0.0, 0.0, 0.0, 0.0), o1 = o0;
             if (live && 2 * f + 1 < ncomp) {
                 double2 qn, qs, un, us;
-                ring_modes_ns(P, Y, 2 * f, rp, m, w, qn, qs);
-                ring_modes_ns(P, Y, 2 * f + 1, rp, m, w, un, us);
+                ring_modes_ns(P, Y, 2 * f, rp, m, ram, qn, qs);
+                ring_modes_ns(P, Y, 2 * f + 1, rp, m, ram, un, us);
                 // P+ = -(Q + iU)/2, P- = -(Q - iU)/2
                 const double2 ppn = cscale(cadd(qn, mul_pi(un)), -0.5), pmn = cscale(csub(qn, mul_pi(un)), -0.5);
                 const double2 pps = cscale(cadd(qs, mul_pi(us)), -0.5), pms = cscale(csub(qs, mul_pi(us)), -0.5);
