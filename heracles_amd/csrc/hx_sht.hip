@@ -180,10 +180,46 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
         // the thread index goes through an empty asm statement per item, so that what derives from it (LDS addresses, pixel
         // offsets) is set up per item instead of being hoisted out of this loop and kept in registers across the passes
         asm volatile("; item" : "+v"(tid));
-        __syncthreads();  // the previous item's last readers of the phase tables and of the buffer
+        // ---- pixels.  RING_FB values of j at a time: all their loads (8 per j) are issued before the first is used -- one trip
+        // to L2 / HBM per batch instead of one per j (out-of-range j read pixel 0 of the ring and write the spare slot of the
+        // buffer; a missing southern ring (the equator) reads the northern one and selects 0).  The first batch is requested
+        // before the phase tables are built, whose sincospi then cover part of its way ----
+        const bool haveS = sS >= 0, pw = MODE == 0 && pixw != nullptr, odd = r & 1;
+        const double sg = (r & 2) ? -1.0 : 1.0;
+        const double *mpN = maps + (long long)c * P.npix + sN, *mpS = maps + (long long)c * P.npix + (haveS ? sS : sN);
+        const double *pwN = pixw + sN, *pwS = pixw + (haveS ? sS : sN);
+        const double2 *zp = zin + (long long)c * P.ny + sN;
+        double2 z[RING_FB][4];
+        auto load_batch = [&](int u0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < RING_FB; ++u) {
+                const int j = tid + (u0 + u) * nt, jj = j < n ? j : 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = jj + q * n;
+                    if (MODE == 0) {
+#if HX_FFT_ABL & 16
+                        z[u][q] = make_double2(1.0 + j, 2.0 + q); continue;
+#endif
+                        double fn = mpN[i], fs = mpS[i];
+                        if (pw) { fn *= pwN[i]; fs *= pwS[i]; }
+                        z[u][q] = make_double2(fn, haveS ? fs : 0.0);
+                    } else {
+                        z[u][q] = zp[i];
+                    }
+                }
+            }
+        };
+        load_batch(0);
+        // (work-group barriers that wait for this wave's LDS traffic only: __syncthreads() would wait for the pixel loads too)
+        auto lds_barrier = []() __attribute__((always_inline)) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+        };
+        lds_barrier();  // the previous item's last readers of the phase tables and of the buffer
         for (int a = tid; a <= (4 * n) >> 6; a += nt) ph_hi[a] = expipi(-(double)(a << 6) / (2.0 * n));
         if (tid < 64) ph_lo[tid] = expipi(-(double)tid / (2.0 * n));
-        __syncthreads();
+        lds_barrier();
         HX_FSTAMP(0);
         auto phase = [&](unsigned q) __attribute__((always_inline)) {  // exp(-i pi q / 2n), q < 4n
 #if HX_FFT_ABL & 1
@@ -193,35 +229,9 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
 #endif
         };
         // ---- fill: t_r[j] x load phase.  t_r = (a, c)[r & 1] +- (b, d)[r & 1] with a = z0 + z2, b = z1 + z3, c = z0 - z2,
-        // d = -i (z1 - z3); a missing southern ring (the equator) reads the northern one and selects 0 ----
+        // d = -i (z1 - z3) ----
         {
-            const bool haveS = sS >= 0, pw = MODE == 0 && pixw != nullptr, odd = r & 1;
-            const double sg = (r & 2) ? -1.0 : 1.0;
-            const double *mpN = maps + (long long)c * P.npix + sN, *mpS = maps + (long long)c * P.npix + (haveS ? sS : sN);
-            const double *pwN = pixw + sN, *pwS = pixw + (haveS ? sS : sN);
-            const double2 *zp = zin + (long long)c * P.ny + sN;
-            // RING_FB values of j at a time: all their loads (8 per j) are issued before the first is used -- one trip to L2 / HBM
-            // per batch instead of one per j (out-of-range j read pixel 0 of the ring and write the spare slot of the buffer)
-            for (int u0 = 0; u0 * nt < n; u0 += RING_FB) {
-                double2 z[RING_FB][4];
-#pragma unroll
-                for (int u = 0; u < RING_FB; ++u) {
-                    const int j = tid + (u0 + u) * nt, jj = j < n ? j : 0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int i = jj + q * n;
-                        if (MODE == 0) {
-#if HX_FFT_ABL & 16
-                            z[u][q] = make_double2(1.0 + j, 2.0 + q); continue;
-#endif
-                            double fn = mpN[i], fs = mpS[i];
-                            if (pw) { fn *= pwN[i]; fs *= pwS[i]; }
-                            z[u][q] = make_double2(fn, haveS ? fs : 0.0);
-                        } else {
-                            z[u][q] = zp[i];
-                        }
-                    }
-                }
+            for (int u0 = 0;;) {
 #pragma unroll
                 for (int u = 0; u < RING_FB; ++u) {
                     const int j = tid + (u0 + u) * nt;
@@ -233,6 +243,9 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
                     const unsigned qn = mod_by_inv(jc * (unsigned)r + (blu ? 2u * jc * jc : 0u), 4u * (unsigned)n, inv4n);
                     buf[j < n ? lds_slot(j) : MP - 1] = cmul(t, phase(qn));
                 }
+                u0 += RING_FB;
+                if (u0 * nt >= n) break;
+                load_batch(u0);
             }
             if (blu)
                 for (int j = n + tid; j < M; j += nt) buf[lds_slot(j)] = make_double2(0.0, 0.0);  // Bluestein padding
