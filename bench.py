@@ -241,6 +241,29 @@ def main():
     out = None
     if rank == 0:
         assert cls is not None and cls.shape[0] == work.nrows
+        # ---- host -> host leg (SURVEY 8d's metric definition: pageable numpy maps in, Cl blocks on the host out) -------
+        # (before the CPU legs, so that their working set on the host is not in its way)
+        host_leg = None
+        if world == 1 and not args.no_host_leg:
+            h0 = maps0.cpu().numpy()
+            h2 = maps2.cpu().numpy().reshape(2 * n2, npix)
+
+            def host_step():
+                plan.map2alm(h0, 0, out=alm0)       # host maps are staged through HBM by the library; alms stay in HBM
+                plan.map2alm(h2, 2, out=alm2.view(2 * n2, nlm))
+                return work.all_pairs_cl()          # numpy array on the host
+
+            host_step()
+            th = time.perf_counter()
+            nh = 2
+            for _ in range(nh):
+                host_step()
+            dth = (time.perf_counter() - th) / nh
+            host_leg = {"value": npairs / dth, "unit": "map->Cl pairs/s", "ms_per_step": dth * 1e3, "steps": nh,
+                        "what": "pageable numpy maps on the host -> batched map2alm (H2D through the library's pinned staging) -> "
+                                "all-pairs Cl -> numpy Cl blocks on the host; alms never leave HBM"}
+            del h0, h2
+
         # ---- verification of what was timed (outside the timed region) --------------------------------------------
         verify, cpu = None, None
         osample = None
@@ -296,28 +319,6 @@ def main():
         if not args.no_cpu_baseline and world == 1 and osample is not None:  # reported on rank 0 at N = 1 only
             oa0, oa2, tim, stride = osample
             cpu = cpu_baseline(nside, lmax, nbins, nbins, oa0, oa2, tim, stride)
-
-        # ---- host -> host leg (SURVEY 8d's metric definition: pageable numpy maps in, Cl blocks on the host out) -------
-        host_leg = None
-        if world == 1 and not args.no_host_leg:
-            h0 = maps0.cpu().numpy()
-            h2 = maps2.cpu().numpy().reshape(2 * n2, npix)
-
-            def host_step():
-                plan.map2alm(h0, 0, out=alm0)       # host maps are staged through HBM by the library; alms stay in HBM
-                plan.map2alm(h2, 2, out=alm2.view(2 * n2, nlm))
-                return work.all_pairs_cl()          # numpy array on the host
-
-            host_step()
-            th = time.perf_counter()
-            nh = 2
-            for _ in range(nh):
-                host_step()
-            dth = (time.perf_counter() - th) / nh
-            host_leg = {"value": npairs / dth, "unit": "map->Cl pairs/s", "ms_per_step": dth * 1e3, "steps": nh,
-                        "what": "pageable numpy maps on the host -> batched map2alm (H2D through the library's pinned staging) -> "
-                                "all-pairs Cl -> numpy Cl blocks on the host; alms never leave HBM"}
-            del h0, h2
 
         mix = None
         if not args.no_mixmat:
