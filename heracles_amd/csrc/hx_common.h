@@ -38,6 +38,7 @@ struct Runtime {
     int device = -1;
     int cus = 256;  // compute units of the device (grid size of persistent kernels)
     hipStream_t stream = nullptr;
+    hipStream_t copy = nullptr;  // created on first use (copy_stream())
     bool own_stream = false;
     bool async = false;
     bool profiling = false;
@@ -99,7 +100,8 @@ struct OutView {
 
 // Host <-> device copies on the library stream; large pageable host buffers are staged through
 // pinned memory by several host threads.  copy_d2h is complete on return, copy_h2d is stream-ordered.
-int copy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int copy_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t on = nullptr);  // on: another stream than the library's
+hipStream_t copy_stream();  // second stream of the library (uploads that overlap its kernels); nullptr if it cannot be created
 int copy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 
 int finish_call();  // synchronise unless async

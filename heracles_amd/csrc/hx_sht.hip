@@ -747,13 +747,17 @@ extern "C" void hx_plan_destroy(hx_plan *plan)
 {
     if (!plan) return;
     if (rt().ready) (void)hipStreamSynchronize(rt().stream);
+    for (int i = 0; i < 2; ++i) {
+        if (plan->stage_up[i]) (void)hipEventDestroy(plan->stage_up[i]);
+        if (plan->stage_done[i]) (void)hipEventDestroy(plan->stage_done[i]);
+    }
     delete plan;
 }
 
 extern "C" int64_t hx_plan_scratch_bytes(const hx_plan *pl)
 {
     if (!pl) return 0;
-    return (int64_t)(pl->Y.bytes + pl->F.bytes + pl->partial.bytes + pl->rec0.bytes + pl->rec2.bytes + pl->cn0.bytes + pl->al0.bytes + pl->cn2.bytes + pl->al2.bytes +
+    return (int64_t)(pl->stage[0].bytes + pl->stage[1].bytes + pl->Y.bytes + pl->F.bytes + pl->partial.bytes + pl->rec0.bytes + pl->rec2.bytes + pl->cn0.bytes + pl->al0.bytes + pl->cn2.bytes + pl->al2.bytes +
                      pl->bhat.bytes + pl->resid.bytes + pl->Fsyn.bytes);
 }
 
@@ -876,7 +880,10 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
     if (niter < 0) return fail(HX_ERR_ARG, "niter < 0");
     InView vmaps, vrw, vpw, vfl;
     OutView valms;
-    HX_TRY(vmaps.bind(maps, sizeof(double) * (size_t)ncomp * pl->npix));
+    // Host maps of a call that takes several sweeps are uploaded sweep by sweep on a second stream, into two buffers of
+    // the plan: the host thread stages sweep k + 1 (pageable -> pinned -> HBM) while the GPU transforms sweep k.
+    const bool piped = niter == 0 && !is_device_ptr(maps) && analysis_next_batch(spin, ncomp) < ncomp && copy_stream() != nullptr;
+    if (!piped) HX_TRY(vmaps.bind(maps, sizeof(double) * (size_t)ncomp * pl->npix));
     HX_TRY(vrw.bind(ring_weights, sizeof(double) * pl->nrp));
     HX_TRY(vpw.bind(pix_weights, sizeof(double) * (size_t)pl->npix));
     HX_TRY(vfl.bind(fl, sizeof(double) * (pl->lmax + 1)));
@@ -886,7 +893,31 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
     if (niter > 0) HX_TRY(resid.alloc(sizeof(double) * (size_t)8 * pl->npix));
     // without iterations the sweeps are sized by analysis_next_batch(); the synthesis of the
     // Jacobi iterations works on 8 components at a time
-    for (int c0 = 0, nb = 0; c0 < ncomp; c0 += nb) {
+    if (piped) {
+        const size_t sweep_bytes = sizeof(double) * (size_t)analysis_next_batch(spin, ncomp) * pl->npix;
+        for (int i = 0; i < 2; ++i) {
+            HX_TRY(pl->stage[i].alloc(sweep_bytes));
+            if (!pl->stage_up[i]) HX_HIP(hipEventCreateWithFlags(&pl->stage_up[i], hipEventDisableTiming));
+            if (!pl->stage_done[i]) HX_HIP(hipEventCreateWithFlags(&pl->stage_done[i], hipEventDisableTiming));
+        }
+        auto upload = [&](int k, int c0, int nb) -> int {
+            const int b = k & 1;
+            if (k >= 2) HX_HIP(hipEventSynchronize(pl->stage_done[b]));  // sweep k - 2 has read this buffer
+            HX_TRY(copy_h2d(pl->stage[b].p, maps + (size_t)c0 * pl->npix, sizeof(double) * (size_t)nb * pl->npix, copy_stream()));
+            HX_HIP(hipEventRecord(pl->stage_up[b], copy_stream()));
+            return HX_OK;
+        };
+        HX_TRY(upload(0, 0, analysis_next_batch(spin, ncomp)));
+        for (int c0 = 0, nb = 0, k = 0; c0 < ncomp; c0 += nb, ++k) {
+            nb = analysis_next_batch(spin, ncomp - c0);
+            HX_HIP(hipStreamWaitEvent(rt().stream, pl->stage_up[k & 1], 0));
+            HX_TRY(analysis_batch(pl, spin, nb, pl->stage[k & 1].as<double>(), valms.as<double2>() + (size_t)c0 * pl->nlm,
+                                  vrw.as<double>(), vpw.as<double>(), vfl.as<double>(), 0));
+            HX_HIP(hipEventRecord(pl->stage_done[k & 1], rt().stream));
+            if (c0 + nb < ncomp) HX_TRY(upload(k + 1, c0 + nb, analysis_next_batch(spin, ncomp - c0 - nb)));
+        }
+    }
+    for (int c0 = 0, nb = 0; !piped && c0 < ncomp; c0 += nb) {
         nb = niter > 0 ? std::min(8, ncomp - c0) : analysis_next_batch(spin, ncomp - c0);
         const double *dm = vmaps.as<double>() + (size_t)c0 * pl->npix;
         double2 *da = valms.as<double2>() + (size_t)c0 * pl->nlm;
@@ -900,14 +931,12 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
     }
     HX_TRY(valms.finish());
     // staging buffers of host arguments are released on return: only an all-device call may stay asynchronous
-    if (vmaps.tmp.p || vrw.tmp.p || vpw.tmp.p || vfl.tmp.p || valms.tmp.p) {
+    if (piped || vmaps.tmp.p || vrw.tmp.p || vpw.tmp.p || vfl.tmp.p || valms.tmp.p) {
         HX_HIP(hipStreamSynchronize(rt().stream));
         return HX_OK;
     }
     return finish_call();
 }
-
-
 
 extern "C" int hx_alm2map(hx_plan *pl, int spin, int ncomp, const double *alms, double *maps)
 {

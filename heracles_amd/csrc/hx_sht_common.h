@@ -244,6 +244,8 @@ struct hx_plan {
     std::vector<FftClass> fft_classes;   // ring pairs grouped by in-LDS FFT length
     hx::DevBuf fft_rp_list;
     hx::DevBuf Y, F, partial, d_dbg, resid, resid_maps, Fsyn;
+    hx::DevBuf stage[2];                      // maps of one sweep each: host input uploaded sweep by sweep (hx_map2alm)
+    hipEvent_t stage_up[2] = {nullptr, nullptr}, stage_done[2] = {nullptr, nullptr};
     hx::PlanDev dev() const;
 };
 
