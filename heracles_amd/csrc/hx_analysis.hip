@@ -65,6 +65,7 @@ struct LegParams {
     long long row0;                    // first partial row of the chunk
     int ng;                            // active column groups (<= NG, + 1 if there are extra 4-column blocks)
     int ncol;                          // doubles per F / partial row: 16 per full group + 4 per extra block
+    int pcol;                          // pipelined kernel: doubles per accumulation row = ncol rounded up to whole 128-byte lines
     int ablate;                        // diagnostic only (HX_ABLATE): 1 skip MFMA, 2 skip recursion, 8 count paths
     unsigned long long *counters;
     // pipelined kernel only: a work-group owns one m and walks its ring groups in order (tasks and of_m are then the whole
@@ -551,7 +552,11 @@ __device__ __host__ inline int pipe_tile_idx(int c, int r) { return c * 32 + ((r
 
 // NSUB: 32-l blocks per flush (their D tiles stay in registers): one work-group reduction and one pair of barriers per
 // NSUB * 32 l
-template <int SPIN, int NG, int NBX, int NSUB = 2>
+// ONESET: ONE ring set per wave (a task = 4 / 8 ring blocks instead of 8 / 16): the B operands of 40 columns (two groups + two
+// 4-column blocks) then fit the register file, a stage does the matrix work of l-block t on one tile while the SAME set's
+// recursion fills the other tile with l-block t + 1, and a flush closes the two l-blocks of a stage pair.  Ten spin-2 fields
+// are one sweep instead of two: the per-stage overheads (recursion block, stage glue) are paid once for twice the matrix work.
+template <int SPIN, int NG, int NBX, int NSUB = 2, int ONESET = 0>
 __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const double2 *__restrict__ coefn,
                                                           const double *__restrict__ alphan)
 {
@@ -562,9 +567,14 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     constexpr int DQ0 = NG * 512;              // first double of the 4-column blocks in a sub-block's D staging area
     constexpr int DSZ = NG * 512 + NBX * 128;  // doubles of one sub-block's D staging area
     constexpr int NCR = 3 * NSUB, NAR = 2 * NSUB;  // blocks in the coefficient / alpha rings
-    static_assert(NG >= 1 && NSUB * DSZ <= 2048, "D tiles of a wave must fit its second tile");
+    // doubles per wave of the second tile: the 16 x 64 lambda tile (2048), or the D tiles of a flush if they need more (one ring
+    // set, 36 / 40 columns: 2304 / 2560)
+    constexpr int TBW = ONESET && NSUB * DSZ > 2048 ? NSUB * DSZ : 2048;
+    static_assert(NG >= 1 && NSUB * DSZ <= TBW, "D tiles of a wave must fit its second tile");
+    static_assert(!ONESET || NSUB == 2, "one ring set: a flush closes the two l-blocks of a stage pair");
+    constexpr int NSB = ONESET ? 1 : 2;       // ring sets per wave
     __shared__ double tileA[NW][2048];         // set 0, 64 KiB
-    __shared__ double tileB[NW][2048];         // set 1; doubles as the D staging area of the flush
+    __shared__ double tileB[NW][TBW];          // set 1; doubles as the D staging area of the flush
     __shared__ double2 coefs[NCR][2][LBLK];    // recursion coefficients, block j in slot j % NCR; [1] = sign of q' flipped (spin 2)
     __shared__ double alphas[NAR][LBLK];       // output scalings alpha_l, block j in slot j % NAR
     // Spin 2, one column group, one block per flush: the D tiles are staged in an area of their own (20 KiB beside the
@@ -589,7 +599,11 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     // (the rows are zeroed by the host before the launch: a first group that stores instead of adding needs a branch inside
     // the stage that carries the deferred reduction -- 224 vs 229 ms per sweep of 5 spin-2 fields, same device)
     auto put = [](double *p, double v) __attribute__((always_inline)) {
+#if HX_PIPE_ABL & 32  // timing experiment: plain stores instead of the atomics (wrong results)
+        *p = v;
+#else
         __builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)p, v);
+#endif
     };
     for (int ti = 0; ti < mt.count; ++ti) {
     const LegTask task = A.tasks[mt.first + ti];
@@ -609,7 +623,8 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     int rpl[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const int rbi = SPIN == 0 ? 2 * (s * NW + w) + (lane >> 5) : s * NW + w;  // spin 0: 64 consecutive ring pairs per set
+        const int se = ONESET ? 0 : s;  // (one ring set: both tile parities belong to it)
+        const int rbi = SPIN == 0 ? 2 * (se * NW + w) + (lane >> 5) : se * NW + w;  // spin 0: 64 consecutive ring pairs per set
         rpl[s] = (task.rb0 + rbi) * RBLK + (lane & 31);
         valid[s] = rbi < task.nrb && rpl[s] < P.nrp;
         const double x = valid[s] ? P.z[rpl[s]] : 0.0;
@@ -617,9 +632,9 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     }
 
     // ---- B operands of both sets: lane (k = lane>>4, j = lane&15) holds F[ring k of the pair][parity of the position][op][column] ----
-    double fr[2][NPAIR][2][NGA], frx[2][NPAIR][2][NXA];
+    double fr[NSB][NPAIR][2][NGA], frx[NSB][NPAIR][2][NXA];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < NSB; ++s)
 #pragma unroll
         for (int sp = 0; sp < NPAIR; ++sp) {
             const int op = SPIN == 0 ? 0 : sp & 1, q = SPIN == 0 ? sp : sp >> 1;
@@ -637,10 +652,10 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         }
 
     // ---- seeds ----
-    double vc[2][NCH], vp[2][NCH];
-    int sc[2][NCH];
+    double vc[NSB][NCH], vp[NSB][NCH];
+    int sc[NSB][NCH];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NSB; ++s) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) { vc[s][c] = 0.0; vp[s][c] = 0.0; sc[s][c] = -100; }
         if (valid[s]) {
@@ -683,7 +698,7 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     // ---- one recursion step of chain c of set S; the caller stores the value it returns (the one BEFORE the step) ----
     // RM 1: chains all dead (nothing stored), 2: mixed (a dead chain stores 0), 3: all live (no exponent bookkeeping)
     auto rec_step = [&](auto SS, auto RMM, int c, int step, const double2 cc) __attribute__((always_inline)) {
-        constexpr int S = decltype(SS)::value, RM = decltype(RMM)::value;
+        constexpr int S = ONESET ? 0 : decltype(SS)::value, RM = decltype(RMM)::value;
         // every 4 steps: promote a scaled chain that has grown past 1 (value *= 2^-300, exponent += 1) -- on the exponent
         // bits, branch-free (a previous value below 2^-722 becomes 0)
         if (RM != 3 && (step & 3) == 0) {
@@ -706,8 +721,8 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     const int frow = (fch >> 1) + 8 * (fch & 1);
     // partial rows this thread writes: (group columns) rows 2 frow + fpos and + 8 of the block; (extra blocks) rows 2 qrow, + 1
     const int qrow = tid / (4 * NXA), qcol = tid % (4 * NXA);
-    double *pgrp = A.partial + (orow + 2 * frow + fpos) * A.ncol + fcol;
-    double *pquad = A.partial + (orow + 2 * qrow) * A.ncol + NG * NCOL + qcol;
+    double *pgrp = A.partial + (orow + 2 * frow + fpos) * A.pcol + fcol;
+    double *pquad = A.partial + (orow + 2 * qrow) * A.pcol + NG * NCOL + qcol;
     // deferred reduction (DEFER): operands of the group columns, then of the 4-column blocks, in the same registers
     double2 s4[NW];
     bool pend = false;
@@ -723,8 +738,8 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     auto red_finish_group = [&]() __attribute__((always_inline)) {
         const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
         put(pgrp, sx * al0);
-        put(pgrp + 8 * (long long)A.ncol, sy * al1);
-        pgrp += (long long)LBLK * A.ncol;
+        put(pgrp + 8 * (long long)A.pcol, sy * al1);
+        pgrp += (long long)LBLK * A.pcol;
     };
     auto red_issue_quad = [&]() __attribute__((always_inline)) {
         if (NBX > 0 && tid < 64 * NBX) {
@@ -739,9 +754,9 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         if (NBX > 0 && tid < 64 * NBX) {
             const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
             put(pquad, sx * al0);
-            put(pquad + A.ncol, sy * al1);
+            put(pquad + A.pcol, sy * al1);
         }
-        pquad += (long long)LBLK * A.ncol;
+        pquad += (long long)LBLK * A.pcol;
         pend = false;
     };
     double4_t accs[NSUB][NGA][2];
@@ -771,6 +786,7 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         double4_t (&acc)[NGA][2] = accs[decltype(SUBB)::value];
         double (&accx)[NXA][2] = accxs[decltype(SUBB)::value];
         constexpr int SM = decltype(SMM)::value, SR = 1 - SM, RM = (HX_PIPE_ABL & 2) ? 0 : decltype(RMM)::value;
+        constexpr int BS = ONESET ? 0 : SM;  // B operands of the set whose tile the matrix instructions read
         constexpr bool MF = decltype(MFF)::value && !(HX_PIPE_ABL & 1);
         using ISR = std::integral_constant<int, SR>;
         using IRM = std::integral_constant<int, RM>;
@@ -815,7 +831,7 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
 #pragma unroll
                 for (int pos = 0; pos < 2; ++pos) {
                     const double a = MF ? (pos ? aq[j].y : aq[j].x) : 0.0;
-                    if (MF) acc[0][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[SM][sp][pos][0], acc[0][pos], 0, 0, 0);
+                    if (MF) acc[0][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[BS][sp][pos][0], acc[0][pos], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (pos == 0) {
                         if (RM >= 2) *reinterpret_cast<double2 *>(tr + pipe_tile_idx(lane, sp)) = make_double2(cur[2 * j], cur[2 * j + 1]);
@@ -836,9 +852,9 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
                     __builtin_amdgcn_sched_barrier(0);
                     if (MF) {
 #pragma unroll
-                        for (int g = 1; g < NG; ++g) acc[g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[SM][sp][pos][g], acc[g][pos], 0, 0, 0);
+                        for (int g = 1; g < NG; ++g) acc[g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[BS][sp][pos][g], acc[g][pos], 0, 0, 0);
 #pragma unroll
-                        for (int g = 0; g < NBX; ++g) accx[g][pos] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[SM][sp][pos][g], accx[g][pos], 0, 0, 0);
+                        for (int g = 0; g < NBX; ++g) accx[g][pos] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[BS][sp][pos][g], accx[g][pos], 0, 0, 0);
                     }
                     if (DEFER && SM == 0 && pos == 1 && j == PPB - 2 && pend) {
                         if (h == 0) red_issue_group();  // into registers the stored recursion values have left
@@ -854,7 +870,7 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     };
     // 0: nothing to do, 1: all chains of the set dead, 2: mixed, 3: all live
     auto set_mode = [&](auto SS) __attribute__((always_inline)) {
-        constexpr int S = decltype(SS)::value;
+        constexpr int S = ONESET ? 0 : decltype(SS)::value;
         bool dead = !valid[S] || sc[S][0] < 0, live = !valid[S] || sc[S][0] == 0;
         if (NCH == 2) {
             dead = dead && (!valid[S] || sc[S][NCH - 1] < 0);
@@ -893,7 +909,7 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         for (int k = 0; k < HB; ++k) cq[k] = coefs[0][chalf][k];
         const int rm = set_mode(I0{});
         tl_live[0] = rm >= 2 || (HX_PIPE_ABL & 2);
-        run_stage(I0{}, I1{}, false, rm, &coefs[0][0][0], &coefs[0][0][0]);  // "MFMA set 1" off: only the recursion of set 0
+        run_stage(I0{}, I1{}, false, rm, &coefs[0][0][0], &coefs[ONESET ? 1 : 0][0][0]);  // "MFMA set 1" off: only the recursion of set 0
     }
     // Global loads of the hand-over (threads < 128: coefficient doubles; threads 128..159: alpha_l) are issued inside the
     // flush BEFORE the one that stores them to LDS, and IN FRONT of that flush's partial-sum stores: vmcnt retires in order,
@@ -933,9 +949,37 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
             tl_live[0] = rm >= 2 || (HX_PIPE_ABL & 2);
         }
     };
+    // one ring set: stage (t, tile t & 1) = matrix work of l-block t || recursion of l-block t + 1 into the other tile; a pair
+    // of stages (l-blocks b, b + 1 -> accumulator sets 0, 1) per flush
+    auto block_pair = [&](int bb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+#pragma unroll
+            for (int g = 0; g < NGA; ++g) accs[sub][g][0] = accs[sub][g][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int g = 0; g < NXA; ++g) accxs[sub][g][0] = accxs[sub][g][1] = 0.0;
+        }
+        const double2 *cf_1 = &coefs[(bb + 1) % NCR][0][0], *cf_2 = &coefs[(bb + 2) % NCR][0][0];
+        {
+            const int rm = bb + 1 < nblk ? set_mode(I0{}) : 0;
+            run_stage(I0{}, I0{}, tl_live[0], rm, cf_1, cf_2);  // l-block bb from tile A, l-block bb + 1 into tile B
+            HX_STAMP(kind_of(tl_live[0], rm));
+            tl_live[1] = rm >= 2 || (HX_PIPE_ABL & 2);
+        }
+        {
+            const int rm = bb + 2 < nblk ? set_mode(I0{}) : 0;
+            run_stage(std::integral_constant<int, NSUB - 1>{}, I1{}, tl_live[1], rm, cf_2, cf_2);  // l-block bb + 1 from tile B, bb + 2 into tile A
+            HX_STAMP(kind_of(tl_live[1], rm));
+            tl_live[0] = rm >= 2 || (HX_PIPE_ABL & 2);
+        }
+    };
     for (int b = 0; b < nblk; b += NSUB) {
-        block(I0{}, b);
-        if (NSUB > 1 && b + 1 < nblk) block(std::integral_constant<int, NSUB - 1>{}, b + 1);
+        if (ONESET) {
+            block_pair(b);
+        } else {
+            block(I0{}, b);
+            if (NSUB > 1 && b + 1 < nblk) block(std::integral_constant<int, NSUB - 1>{}, b + 1);
+        }
         if (HX_PIPE_ABL & 4) {
             double chk = 0.0;  // keeps every accumulator alive
 #pragma unroll
@@ -992,28 +1036,32 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
             if (sub > 0 && !two) break;
             const double *alb = alphas[(b + sub) % NAR];
             const double *dt0 = &tileB[0][0] + sub * DSZ;
-            const long long rsub = (long long)sub * LBLK * A.ncol;
+            const long long rsub = (long long)sub * LBLK * A.pcol;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 double2 s4[NW];
 #pragma unroll
                 for (int ww = 0; ww < NW; ++ww)
-                    s4[ww] = *reinterpret_cast<const double2 *>(dt0 + ww * 2048 + (g * 2 + fpos) * 256 + fcol * 16 + ((fch ^ (fcol & 7)) * 2));
+                    s4[ww] = *reinterpret_cast<const double2 *>(dt0 + ww * TBW + (g * 2 + fpos) * 256 + fcol * 16 + ((fch ^ (fcol & 7)) * 2));
                 const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
                 put(pgrp + rsub + g * NCOL, sx * alb[2 * frow + fpos]);
-                put(pgrp + rsub + g * NCOL + 8 * (long long)A.ncol, sy * alb[2 * frow + 8 + fpos]);
+                put(pgrp + rsub + g * NCOL + 8 * (long long)A.pcol, sy * alb[2 * frow + 8 + fpos]);
             }
             if (NBX > 0 && tid < 64 * NBX) {
                 double2 s4[NW];
 #pragma unroll
-                for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(dt0 + ww * 2048 + DQ0 + tid * 2);
+                for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(dt0 + ww * TBW + DQ0 + tid * 2);
                 const double sx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), sy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
                 put(pquad + rsub, sx * alb[2 * qrow]);
-                put(pquad + rsub + A.ncol, sy * alb[2 * qrow + 1]);
+                put(pquad + rsub + A.pcol, sy * alb[2 * qrow + 1]);
             }
         }
-        pgrp += (long long)NSUB * LBLK * A.ncol;
-        pquad += (long long)NSUB * LBLK * A.ncol;
+        pgrp += (long long)NSUB * LBLK * A.pcol;
+        pquad += (long long)NSUB * LBLK * A.pcol;
+        if (ONESET) {  // coefficients of the first vector block of the next stage pair (recursion of l-block b + 3: stored by this flush)
+#pragma unroll
+            for (int k = 0; k < HB; ++k) cq[k] = coefs[(b + NSUB + 1) % NCR][chalf][k];
+        }
         HX_STAMP(7);
         lds_barrier();  // D tiles consumed: tileB may be overwritten by the recursion of the next stage
         HX_STAMP(6);
@@ -1379,12 +1427,29 @@ static int ring_mlim(int lmax, int spin, double sth, double cth)
 // The pipelined kernel is matrix-bound, so a sweep costs what its (4-column padded) columns cost whatever the
 // split; 32 columns is what the B operands of two ring sets leave of the register file.
 struct SweepShape {
-    int ng, nbx, quad, ncol;
+    int ng, nbx, quad, ncol, oneset;
 };
-static SweepShape sweep_shape(int nb)
+// HX_PIPE_ONESET=0 keeps ten spin-2 fields as two sweeps of five (the kernel of the first half of round 2): A/B switch
+static bool oneset_enabled()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("HX_PIPE_ONESET");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v == 1;
+}
+static SweepShape sweep_shape(int spin, int nb)
 {
     const int cols = 2 * nb;
-    SweepShape sh = {0, 0, 0, 0};
+    SweepShape sh = {0, 0, 0, 0, 0};
+    if (spin == 2 && cols > 2 * NCOL && cols <= 2 * NCOL + 8 && oneset_enabled()) {  // 9 or 10 fields: two groups + one or two blocks, one ring set per wave
+        sh.ng = 2;
+        sh.nbx = (cols - 2 * NCOL) / 4;
+        sh.oneset = 1;
+        sh.ncol = cols;
+        return sh;
+    }
     if (cols <= 8) {
         sh.quad = (cols + 3) / 4;
         sh.ncol = 4 * sh.quad;
@@ -1400,14 +1465,17 @@ static SweepShape sweep_shape(int nb)
     sh.ncol = NCOL * sh.ng + 4 * sh.nbx;
     return sh;
 }
-int analysis_max_comp(int /*spin*/) { return 8 * NGMAX; }
+int analysis_max_comp(int spin) { return (spin == 2 && oneset_enabled()) ? 8 * NGMAX + 4 : 8 * NGMAX; }
 
 // Components of the next sweep when `remaining` are left: as few sweeps as the 32-column limit allows, of equal
 // size (ten spin-2 fields = 5 + 5, each one group + one 4-column block: no padded columns, and both sweeps have
 // enough matrix work per recursion step to hide the recursion).
-int analysis_next_batch(int spin, int remaining)
+// from_host: the maps are uploaded sweep by sweep while the previous sweep is transformed (hx_map2alm): sweeps of at most 16
+// components, so that ten spin-2 fields from host memory are two overlapped sweeps of five rather than one sweep behind its
+// whole upload.
+int analysis_next_batch(int spin, int remaining, bool from_host)
 {
-    const int unit = spin == 0 ? 1 : 2, maxu = analysis_max_comp(spin) / unit;
+    const int unit = spin == 0 ? 1 : 2, maxu = (from_host ? 8 * NGMAX : analysis_max_comp(spin)) / unit;
     const int units = remaining / unit;
     const int nsweep = (units + maxu - 1) / maxu;
     return unit * ((units + nsweep - 1) / nsweep);
@@ -1480,6 +1548,9 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
 {
     // column groups of the F / partial rows: full groups (+ 1 holding the extra blocks); the 4x4x4 path has one
     const int ng = sh.quad ? 1 : sh.ng + (sh.nbx > 0 ? 1 : 0), ncol = sh.ncol;
+    // rows of the pipelined kernel start on 128-byte lines: the atomics of a flush (16 lanes x 8 B per row and column group)
+    // then touch whole aligned lines instead of straddling two
+    const int pcol = sh.quad ? ncol : (ncol + 15) / 16 * 16;
     hipStream_t st = rt().stream;
     PlanDev P = pl->dev();
     const int t0 = ts.of_m[m0].first;
@@ -1495,12 +1566,12 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         ProfScope ps2(SPIN == 0 ? "legendre_analysis_s0" : "legendre_analysis_s2");
         LegParams A;
         A.P = P; A.tasks = ts.d_tasks.as<LegTask>() + t0; A.F = pl->F.as<double>(); A.partial = pl->partial.as<double>();
-        A.m0 = m0; A.row0 = ts.rows_before_m[m0]; A.ng = ng; A.ncol = ncol;
+        A.m0 = m0; A.row0 = ts.rows_before_m[m0]; A.ng = ng; A.ncol = ncol; A.pcol = pcol;
         A.ablate = 0;
         A.counters = nullptr;
         A.of_m = ts.d_of_m.as<MTasks>(); A.arow = ts.d_arow.as<long long>(); A.arow0 = ts.arow[m0];
         if (!sh.quad) A.tasks = ts.d_tasks.as<LegTask>();  // the pipelined kernel indexes the whole list through of_m
-        if (!sh.quad) HX_HIP(hipMemsetAsync(pl->partial.p, 0, (size_t)(ts.arow[m1] - ts.arow[m0]) * ncol * sizeof(double), st));
+        if (!sh.quad) HX_HIP(hipMemsetAsync(pl->partial.p, 0, (size_t)(ts.arow[m1] - ts.arow[m0]) * pcol * sizeof(double), st));
 #if defined(HX_DIAG) && (HX_PIPE_ABL & 8)
         HX_TRY(pl->d_dbg.alloc(144));
         HX_HIP(hipMemsetAsync(pl->d_dbg.p, 0, 144, st));
@@ -1533,6 +1604,10 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
             hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 1, 2>), pgrid, pblock, 0, st, A, cn, al);
         else if (sh.ng == 1 && sh.nbx == 1)
             hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 1, 1>), pgrid, pblock, 0, st, A, cn, al);
+        else if (sh.oneset && SPIN == 2 && sh.nbx == 2)
+            hipLaunchKernelGGL((k_legendre_pipe<2, 2, 2, 2, 1>), pgrid, pblock, 0, st, A, cn, al);
+        else if (sh.oneset && SPIN == 2 && sh.nbx == 1)
+            hipLaunchKernelGGL((k_legendre_pipe<2, 2, 1, 2, 1>), pgrid, pblock, 0, st, A, cn, al);
         else if (sh.ng == 2 && sh.nbx == 0)
             hipLaunchKernelGGL((k_legendre_pipe<SPIN, 2, 0, 1>), pgrid, pblock, 0, st, A, cn, al);  // a second accumulator set spills 20-76 registers
         else
@@ -1563,7 +1638,7 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
     {
         ProfScope ps("alm_reduce");
         hipLaunchKernelGGL(k_alm_reduce<SPIN>, dim3(m1 - m0), dim3(256), 0, st, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
-                           pl->partial.as<double>(), sh.quad ? ts.rows_before_m[m0] : ts.arow[m0], m0, nb, ng, ncol, d_fl, add, d_alms, pl->nlm,
+                           pl->partial.as<double>(), sh.quad ? ts.rows_before_m[m0] : ts.arow[m0], m0, nb, ng, pcol, d_fl, add, d_alms, pl->nlm,
                            sh.quad ? nullptr : ts.d_arow.as<long long>());
     }
     HX_HIP(hipGetLastError());
@@ -1581,10 +1656,11 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     if (spin) HX_TRY(ensure_rec2(pl));
     // doubles per F / partial row: only the columns in use are stored -- 4-column granularity on the
     // 4x4x4 path (<= 8 columns), 16 per full group + 4 per extra block on the pipelined kernel
-    const SweepShape sh = sweep_shape(nb);
+    const SweepShape sh = sweep_shape(spin, nb);
     const bool half = sh.quad == 1 && spin == 0 && HX_QNW0 < LegCfg<0>::NW;
     if (half) HX_TRY(build_task_set(pl, 0, HX_QNW0, pl->ts[2]));
-    hx_plan::TaskSet &ts = half ? pl->ts[2] : pl->ts[sidx];
+    if (sh.oneset) HX_TRY(build_task_set(pl, 2, PipeCfg<2>::NW * PipeCfg<2>::RBS, pl->ts[3]));  // one ring set per wave: 4 ring blocks per task
+    hx_plan::TaskSet &ts = sh.oneset ? pl->ts[3] : (half ? pl->ts[2] : pl->ts[sidx]);
     const int ncol = sh.ncol;
     if (pl->hsrc == nullptr) {
         HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
@@ -1593,7 +1669,7 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
 
     // budget: hx_set_scratch_budget() / HX_SCRATCH_GB, else 64 GB but never more than half of what is free on
     // the device (what this plan already holds for F / partial counts as free)
-    double budget = 64e9;
+    double budget = 80e9;
     if (scratch_budget_bytes() > 0.0) budget = scratch_budget_bytes();
     else {
         size_t fr = 0, tot = 0;
@@ -1605,19 +1681,20 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     const int lmax = pl->lmax;
     // rows of the partial buffer: one span per (m, ring group) on the 4x4x4 kernels, one per m on the pipelined kernel
     const std::vector<long long> &prow = sh.quad ? ts.rows_before_m : ts.arow;
+    const int pcol = sh.quad ? ncol : (ncol + 15) / 16 * 16;  // doubles per row of the partial buffer (launch_chunk)
     std::vector<std::pair<int, int>> chunks;
     size_t maxF = 16, maxP = 16;
     for (int m0 = 0; m0 <= lmax;) {
         int m1 = m0 + 1;  // a chunk holds at least one m, whatever the budget
         while (m1 <= lmax) {
             const double bytes = f_per_m * (m1 + 1 - m0) +
-                                 (double)(prow[m1 + 1] - prow[m0]) * ncol * sizeof(double);
+                                 (double)(prow[m1 + 1] - prow[m0]) * pcol * sizeof(double);
             if (bytes > budget) break;
             ++m1;
         }
         chunks.emplace_back(m0, m1);
         maxF = std::max(maxF, (size_t)(f_per_m * (m1 - m0)));
-        maxP = std::max(maxP, (size_t)(prow[m1] - prow[m0]) * ncol * sizeof(double));
+        maxP = std::max(maxP, (size_t)(prow[m1] - prow[m0]) * pcol * sizeof(double));
         m0 = m1;
     }
     HX_TRY(pl->F.alloc(maxF));
@@ -1654,7 +1731,7 @@ extern "C" int hx_plan_mfma_flops(hx_plan *pl, int spin, int ncomp, double *flop
     double per_wave_block = 0.0;
     for (int c0 = 0, nb = 0; c0 < ncomp; c0 += nb) {
         nb = analysis_next_batch(spin, ncomp - c0);
-        const SweepShape sh = sweep_shape(nb);
+        const SweepShape sh = sweep_shape(spin, nb);
         per_wave_block += 16.0 * nop * (sh.ng * 2048.0 + (sh.nbx + sh.quad) * 512.0);
     }
     *flops = wave_blocks * per_wave_block;

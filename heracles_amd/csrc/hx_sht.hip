@@ -882,7 +882,7 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
     OutView valms;
     // Host maps of a call that takes several sweeps are uploaded sweep by sweep on a second stream, into two buffers of
     // the plan: the host thread stages sweep k + 1 (pageable -> pinned -> HBM) while the GPU transforms sweep k.
-    const bool piped = niter == 0 && !is_device_ptr(maps) && analysis_next_batch(spin, ncomp) < ncomp && copy_stream() != nullptr;
+    const bool piped = niter == 0 && !is_device_ptr(maps) && analysis_next_batch(spin, ncomp, true) < ncomp && copy_stream() != nullptr;
     if (!piped) HX_TRY(vmaps.bind(maps, sizeof(double) * (size_t)ncomp * pl->npix));
     HX_TRY(vrw.bind(ring_weights, sizeof(double) * pl->nrp));
     HX_TRY(vpw.bind(pix_weights, sizeof(double) * (size_t)pl->npix));
@@ -894,7 +894,7 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
     // without iterations the sweeps are sized by analysis_next_batch(); the synthesis of the
     // Jacobi iterations works on 8 components at a time
     if (piped) {
-        const size_t sweep_bytes = sizeof(double) * (size_t)analysis_next_batch(spin, ncomp) * pl->npix;
+        const size_t sweep_bytes = sizeof(double) * (size_t)analysis_next_batch(spin, ncomp, true) * pl->npix;
         for (int i = 0; i < 2; ++i) {
             HX_TRY(pl->stage[i].alloc(sweep_bytes));
             if (!pl->stage_up[i]) HX_HIP(hipEventCreateWithFlags(&pl->stage_up[i], hipEventDisableTiming));
@@ -907,14 +907,14 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
             HX_HIP(hipEventRecord(pl->stage_up[b], copy_stream()));
             return HX_OK;
         };
-        HX_TRY(upload(0, 0, analysis_next_batch(spin, ncomp)));
+        HX_TRY(upload(0, 0, analysis_next_batch(spin, ncomp, true)));
         for (int c0 = 0, nb = 0, k = 0; c0 < ncomp; c0 += nb, ++k) {
-            nb = analysis_next_batch(spin, ncomp - c0);
+            nb = analysis_next_batch(spin, ncomp - c0, true);
             HX_HIP(hipStreamWaitEvent(rt().stream, pl->stage_up[k & 1], 0));
             HX_TRY(analysis_batch(pl, spin, nb, pl->stage[k & 1].as<double>(), valms.as<double2>() + (size_t)c0 * pl->nlm,
                                   vrw.as<double>(), vpw.as<double>(), vfl.as<double>(), 0));
             HX_HIP(hipEventRecord(pl->stage_done[k & 1], rt().stream));
-            if (c0 + nb < ncomp) HX_TRY(upload(k + 1, c0 + nb, analysis_next_batch(spin, ncomp - c0 - nb)));
+            if (c0 + nb < ncomp) HX_TRY(upload(k + 1, c0 + nb, analysis_next_batch(spin, ncomp - c0 - nb, true)));
         }
     }
     for (int c0 = 0, nb = 0; !piped && c0 < ncomp; c0 += nb) {

@@ -239,7 +239,7 @@ struct hx_plan {
         std::vector<long long> rows_before_m; // partial rows of all tasks with smaller m (size lmax+2)
         std::vector<long long> arow;          // the same with ONE span of rows per m (pipelined kernel: ring groups summed in place)
         hx::DevBuf d_tasks, d_of_m, d_arow;
-    } ts[3];  // spin 0, spin 2, spin 0 with half-size work-groups
+    } ts[4];  // spin 0, spin 2, spin 0 with half-size work-groups, spin 2 with one ring set per wave (4 ring blocks per task)
     struct FftClass { int M, first, count, big; };
     std::vector<FftClass> fft_classes;   // ring pairs grouped by in-LDS FFT length
     hx::DevBuf fft_rp_list;
@@ -259,6 +259,6 @@ int build_tasks(hx_plan *pl, int spin);
 int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 *d_alms, const double *d_rw,
                    const double *d_pw, const double *d_fl, int add);
 int analysis_max_comp(int spin);
-int analysis_next_batch(int spin, int remaining);
+int analysis_next_batch(int spin, int remaining, bool from_host = false);
 int legendre_synthesis(hx_plan *pl, int spin, int nb, const double2 *d_alms, double *d_Fsyn);
 }  // namespace hx
