@@ -210,9 +210,10 @@ def main():
                 tk = json.load(f)["kernels"]
         except (OSError, ValueError, KeyError):
             return None, None
+        # the variant the timed (device-resident) step runs is the one with the most bytes per launch: the host -> host leg of
+        # the profiled command goes through two-sweep variants of the same family (maps uploaded sweep by sweep)
         sel = [v for k, v in tk.items() if k.startswith(prefix)]
-        n = sum(v["launches"] for v in sel)
-        return (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n if n else None), path
+        return (max(v["hbm_bytes_per_launch"] for v in sel) if sel else None), path
 
     def roof(name, kernel, alg_flops_step, spin, ncomp):
         nl_, ms_ = hx._lib.profile_get(name)

@@ -1647,7 +1647,7 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
 
 // One analysis pass over a batch of <= 8*NGMAX components (device pointers).  F and the
 // partial sums are produced per m-chunk so that their footprint stays within a budget
-// (HX_SCRATCH_GB, default min(64 GB, half the free HBM)); Y (ring spectra of the batch) persists across chunks.
+// (HX_SCRATCH_GB, default min(80 GB, half the free HBM)); Y (ring spectra of the batch) persists across chunks.
 int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 *d_alms, const double *d_rw,
                    const double *d_pw, const double *d_fl, int add)
 {
@@ -1667,7 +1667,7 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
         HX_TRY(launch_ring_subdft_maps(pl, nb, d_maps, d_pw, pl->Y.as<double2>()));
     }
 
-    // budget: hx_set_scratch_budget() / HX_SCRATCH_GB, else 64 GB but never more than half of what is free on
+    // budget: hx_set_scratch_budget() / HX_SCRATCH_GB, else 80 GB but never more than half of what is free on
     // the device (what this plan already holds for F / partial counts as free)
     double budget = 80e9;
     if (scratch_budget_bytes() > 0.0) budget = scratch_budget_bytes();

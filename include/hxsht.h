@@ -65,7 +65,7 @@ int hx_set_max_lds_fft(int points);
 void hx_plan_destroy(hx_plan *plan);
 int64_t hx_plan_scratch_bytes(const hx_plan *plan);
 /* HBM the analysis may use for the operands and ring-group partial sums of ONE m-chunk (bytes; a chunk always
- * holds at least one m).  0 (default) = min(64 GB, half of the free HBM); the environment variable
+ * holds at least one m).  0 (default) = min(80 GB, half of the free HBM); the environment variable
  * HX_SCRATCH_GB sets the initial value.  The result does not depend on the chunking (tests/test_gpu_sht.py). */
 int hx_set_scratch_budget(double bytes);
 /* m-chunks the most recent analysis sweep of this plan was cut into (diagnostic / tests). */

@@ -144,17 +144,17 @@ def test_map2alm_against_oracle_on_sampled_m(plan, oracle, spin):
 @pytest.mark.parametrize("spin,ncomp,check", [(0, 10, (0, 7, 8, 9)), (2, 20, (0, 1, 8, 9, 10, 11, 18, 19))])
 def test_bench_batch_shapes_against_oracle_on_sampled_m(plan, oracle, spin, ncomp, check):
     """The batches bench.py times, at its size: 10 spin-0 maps = ONE sweep of the pipelined kernel (a 16-column group + a
-    4-column block: components 8, 9 sit in the block), 20 spin-2 components = two sweeps of 5 fields (fields 0 and 4 = first
-    and last of the first sweep -- the last one in the 4-column block --, 5 and 9 of the second).  Components of every
-    column group / block / sweep against the oracle on every 512th m (all rings, all l); one work-group per m adds its
-    32 / 16 ring groups in place there."""
+    4-column block: components 8, 9 sit in the block), 20 spin-2 components = ONE sweep of 40 columns on the kernel with one
+    ring set per wave (fields 0 and 4 in the first and second 16-column group, 5 in the second group, 9 in the second
+    4-column block).  Components of every column group / block against the oracle on every 512th m (all rings, all l);
+    one work-group per m adds its 16 (spin 0) / 64 (spin 2) ring groups in place there."""
     import torch
 
     g = torch.Generator(device="cuda").manual_seed(30 + spin)
     x = torch.randn((ncomp, NPIX), dtype=torch.float64, device="cuda", generator=g)
     b = torch.empty((ncomp, NLM), dtype=torch.complex128, device="cuda")
     plan.map2alm(x, spin, out=b, niter=0)
-    assert plan.last_chunks == 1  # F and the rows of a whole sweep fit the default budget
+    assert plan.last_chunks == 1  # F and the rows of a whole sweep fit the default budget (spin 2: 64 + 7 GB of 80)
     stride = 512
     step = 1 if spin == 0 else 2
     for c0 in check[::step]:

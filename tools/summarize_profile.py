@@ -20,7 +20,7 @@ def short(name):
 
 
 # 1. kernel stats of the traced bench command
-stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0]
+stats = max(glob.glob(f"{src}/trace/*/*_kernel_stats.csv"), key=os.path.getmtime)  # a stale run directory may sit beside the new one
 rows = list(csv.DictReader(open(stats)))
 with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
     w = csv.writer(f)
@@ -34,7 +34,7 @@ open(f"profiles/{tag}_bench_under_rocprof.json", "w").write(bench + "\n")
 out = [f"# PMC summary ({tag}): per-dispatch averages at FULL size (bench.py --steps 1 --warmup 0: nside 4096, lmax 6144, 10 + 10 maps)\n",
        "clock = GRBM_GUI_ACTIVE / 8 XCDs / duration; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x clock)\n"]
 for d in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
-    fs = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")
+    fs = sorted(glob.glob(f"{src}/{d}/*/*_counter_collection.csv"), key=os.path.getmtime, reverse=True)
     if not fs:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -46,7 +46,7 @@ for d in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         seen[k].add(r["Dispatch_Id"])
     dur = collections.defaultdict(list)
-    for r in csv.DictReader(open(glob.glob(f"{src}/{d}/*/*_kernel_trace.csv")[0])):
+    for r in csv.DictReader(open(fs[0].replace("_counter_collection.csv", "_kernel_trace.csv"))):
         dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     out.append(f"\n## {d}\n")
     for k in sorted(agg):
@@ -66,7 +66,7 @@ open(f"profiles/{tag}_pmc_summary.md", "w").write("\n".join(out) + "\n")
 # 3. HBM traffic per launch (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md)
 res = collections.defaultdict(dict)
 for kind, d in (("fetch", "pmc_fetch"), ("write", "pmc_write")):
-    fs = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")
+    fs = sorted(glob.glob(f"{src}/{d}/*/*_counter_collection.csv"), key=os.path.getmtime, reverse=True)
     if not fs:
         continue
     agg, n = collections.defaultdict(float), collections.defaultdict(set)
