@@ -230,6 +230,49 @@ def test_map2alm_m_chunked_batches_medium(oracle, spin, ncomp):
         assert err <= TOL * scale, (m, err / scale)
 
 
+@pytest.mark.parametrize("nside,lmax", [(16, 32), (16, 47), (64, 100), (256, 511)])
+@pytest.mark.parametrize("ncomp", [18, 20, 22])
+def test_one_ring_set_kernel_device_batches(oracle, nside, lmax, ncomp):
+    """9 - 10 spin-2 fields that are ALREADY IN HBM go through the Legendre kernel with one ring set per wave in one sweep of
+    36 / 40 columns (host arrays are uploaded and transformed as two overlapped sweeps of the two-set kernel instead, which is
+    what the other tests of this file exercise): against the oracle, with odd and even numbers of l-blocks, tasks of fewer
+    than 4 ring blocks, 22 components = one sweep of 6 + one of 5 fields, and -- at nside 256 -- cut into m-chunks without
+    changing a bit."""
+    import torch
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(900 + nside + ncomp)
+    maps = rng.standard_normal((ncomp, 12 * nside**2))
+    dev = torch.as_tensor(maps).cuda()
+    plan = hx.get_plan(nside, lmax)
+    out = plan.map2alm(dev, 2)
+    got = out.cpu().numpy() if hasattr(out, "cpu") else np.asarray(out)
+    if nside >= 256:
+        hx._lib.set_scratch_budget(2.5e7)
+        try:
+            again = plan.map2alm(dev, 2)
+            assert plan.last_chunks >= 3, plan.last_chunks
+        finally:
+            hx._lib.set_scratch_budget(0)
+        np.testing.assert_array_equal(again.cpu().numpy() if hasattr(again, "cpu") else np.asarray(again), got)
+        stride = 16
+        oracle.set_mstride(stride)
+        try:
+            ref = oracle.map2alm(maps, nside, lmax, spin=2)
+        finally:
+            oracle.set_mstride(1)
+        scale = np.abs(got).max()
+        for m in range(0, lmax + 1, stride):
+            base = m * (2 * lmax + 1 - m) // 2
+            sl = slice(base + m, base + lmax + 1)
+            assert np.abs(got[:, sl] - ref[:, sl]).max() <= 1e-11 * scale, m
+    else:
+        close(got, oracle.map2alm(maps, nside, lmax, spin=2))
+    # the host route (two sweeps of the two-set kernel) agrees to rounding
+    host = plan.map2alm(maps, 2)
+    assert np.abs(host - got).max() <= 1e-12 * np.abs(got).max()
+
+
 @pytest.mark.parametrize("spin,ncomp", [(0, 10), (2, 10), (2, 16)])
 def test_ring_groups_summed_in_fixed_order(spin, ncomp):
     """The pipelined Legendre kernel adds the ring groups of an m in place with f64 atomics: one work-group per m, program
