@@ -1548,9 +1548,9 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
 {
     // column groups of the F / partial rows: full groups (+ 1 holding the extra blocks); the 4x4x4 path has one
     const int ng = sh.quad ? 1 : sh.ng + (sh.nbx > 0 ? 1 : 0), ncol = sh.ncol;
-    // rows of the pipelined kernel start on 128-byte lines: the atomics of a flush (16 lanes x 8 B per row and column group)
-    // then touch whole aligned lines instead of straddling two
-    const int pcol = sh.quad ? ncol : (ncol + 15) / 16 * 16;
+    // rows of the one-ring-set kernel start on 128-byte lines: the atomics of a flush (16 lanes x 8 B per row and column group)
+    // then touch whole aligned lines instead of straddling two (-10 ms for its 40-column sweep; nothing for the other shapes)
+    const int pcol = sh.oneset ? (ncol + 15) / 16 * 16 : ncol;
     hipStream_t st = rt().stream;
     PlanDev P = pl->dev();
     const int t0 = ts.of_m[m0].first;
@@ -1681,7 +1681,7 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     const int lmax = pl->lmax;
     // rows of the partial buffer: one span per (m, ring group) on the 4x4x4 kernels, one per m on the pipelined kernel
     const std::vector<long long> &prow = sh.quad ? ts.rows_before_m : ts.arow;
-    const int pcol = sh.quad ? ncol : (ncol + 15) / 16 * 16;  // doubles per row of the partial buffer (launch_chunk)
+    const int pcol = sh.oneset ? (ncol + 15) / 16 * 16 : ncol;  // doubles per row of the partial buffer (launch_chunk)
     std::vector<std::pair<int, int>> chunks;
     size_t maxF = 16, maxP = 16;
     for (int m0 = 0; m0 <= lmax;) {
