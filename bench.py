@@ -134,6 +134,10 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        # the communicator is set up by the first collective: do one now, so that a run with --warmup 0 does not time it
+        tok = torch.ones(1, dtype=torch.float64, device="cpu" if share else dev)
+        dist.all_reduce(tok)
+        assert float(tok.item()) == world
 
     import heracles_amd as hx
     from heracles_amd import distributed as hxd
