@@ -26,10 +26,11 @@ SYMBOLS = (
     "hx_version", "hx_last_error", "hx_device_count", "hx_init", "hx_set_stream",
     "hx_get_stream", "hx_set_async", "hx_synchronize", "hx_timer_start", "hx_timer_stop",
     "hx_profile_enable", "hx_profile_reset", "hx_profile_get", "hx_plan_create", "hx_set_max_lds_fft",
-    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_set_scratch_budget", "hx_plan_last_chunks", "hx_plan_mfma_flops", "hx_plan_executed_flops", "hx_measure_peaks", "hx_measured_mfma_clock", "hx_map2alm", "hx_alm2map",
+    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_set_scratch_budget", "hx_plan_last_chunks", "hx_plan_mfma_flops", "hx_plan_executed_flops", "hx_executed_flops", "hx_measure_peaks", "hx_measured_mfma_clock", "hx_map2alm", "hx_alm2map",
     "hx_alm2cl_pairs", "hx_gauss_legendre", "hx_wigner_d_table", "hx_mixmat",
     "hx_mixmat_eb", "hx_mixmat_batch", "hx_mixctx_create", "hx_mixctx_apply", "hx_mixctx_destroy", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_alm_resample", "hx_region_maps", "hx_alm_subtract", "hx_fits_unpack_f64", "hx_fits_pack_f64",
     "hx_pointsht_create", "hx_pointsht_destroy", "hx_pointsht_info", "hx_pointsht_adjoint",
+    "hx_pixel_weights_size", "hx_pixel_weights_expand",
 )
 
 
@@ -80,6 +81,7 @@ def load():
         L.hx_plan_last_chunks.argtypes = [vp]
         L.hx_plan_mfma_flops.argtypes = [vp, i, i, C.POINTER(C.c_double)]
         L.hx_plan_executed_flops.argtypes = [vp, i, i, C.POINTER(C.c_double)]
+        L.hx_executed_flops.argtypes = [C.POINTER(C.c_double), i]
         L.hx_measure_peaks.argtypes = [C.POINTER(C.c_double)]
         L.hx_measured_mfma_clock.restype = C.c_double
         L.hx_map2alm.argtypes = [vp, i, i, dp, dp, dp, dp, dp, i]
@@ -111,6 +113,9 @@ def load():
         L.hx_pointsht_destroy.restype = None
         L.hx_pointsht_info.argtypes = [vp, C.POINTER(C.c_int)]
         L.hx_pointsht_adjoint.argtypes = [vp, i, i, C.c_int64, dp, dp, dp]
+        L.hx_pixel_weights_size.argtypes = [i]
+        L.hx_pixel_weights_size.restype = C.c_int64
+        L.hx_pixel_weights_expand.argtypes = [i, C.c_int64, dp, dp]
         L.hx_timer_stop.argtypes = [C.POINTER(C.c_float)]
         L.hx_profile_get.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         _lib = L
@@ -180,6 +185,15 @@ def measure_peaks():
 
 def synchronize():
     check(load().hx_synchronize())
+
+
+def executed_flops(reset=False):
+    """(matrix-instruction flops, vector-unit flops) the Legendre analysis kernels executed since the last reset, as counted by
+    the kernels themselves."""
+    ensure_init()
+    out = (C.c_double * 2)()
+    check(load().hx_executed_flops(out, 1 if reset else 0))
+    return out[0], out[1]
 
 
 def set_scratch_budget(nbytes: float):

@@ -78,39 +78,6 @@ struct LegParams {
 // =====================================================================================
 // Y -> F operands:  un-pack N/S, ring phase, quadrature weight, parity combinations
 // =====================================================================================
-// What a ring pair needs at one m, whatever the component: where Z[m] and Z[-m] sit in its spectrum (X[4k+r] = Y_r[k]) and
-// the phase x quadrature weight.  One thread per ring pair of the block computes it (integer divisions, one sincospi) and
-// hands it over through LDS: done per (ring pair, m, component slot) it was half of the kernel's time (3.7e9 vector
-// instructions per spin-2 sweep, profiles/r02_pmc_summary.md).
-struct RingAtM {
-    double2 ph;        // w e^{-i m phi_0} (w = 0 for padding ring pairs)
-    long long i0, i1;  // Z[m mod nphi], Z[-m mod nphi] relative to the component's spectrum
-    int hasS;
-};
-
-// F_N(m), F_S(m) of ring pair rp for component c, including phase and quadrature weight
-__device__ inline void ring_modes_ns(const PlanDev &P, const double2 *__restrict__ Y, int c, int rp, int m,
-                                     const RingAtM &r, double2 &FN, double2 &FS)
-{
-    if (P.hsrc) {
-        // equiangular rings theta_j = 2 pi (j + 1/2) / N of the point transform: the spectrum h_m is given on the full circle,
-        // lambda_lm(2 pi - theta) = (-1)^m lambda_lm(theta) (both spins) folds the second half onto the rings
-        const double w = r.ph.x;
-        const double2 *h = P.hsrc + (long long)c * P.hsrc_stride + (long long)m * P.hN;
-        const double sg = (m & 1) ? -w : w;
-        const double2 a = h[rp], b = h[P.hN - 1 - rp], cN = h[P.hN / 2 - 1 - rp], d = h[P.hN / 2 + rp];
-        FN = make_double2(w * a.x + sg * b.x, w * a.y + sg * b.y);
-        FS = make_double2(w * cN.x + sg * d.x, w * cN.y + sg * d.y);
-        return;
-    }
-    const double2 *Yc = Y + (long long)c * P.ny;
-    const double2 a = Yc[r.i0], b = cconj(Yc[r.i1]);
-    const double2 xn = cscale(cadd(a, b), 0.5);
-    const double2 xs = mul_mi(cscale(csub(a, b), 0.5));  // (a-b)/(2i)
-    FN = cmul(xn, r.ph);
-    FS = r.hasS ? cmul(xs, r.ph) : make_double2(0.0, 0.0);
-}
-
 // grid: x = m - m0, y = tiles of 32 ring pairs; block 256 = 32 ring pairs x 8 slots.
 // Component c lives in column group c/8, slot c%8 (spin 2: field f = c/2 in group f/4).
 template <int SPIN>
@@ -126,24 +93,7 @@ __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double
     // never read
     const MTasks mt = of_m[m];
     if (mt.count == 0 || (int)blockIdx.y < tasks[mt.first].rb0) return;
-    if (threadIdx.x < 32) {
-        const int r = blockIdx.y * 32 + threadIdx.x;
-        RingAtM q;
-        const bool live = r < P.nrp;
-        const double w = live ? (rw ? rw[r] : 1.0) * P.wnorm : 0.0;
-        q.ph = make_double2(w, 0.0);
-        q.i0 = q.i1 = 0;
-        q.hasS = 0;
-        if (live && !P.hsrc) {
-            const int n = P.nsub[r], nphi = 4 * n;
-            const int mm = m % nphi, mc = (nphi - mm) % nphi;
-            q.i0 = P.startN[r] + (long long)(mm & 3) * n + (mm >> 2);  // Z[mm], X[4k+r] = Y_r[k]
-            q.i1 = P.startN[r] + (long long)(mc & 3) * n + (mc >> 2);
-            if (P.shifted[r]) q.ph = cscale(expipi(-(double)(m % (2 * nphi)) / (double)nphi), w);
-            q.hasS = P.startS[r] >= 0;
-        }
-        ring_at_m[threadIdx.x] = q;
-    }
+    if (threadIdx.x < 32) ring_at_m[threadIdx.x] = ring_at_m_of(P, blockIdx.y * 32 + threadIdx.x, m, rw);
     __syncthreads();
     const int rp = blockIdx.y * 32 + (threadIdx.x >> 3);
     const int slot = threadIdx.x & 7;
@@ -524,6 +474,12 @@ __global__ __launch_bounds__(NWV * 64, (NWV < LegCfg<SPIN>::NW ? 2 : 1)) void k_
 //     order, as before.
 // Layouts of F and the task list are those of the first kernel (a task = 16 / 8 blocks of 32 ring pairs); the rows of
 // `partial` are shared by the tasks of an m (LegParams::arow).
+// Work the Legendre kernels EXECUTE, counted by the kernels themselves (one atomic per wave at its end; wave-uniform scalar
+// counters): [0] FP64 flops of the matrix instructions actually issued (stages whose ring set is still below 2^-300 skip theirs),
+// [1] FP64 vector flops of the recursions (2 FMAs per generated value).  bench.py's roofline fraction is quoted on these; they agree
+// with SQ_INSTS_VALU_MFMA_F64 of the PMC passes (profiles/).
+__device__ unsigned long long g_exec_flops[2];
+
 template <int SPIN>
 struct PipeCfg {
     static constexpr int NW = 4;                              // waves per work-group
@@ -605,6 +561,7 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         __builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)p, v);
 #endif
     };
+    int n_mf = 0, n_rec = 0;  // stages of this wave that issued their matrix instructions / ran a recursion (wave-uniform)
     for (int ti = 0; ti < mt.count; ++ti) {
     const LegTask task = A.tasks[mt.first + ti];
     // the thread index goes through an empty asm statement per ring group: everything derived from it (LDS addresses, row
@@ -886,6 +843,8 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     using BF = std::integral_constant<bool, false>;
     // dispatch on (MFMA of set SM wanted, recursion mode of the other set)
     auto run_stage = [&](auto SUBB, auto SMM, bool mf, int rm, const double2 *cf_rec, const double2 *cf_next) __attribute__((always_inline)) {
+        n_mf = __builtin_amdgcn_readfirstlane(n_mf + (mf ? 1 : 0));
+        n_rec = __builtin_amdgcn_readfirstlane(n_rec + (rm ? 1 : 0));
         if (mf) {
             if (rm == 3) stage(SUBB, SMM, BT{}, I3{}, cf_rec, cf_next);
             else if (rm == 2) stage(SUBB, SMM, BT{}, I2{}, cf_rec, cf_next);
@@ -1084,6 +1043,11 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     }
 #endif
     }  // ring groups of this m
+    if ((threadIdx.x & 63) == 0) {
+        // a stage = 16 slot pairs x 2 positions x (NG 16x16x4 + NBX 4x4x4_4b) instructions; a recursion stage = 64 lanes x 32 steps x 2 FMAs
+        atomicAdd(&g_exec_flops[0], (unsigned long long)n_mf * (32ull * (NG * 2048ull + NBX * 512ull)));
+        atomicAdd(&g_exec_flops[1], (unsigned long long)n_rec * (64ull * LBLK * 4ull));
+    }
 }
 
 // =====================================================================================
@@ -1645,12 +1609,80 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
     return HX_OK;
 }
 
+// Batches of <= 4 spin-0 maps / <= 2 spin-2 fields: one sweep PER MAP / FIELD of the vector-unit kernel (hx_legendre_valu.hip).
+// The ring Fourier stage runs once for the whole batch.  HX_VALU=0 keeps the 4x4x4 kernels of round 1 (A/B switch).
+static bool valu_enabled()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("HX_VALU");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v == 1;
+}
+static bool valu_batch(int spin, int nb) { return valu_enabled() && nb <= 4; }
+
+static int analysis_batch_valu(hx_plan *pl, int spin, int nb, const double *d_maps, double2 *d_alms, const double *d_rw,
+                               const double *d_pw, const double *d_fl, int add)
+{
+    if (spin) HX_TRY(ensure_rec2(pl));
+    hx_plan::TaskSet &ts = spin ? pl->ts[4] : pl->ts[5];
+    HX_TRY(build_task_set(pl, spin, valu_task_blocks(spin), ts));
+    if (pl->hsrc == nullptr) {
+        HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
+        HX_TRY(launch_ring_subdft_maps(pl, nb, d_maps, d_pw, pl->Y.as<double2>()));
+    }
+    double budget = 80e9;
+    if (scratch_budget_bytes() > 0.0) budget = scratch_budget_bytes();
+    else {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min(budget, 0.5 * (double)(fr + pl->F.bytes + pl->partial.bytes));
+        budget = std::max(budget, 2e9);
+    }
+    const int lmax = pl->lmax, pcol = valu_partial_cols(spin), unit = spin ? 2 : 1;
+    const double f_per_m = (double)pl->nrp_pad * valu_operand_doubles(spin) * sizeof(double);
+    const std::vector<long long> &prow = ts.rows_before_m;
+    std::vector<std::pair<int, int>> chunks;
+    size_t maxF = 16, maxP = 16;
+    for (int m0 = 0; m0 <= lmax;) {
+        int m1 = m0 + 1;
+        while (m1 <= lmax) {
+            const double bytes = f_per_m * (m1 + 1 - m0) + (double)(prow[m1 + 1] - prow[m0]) * pcol * sizeof(double);
+            if (bytes > budget) break;
+            ++m1;
+        }
+        chunks.emplace_back(m0, m1);
+        maxF = std::max(maxF, (size_t)(f_per_m * (m1 - m0)));
+        maxP = std::max(maxP, (size_t)(prow[m1] - prow[m0]) * pcol * sizeof(double));
+        m0 = m1;
+    }
+    HX_TRY(pl->F.alloc(maxF));
+    HX_TRY(pl->partial.alloc(maxP));
+    pl->last_chunks = (int)chunks.size();
+    PlanDev P = pl->dev();
+    for (int c0 = 0; c0 < nb; c0 += unit)
+        for (auto &ch : chunks) {
+            const int m0 = ch.first, m1 = ch.second;
+            HX_TRY(launch_valu_chunk(pl, spin, ts, m0, m1, c0, d_rw));
+            ProfScope ps("alm_reduce");
+            if (spin == 0)
+                hipLaunchKernelGGL(k_alm_reduce<0>, dim3(m1 - m0), dim3(256), 0, rt().stream, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
+                                   pl->partial.as<double>(), ts.rows_before_m[m0], m0, 1, 1, pcol, d_fl, add, d_alms + (size_t)c0 * pl->nlm, pl->nlm, nullptr);
+            else
+                hipLaunchKernelGGL(k_alm_reduce<2>, dim3(m1 - m0), dim3(256), 0, rt().stream, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
+                                   pl->partial.as<double>(), ts.rows_before_m[m0], m0, 2, 1, pcol, d_fl, add, d_alms + (size_t)c0 * pl->nlm, pl->nlm, nullptr);
+            HX_HIP(hipGetLastError());
+        }
+    return HX_OK;
+}
+
 // One analysis pass over a batch of <= 8*NGMAX components (device pointers).  F and the
 // partial sums are produced per m-chunk so that their footprint stays within a budget
 // (HX_SCRATCH_GB, default min(80 GB, half the free HBM)); Y (ring spectra of the batch) persists across chunks.
 int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 *d_alms, const double *d_rw,
                    const double *d_pw, const double *d_fl, int add)
 {
+    if (valu_batch(spin, nb)) return analysis_batch_valu(pl, spin, nb, d_maps, d_alms, d_rw, d_pw, d_fl, add);
     const int sidx = spin ? 1 : 0, nop = spin ? 2 : 1;
     HX_TRY(build_tasks(pl, spin));
     if (spin) HX_TRY(ensure_rec2(pl));
@@ -1735,6 +1767,27 @@ extern "C" int hx_plan_mfma_flops(hx_plan *pl, int spin, int ncomp, double *flop
         per_wave_block += 16.0 * nop * (sh.ng * 2048.0 + (sh.nbx + sh.quad) * 512.0);
     }
     *flops = wave_blocks * per_wave_block;
+    return HX_OK;
+}
+
+// FP64 flops the Legendre analysis kernels EXECUTED since the last reset, counted by the kernels themselves: out2[0] matrix
+// instructions (stages that skip theirs because every ring of the set is still below 2^-300 are not counted), out2[1] vector
+// unit (recursions of the pipelined kernels, everything of the single-map kernels).  Synchronises the library stream.
+extern "C" int hx_executed_flops(double *out2, int reset)
+{
+    using namespace hx;
+    if (!out2) return fail(HX_ERR_ARG, "hx_executed_flops: null output");
+    HX_TRY(ensure_ready());
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    unsigned long long v[2] = {0, 0}, w = 0;
+    HX_HIP(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_exec_flops), sizeof(v)));
+    HX_TRY(valu_exec_flops(&w, reset != 0));
+    if (reset) {
+        const unsigned long long z[2] = {0, 0};
+        HX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_exec_flops), z, sizeof(z)));
+    }
+    out2[0] = (double)v[0];
+    out2[1] = (double)v[1] + (double)w;
     return HX_OK;
 }
 

@@ -101,6 +101,7 @@ struct OutView {
 // Host <-> device copies on the library stream; large pageable host buffers are staged through
 // pinned memory by several host threads.  copy_d2h is complete on return, copy_h2d is stream-ordered.
 int copy_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t on = nullptr);  // on: another stream than the library's
+void stager_reset_events();  // hx_init on another device: recreate the staging events there
 hipStream_t copy_stream();  // second stream of the library (uploads that overlap its kernels); nullptr if it cannot be created
 int copy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 

@@ -400,3 +400,66 @@ extern "C" int hx_ud_grade(int nside_in, int nside_out, int nmaps, const double 
     HX_TRY(vout.finish());
     return finish_call();
 }
+
+// =====================================================================================
+// healpy pixel weights: compressed octant -> full-sky array (heracles/healpy.py:183-189, use_pixel_weights=True)
+// =====================================================================================
+// healpy's `healpix_full_weights_nside_NNNN.fits` holds (nside + 1)(3 nside + 1) / 4 values: for every ring of the northern
+// hemisphere (equator included) the weights of the pixels of half a quadrant -- the quadrature weights have the 8-fold symmetry
+// of the pixelisation (4 quadrants x mirror inside a quadrant) plus north/south.  The expansion is the published algorithm of
+// healpix_cxx's apply_fullweights (third-party, not in /root/reference; restated):  ring i < 2 nside has q = min(nside, i + 1)
+// pixels per quadrant; it is "shifted" (pixel centres off the quadrant boundary) for i < nside - 1 or i + nside odd; it stores
+// w = (q + 1) / 2 values, + 1 if q is even and the ring is not shifted; pixel j of the ring uses value min(j4, q - shifted - j4),
+// j4 = j mod q; the map value is multiplied by 1 + value.  One work-group per ring pair.
+namespace hx {
+__global__ __launch_bounds__(256) void k_expand_pixel_weights(int nside, const long long *__restrict__ voff, const double *__restrict__ wgt,
+                                                              double *__restrict__ out)
+{
+    const int i = blockIdx.x;  // ring of the northern hemisphere, 0 = the ring next to the pole
+    const long long ns = nside, npix = 12 * ns * ns;
+    const int q = i + 1 < nside ? i + 1 : nside;
+    const bool shifted = (i < nside - 1) || ((i + nside) & 1);
+    const long long pix = i < nside ? 2ll * i * (i + 1) : 2 * ns * (ns - 1) + (long long)(i - nside + 1) * 4 * ns;  // first pixel of the ring
+    const long long psouth = npix - pix - 4ll * q;
+    const double *w = wgt + voff[i];
+    for (int j = threadIdx.x; j < 4 * q; j += blockDim.x) {
+        const int j4 = j % q, mir = q - (shifted ? 1 : 0) - j4;
+        const double v = 1.0 + w[j4 < mir ? j4 : mir];
+        out[pix + j] = v;
+        if (i != 2 * nside - 1) out[psouth + j] = v;
+    }
+}
+}  // namespace hx
+
+extern "C" int64_t hx_pixel_weights_size(int nside) { return nside < 1 ? 0 : ((int64_t)(nside + 1) * (3 * (int64_t)nside + 1)) / 4; }
+
+extern "C" int hx_pixel_weights_expand(int nside, int64_t ncompressed, const double *compressed, double *weights)
+{
+    HX_TRY(ensure_ready());
+    if (nside < 1 || nside > 8192 || !compressed || !weights) return fail(HX_ERR_ARG, "hx_pixel_weights_expand: bad arguments");
+    if (ncompressed != hx_pixel_weights_size(nside))
+        return fail(HX_ERR_ARG, "hx_pixel_weights_expand: %lld compressed weights, NSIDE=%d needs %lld", (long long)ncompressed, nside,
+                    (long long)hx_pixel_weights_size(nside));
+    std::vector<long long> voff(2 * nside);
+    long long v = 0;
+    for (int i = 0; i < 2 * nside; ++i) {
+        voff[i] = v;
+        const int q = std::min(nside, i + 1);
+        const bool shifted = (i < nside - 1) || ((i + nside) & 1);
+        v += ((q + 1) >> 1) + (((q & 1) || shifted) ? 0 : 1);
+    }
+    if (v != ncompressed) return fail(HX_ERR_ARG, "hx_pixel_weights_expand: internal size mismatch");
+    DevBuf d_off;
+    HX_TRY(d_off.alloc(sizeof(long long) * voff.size()));
+    HX_HIP(hipMemcpy(d_off.p, voff.data(), sizeof(long long) * voff.size(), hipMemcpyHostToDevice));
+    InView vin;
+    OutView vout;
+    HX_TRY(vin.bind(compressed, sizeof(double) * ncompressed));
+    HX_TRY(vout.bind(weights, sizeof(double) * 12ll * nside * nside));
+    hipLaunchKernelGGL(hx::k_expand_pixel_weights, dim3(2 * nside), dim3(256), 0, rt().stream, nside, d_off.as<long long>(), vin.as<double>(),
+                       vout.as<double>());
+    HX_HIP(hipGetLastError());
+    HX_TRY(vout.finish());
+    HX_HIP(hipStreamSynchronize(rt().stream));  // d_off dies with this scope
+    return HX_OK;
+}

@@ -69,6 +69,8 @@ __global__ void k_wigner_table(int lmax, int a, int b, int n, const double *__re
     if (a == 0 && b == 0) d0 = 1.0;
     else if (a == 2 && b == 0) d0 = 0.61237243569579452455 * (1.0 - xx) * (1.0 + xx);
     else if (a == 2 && b == 2) d0 = 0.25 * (1.0 + xx) * (1.0 + xx);
+    else if (a == 1 && b == 1) d0 = 0.5 * (1.0 + xx);                    // d^1_{11}   (transforms.py:68-73)
+    else if (a * b == -1) d0 = 0.5 * (1.0 - xx);                         // d^1_{-1,1} = d^1_{1,-1}
     else d0 = 0.25 * (1.0 - xx) * (1.0 - xx);  // (2,-2)
     for (int l = 0; l < l0 && l <= lmax; ++l) out[l * sl + k * sk] = 0.0;
     if (l0 > lmax) return;
@@ -362,7 +364,7 @@ extern "C" int hx_wigner_d_table(int lmax, int a, int b, int n, const double *x,
 {
     HX_TRY(ensure_ready());
     if (lmax < 0 || n < 1 || !x || !out) return fail(HX_ERR_ARG, "hx_wigner_d_table: bad argument");
-    if (!((a == 0 && b == 0) || (a == 2 && b == 0) || (a == 2 && b == 2) || (a == 2 && b == -2)))
+    if (!((a == 0 && b == 0) || (a == 2 && b == 0) || (a == 2 && b == 2) || (a == 2 && b == -2) || (a == 1 && b == 1) || (a * b == -1)))
         return fail(HX_ERR_UNSUPPORTED, "hx_wigner_d_table: (a,b)=(%d,%d) not supported", a, b);
     InView vx;
     OutView vo;

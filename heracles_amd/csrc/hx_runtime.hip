@@ -1,6 +1,7 @@
 // hx_runtime.hip -- device selection, streams, timers, error state of libhxsht.so.
 #include "hx_common.h"
 
+#include <pthread.h>
 #include <sched.h>
 
 #include <algorithm>
@@ -236,9 +237,29 @@ struct Stager {
         if (nthreads > 1) {
             pool = new CopyPool;
             pool->start(nthreads, cpus);
+            static bool fork_handler = false;
+            if (!fork_handler) {
+                fork_handler = true;
+                (void)pthread_atfork(nullptr, nullptr, forget_pool_in_child);
+            }
         }
         ok = true;
         return true;
+    }
+    static void forget_pool_in_child();
+    // hx_init on another device: the events belong to the old device's context
+    void reset_events()
+    {
+        for (int i = 0; i < 2; ++i)
+            if (ev[i]) {
+                (void)hipEventDestroy(ev[i]);
+                ev[i] = nullptr;
+                if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ev[i] = nullptr;
+                    ok = false;
+                }
+            }
     }
 };
 Stager &stager()
@@ -246,6 +267,10 @@ Stager &stager()
     static Stager s;
     return s;
 }
+// A forked child has none of the detached copy workers: pool->copy would wait for them forever.  The child falls back to a
+// plain memcpy into the pinned buffers (HIP itself does not survive fork() either; this only keeps a child that never touches
+// the GPU, or that re-initialises it, from hanging inside the stager).
+void Stager::forget_pool_in_child() { stager().pool = nullptr; }
 
 void parallel_memcpy(void *dst, const void *src, size_t n, int nthreads)
 {
@@ -269,6 +294,8 @@ bool is_pinned_host(const void *p)
 
 }  // namespace
 
+void stager_reset_events() { stager().reset_events(); }
+
 hipStream_t copy_stream()
 {
     Runtime &r = rt();
@@ -279,9 +306,15 @@ hipStream_t copy_stream()
     return r.copy;
 }
 
+// The two pinned buffers, their events and the copy pool's job fields are one shared set: staging is serialised process-wide
+// (ctypes releases the GIL, so two Python threads can be inside the library at once; everything else in the library is
+// single-threaded by contract, include/hxsht.h).
+static std::mutex g_stage_mu;
+
 int copy_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t on)
 {
     hipStream_t st = on ? on : rt().stream;
+    std::lock_guard<std::mutex> stage_lock(g_stage_mu);
     Stager &s = stager();
     if (bytes < STAGE_MIN || is_pinned_host(src_host) || !s.init()) {
         HX_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
@@ -301,6 +334,7 @@ int copy_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t on)
 int copy_d2h(void *dst_host, const void *src_dev, size_t bytes)
 {
     hipStream_t st = rt().stream;
+    std::lock_guard<std::mutex> stage_lock(g_stage_mu);
     Stager &s = stager();
     if (bytes < STAGE_MIN || is_pinned_host(dst_host) || !s.init()) {
         HX_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
@@ -412,6 +446,12 @@ int hx_init(int device)
                     prop.gcnArchName);
     if (r.ready && r.device == device) return HX_OK;
     if (r.own_stream && r.stream) (void)hipStreamDestroy(r.stream);
+    if (r.ready) {
+        // re-initialisation on another device: the second (copy) stream and the stager's events were created on the old one
+        if (r.copy) (void)hipStreamDestroy(r.copy);
+        r.copy = nullptr;
+        stager_reset_events();
+    }
     HX_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
     r.own_stream = true;
     if (!r.t0) HX_HIP(hipEventCreate(&r.t0));

@@ -126,6 +126,59 @@ __device__ inline void spin2_seeds(int m, double sth, double omx, double kfac2m,
 
 #ifdef __HIPCC__
 using namespace hxfft;
+// What a ring pair needs at one m, whatever the component: where Z[m] and Z[-m] sit in its spectrum (X[4k+r] = Y_r[k]) and
+// the phase x quadrature weight.  One thread per ring pair of the block computes it (integer divisions, one sincospi) and
+// hands it over through LDS: done per (ring pair, m, component slot) it was half of the kernel's time (3.7e9 vector
+// instructions per spin-2 sweep, profiles/r02_pmc_summary.md).
+struct RingAtM {
+    double2 ph;        // w e^{-i m phi_0} (w = 0 for padding ring pairs)
+    long long i0, i1;  // Z[m mod nphi], Z[-m mod nphi] relative to the component's spectrum
+    int hasS;
+};
+
+// F_N(m), F_S(m) of ring pair rp for component c, including phase and quadrature weight
+__device__ inline void ring_modes_ns(const PlanDev &P, const double2 *__restrict__ Y, int c, int rp, int m,
+                                     const RingAtM &r, double2 &FN, double2 &FS)
+{
+    if (P.hsrc) {
+        // equiangular rings theta_j = 2 pi (j + 1/2) / N of the point transform: the spectrum h_m is given on the full circle,
+        // lambda_lm(2 pi - theta) = (-1)^m lambda_lm(theta) (both spins) folds the second half onto the rings
+        const double w = r.ph.x;
+        const double2 *h = P.hsrc + (long long)c * P.hsrc_stride + (long long)m * P.hN;
+        const double sg = (m & 1) ? -w : w;
+        const double2 a = h[rp], b = h[P.hN - 1 - rp], cN = h[P.hN / 2 - 1 - rp], d = h[P.hN / 2 + rp];
+        FN = make_double2(w * a.x + sg * b.x, w * a.y + sg * b.y);
+        FS = make_double2(w * cN.x + sg * d.x, w * cN.y + sg * d.y);
+        return;
+    }
+    const double2 *Yc = Y + (long long)c * P.ny;
+    const double2 a = Yc[r.i0], b = cconj(Yc[r.i1]);
+    const double2 xn = cscale(cadd(a, b), 0.5);
+    const double2 xs = mul_mi(cscale(csub(a, b), 0.5));  // (a-b)/(2i)
+    FN = cmul(xn, r.ph);
+    FS = r.hasS ? cmul(xs, r.ph) : make_double2(0.0, 0.0);
+}
+
+// RingAtM of ring pair r (pole -> equator) at order m; rw = ring quadrature weights or null (unit weights)
+__device__ inline RingAtM ring_at_m_of(const PlanDev &P, int r, int m, const double *__restrict__ rw)
+{
+    RingAtM q;
+    const bool live = r < P.nrp;
+    const double w = live ? (rw ? rw[r] : 1.0) * P.wnorm : 0.0;
+    q.ph = make_double2(w, 0.0);
+    q.i0 = q.i1 = 0;
+    q.hasS = 0;
+    if (live && !P.hsrc) {
+        const int n = P.nsub[r], nphi = 4 * n;
+        const int mm = m % nphi, mc = (nphi - mm) % nphi;
+        q.i0 = P.startN[r] + (long long)(mm & 3) * n + (mm >> 2);  // Z[mm], X[4k+r] = Y_r[k]
+        q.i1 = P.startN[r] + (long long)(mc & 3) * n + (mc >> 2);
+        if (P.shifted[r]) q.ph = cscale(expipi(-(double)(m % (2 * nphi)) / (double)nphi), w);
+        q.hasS = P.startS[r] >= 0;
+    }
+    return q;
+}
+
 // In-LDS FFT drivers on the padded buffer of hx_fft_core.h (element e in slot lds_slot(e)): fused radix-2^K passes, K <= 4,
 // schedule fft_sched_k(log2 M, pass) (tests/csrc/test_fft_core.cpp runs this exact schedule on the host).  Thread gt of the gn threads
 // that share one transform; EVERY thread of the block must call (one __syncthreads per pass), all with the same M.
@@ -239,7 +292,8 @@ struct hx_plan {
         std::vector<long long> rows_before_m; // partial rows of all tasks with smaller m (size lmax+2)
         std::vector<long long> arow;          // the same with ONE span of rows per m (pipelined kernel: ring groups summed in place)
         hx::DevBuf d_tasks, d_of_m, d_arow;
-    } ts[4];  // spin 0, spin 2, spin 0 with half-size work-groups, spin 2 with one ring set per wave (4 ring blocks per task)
+    } ts[6];  // spin 0, spin 2, spin 0 with half-size work-groups, spin 2 with one ring set per wave (4 ring blocks per task),
+       // spin 2 / spin 0 on the vector unit (hx_legendre_valu.hip: 2 R ring blocks per task)
     struct FftClass { int M, first, count, big; };
     std::vector<FftClass> fft_classes;   // ring pairs grouped by in-LDS FFT length
     hx::DevBuf fft_rp_list;
@@ -261,4 +315,10 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
 int analysis_max_comp(int spin);
 int analysis_next_batch(int spin, int remaining, bool from_host = false);
 int legendre_synthesis(hx_plan *pl, int spin, int nb, const double2 *d_alms, double *d_Fsyn);
+// hx_legendre_valu.hip: one map (spin 0) / one field (spin 2) per sweep on the FP64 vector unit
+int launch_valu_chunk(hx_plan *pl, int spin, hx_plan::TaskSet &ts, int m0, int m1, int c0, const double *d_rw);
+int valu_task_blocks(int spin);      // 32-ring-pair blocks per task
+int valu_partial_cols(int spin);     // doubles per row of the partial buffer
+int valu_operand_doubles(int spin);  // doubles per (m, ring pair) of the operand array
+int valu_exec_flops(unsigned long long *v, bool reset);  // FP64 vector flops executed by the vector-unit kernels since the last reset
 }  // namespace hx

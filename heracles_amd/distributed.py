@@ -141,6 +141,12 @@ class ShardedTwoPoint:
         import torch.distributed as dist
 
         buf = self.buffer()
+        if buf.is_cuda:
+            # the transforms ran on libhxsht's own stream (possibly asynchronously, hx_set_async): they must have written
+            # this rank's slice before the collective reads it
+            from . import _lib
+
+            _lib.synchronize()
         flat = torch.view_as_real(buf)  # complex dtypes are gathered through their real view (same bytes)
         mine = flat[self.rank * self.ncomp_max : (self.rank + 1) * self.ncomp_max]
         if dist.get_backend(self.group) == "gloo":

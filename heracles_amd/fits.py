@@ -164,14 +164,31 @@ def _meta_cards(md):
 
 
 def _columns(h):
-    """[(name, repeat)] of a table whose columns are all 8-byte floats ('rD')."""
+    """[(name, repeat)] of a table whose columns are all floats of one width: 'rD' (8 bytes) or 'rE' (4 bytes, what healpy's
+    write_map produces for masks and visibility maps by default).  The width is returned by _column_width."""
     cols = []
     for i in range(1, h["TFIELDS"] + 1):
-        m = re.fullmatch(r"(\d*)D", str(h[f"TFORM{i}"]).strip())
+        m = re.fullmatch(r"(\d*)([DE])", str(h[f"TFORM{i}"]).strip())
         if not m:
-            raise NotImplementedError(f"column {i} has TFORM {h[f'TFORM{i}']!r}: only float64 ('D') columns are supported")
+            raise NotImplementedError(f"column {i} has TFORM {h[f'TFORM{i}']!r}: only float64 ('D') and float32 ('E') columns are supported")
         cols.append((str(h.get(f"TTYPE{i}", f"COL{i}")).strip(), int(m.group(1) or 1)))
     return cols
+
+
+def _column_width(h):
+    kinds = {re.fullmatch(r"(\d*)([DE])", str(h[f"TFORM{i}"]).strip()).group(2) for i in range(1, h["TFIELDS"] + 1)}
+    if len(kinds) != 1:
+        raise NotImplementedError("columns of mixed float widths")
+    return 8 if kinds == {"D"} else 4
+
+
+def _tdim(h, i):
+    """Leading dimensions (C order) of vector column i from its TDIMi card '(d_fast,...,d_slow)', or None."""
+    t = h.get(f"TDIM{i}")
+    if t is None:
+        return None
+    dims = [int(x) for x in str(t).strip().strip("()").split(",") if x.strip()]
+    return tuple(reversed(dims))
 
 
 def _new_file(path, clobber):
@@ -181,8 +198,10 @@ def _new_file(path, clobber):
                                    _card("NAXIS", 0, "number of data axes"), _card("EXTEND", True, "FITS dataset may contain extensions")]))
 
 
-def _append_table(path, ext, names, repeat, nrows, payload, extra_cards, md):
-    """One BINTABLE extension of len(names) columns 'repeat D' with the given big-endian row-major payload."""
+def _append_table(path, ext, names, repeat, nrows, payload, extra_cards, md, lead=None):
+    """One BINTABLE extension of len(names) columns 'repeat D' with the given big-endian row-major payload; lead: the
+    leading dimensions (C order) a row's vector stands for -- written as TDIM in FITS (fastest-first) order, as fitsio does
+    for the moveaxis layout of heracles/io.py:189-200."""
     nb = 8 * repeat * len(names)
     cards = [_card("XTENSION", "BINTABLE", "binary table extension"), _card("BITPIX", 8, "8-bit bytes"), _card("NAXIS", 2, "2-dimensional binary table"),
              _card("NAXIS1", nb, "width of table in bytes"), _card("NAXIS2", nrows, "number of rows in table"),
@@ -192,7 +211,8 @@ def _append_table(path, ext, names, repeat, nrows, payload, extra_cards, md):
         cards.append(_card(f"TTYPE{i}", name, f"label for field {i:3d}"))
         cards.append(_card(f"TFORM{i}", "D" if repeat == 1 else f"{repeat}D", "data format of field: 8-byte DOUBLE"))
         if repeat > 1:
-            cards.append(_card(f"TDIM{i}", f"({repeat})", "dimensions of field"))
+            dims = tuple(lead) if lead else (repeat,)
+            cards.append(_card(f"TDIM{i}", "(" + ",".join(str(d) for d in reversed(dims)) + ")", "dimensions of field"))
     cards.append(_card("EXTNAME", ext, "name of this binary table extension"))
     cards += extra_cards + _meta_cards(md)
     with open(path, "ab") as f:
@@ -210,8 +230,12 @@ def _to_table(array, nrows, nc1, nc2, s1, s2, srow):
     return table
 
 
-def _from_table(path, off, nrows, nc1, nc2, s1, s2, srow, out):
-    raw = np.fromfile(path, dtype=np.float64, count=nrows * nc1 * nc2, offset=off)  # bytes as they are in the file
+def _from_table(path, off, nrows, nc1, nc2, s1, s2, srow, out, width=8):
+    if width == 4:
+        # float32 columns: widened on the host, then the same device pass as float64 tables (the kernel swaps 8-byte words)
+        raw = np.fromfile(path, dtype=">f4", count=nrows * nc1 * nc2, offset=off).astype(">f8").view(np.float64)
+    else:
+        raw = np.fromfile(path, dtype=np.float64, count=nrows * nc1 * nc2, offset=off)  # bytes as they are in the file
     _lib.ensure_init()
     _lib.check(_lib.load().hx_fits_unpack_f64(nrows, nc1, nc2, s1, s2, srow, _lib.ptr(raw), _lib.ptr(out)))
     return out
@@ -269,7 +293,7 @@ def _read_map(path, h, off, device=None):
     nrows, ncols = h["NAXIS2"], len(cols)
     npix = nrows * rep
     out = _empty((ncols, npix) if ncols > 1 else (npix,), False, device)
-    _from_table(path, off, nrows, ncols, rep, npix, 1, rep, out)
+    _from_table(path, off, nrows, ncols, rep, npix, 1, rep, out, _column_width(h))
     return _with_metadata(out, _metadata(h), device)
 
 
@@ -281,7 +305,7 @@ def _write_complex(path, ext, a):
     for d in arr.shape[:-1]:
         rep *= d
     payload = _to_table(arr, n, 2, rep, 1, 2 * n, 2)
-    _append_table(path, ext, ["real", "imag"], rep, n, payload, [], md)
+    _append_table(path, ext, ["real", "imag"], rep, n, payload, [], md, lead=tuple(arr.shape[:-1]))
 
 
 def _read_complex(path, h, off, device=None):
@@ -289,8 +313,13 @@ def _read_complex(path, h, off, device=None):
     if "real" not in cols or "imag" not in cols or list(cols)[:2] != ["real", "imag"] or cols["real"] != cols["imag"]:
         raise NotImplementedError("expected the columns 'real', 'imag' of equal shape")
     rep, n = cols["real"], h["NAXIS2"]
+    if _column_width(h) != 8:
+        raise NotImplementedError("complex arrays are stored as float64 columns (heracles/io.py:189-200)")
     out = _empty((rep, n) if rep > 1 else (n,), True, device)
     _from_table(path, off, n, 2, rep, 1, 2 * n, 2, out)
+    lead = _tdim(h, 1)
+    if lead is not None and len(lead) > 1 and int(np.prod(lead)) == rep:
+        out = out.reshape(*lead, n)  # the moveaxis(0, -1) layout of io.py:203-218
     return _with_metadata(out, _metadata(h), device)
 
 

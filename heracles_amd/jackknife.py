@@ -104,24 +104,44 @@ def region_alms(fields, maps, jk_map, *, device="cuda"):
     out = torch.empty((njk + 1, ncomp, nlm), dtype=torch.complex128, device=device)
     region = torch.as_tensor(np.ascontiguousarray(jk_map, dtype=np.float64)).to(device)
     L = _lib.load()
-    for spin in (0, 2):
-        ks = by_spin[spin]
-        if not ks:
-            continue
+
+    def settings(k):
+        """What a mapper contributes to the transform besides (nside, lmax): the fields of one batched call must agree on all
+        of it -- the reference transforms every field with its OWN mapper (dices/jackknife.py:143-148 via mapping.transform)."""
+        mp = mappers[k]
+        pw = getattr(mp, "pixwin", None)
+        return (fields[k[0]].spin, bool(mp.deconvolve), id(pw) if pw is not None else None, id(mp.ring_weights) if mp.ring_weights is not None else None,
+                id(mp.pixel_weights) if mp.pixel_weights is not None else None, int(mp.niter))
+
+    groups = {}
+    for k in order:
+        groups.setdefault(settings(k), []).append(k)
+    for sett, ks in groups.items():
+        spin = sett[0]
         mp = mappers[ks[0]]
         fl = mp._fl(spin)
         stack = np.concatenate([np.ascontiguousarray(np.asarray(maps[k], dtype=np.float64)).reshape(-1, npix) for k in ks])
         dmaps = torch.as_tensor(stack).to(device)
         scratch = torch.empty_like(dmaps)
+        # the keys of a group need not be adjacent in `order`: transform into a work tensor, scatter per key
+        contiguous = all(comps[ks[i + 1]].start == comps[ks[i]].stop for i in range(len(ks) - 1))
+        work = None if contiguous else torch.empty((dmaps.shape[0], nlm), dtype=torch.complex128, device=device)
         c0 = comps[ks[0]].start
         for k in range(njk + 1):
             src = dmaps
             if k > 0:
                 _lib.check(L.hx_region_maps(npix, dmaps.shape[0], _lib.ptr(dmaps), _lib.ptr(region), float(k), _lib.ptr(scratch)))
                 src = scratch
-            plan.map2alm(src, spin, ring_weights=mp.ring_weights, pix_weights=mp.pixel_weights, fl=fl, niter=mp.niter,
-                         out=out[k, c0 : c0 + dmaps.shape[0]])
-        del dmaps, scratch
+            dst = out[k, c0 : c0 + dmaps.shape[0]] if contiguous else work
+            plan.map2alm(src, spin, ring_weights=mp.ring_weights, pix_weights=mp.pixel_weights, fl=fl, niter=mp.niter, out=dst)
+            if not contiguous:
+                _lib.synchronize()
+                r = 0
+                for kk in ks:
+                    n = comps[kk].stop - comps[kk].start
+                    out[k, comps[kk]] = work[r : r + n]
+                    r += n
+        del dmaps, scratch, work
     return RegionAlms(order, meta, comps, out)
 
 

@@ -180,11 +180,13 @@ def ud_grade(data, nside_out, dtype=np.float64):
 class HipHealpixMapper:
     """Mapper for HEALPix maps whose ``transform`` runs on MI355X."""
 
-    #: kept for interface compatibility with HealpixMapper.DATAPATH (heracles/healpy.py:73)
+    #: directory of healpy's pixel-weight files, as HealpixMapper.DATAPATH (heracles/healpy.py:73; set from the configuration
+    #: at heracles/cli.py:536-538): ``<DATAPATH>/full_weights/healpix_full_weights_nside_NNNN.fits`` is read on the first
+    #: transform, expanded to the full sky on the GPU and kept in HBM (heracles_amd/weights.py)
     DATAPATH = None
 
     def __init__(self, nside, lmax=None, *, deconvolve=None, dtype=np.float64, niter=3,
-                 pixwin=None, pixel_weights=None, ring_weights=None):
+                 pixwin=None, pixel_weights=None, ring_weights=None, datapath=None):
         if lmax is None:
             lmax = 3 * nside // 2
         if deconvolve is None:
@@ -198,6 +200,7 @@ class HipHealpixMapper:
         self.pixwin = pixwin
         self.pixel_weights = pixel_weights
         self.ring_weights = ring_weights
+        self.datapath = datapath
 
     @property
     def nside(self):
@@ -236,12 +239,23 @@ class HipHealpixMapper:
         fl[abs(spin):] /= pw[abs(spin):]
         return fl
 
+    def _load_weights(self):
+        """use_pixel_weights=True, datapath=DATAPATH of heracles/healpy.py:183-189: the weight file of this resolution, if a
+        data path is configured and holds one."""
+        if self.pixel_weights is None and self.ring_weights is None:
+            path = self.datapath if self.datapath is not None else type(self).DATAPATH
+            if path is not None:
+                from .weights import load_pixel_weights
+
+                self.pixel_weights = load_pixel_weights(path, self.__nside)
+
     def transform(self, data, spin=0):
         """Spherical harmonic transform of HEALPix maps; heracles/healpy.py:162-203."""
         if spin not in (0, 2):
             raise NotImplementedError(f"spin-{spin} maps not yet supported")
         fl = self._fl(spin)
         plan = sht.get_plan(self.__nside, self.__lmax)
+        self._load_weights()
         if self.pixel_weights is None and self.ring_weights is None:
             _warn_unit_weights()
         if hasattr(data, "data_ptr"):
@@ -271,6 +285,7 @@ class HipHealpixMapper:
             stack = np.stack([np.ascontiguousarray(_native(maps[i]), dtype=np.float64) for i in idx])
             fl = self._fl(s)
             plan = sht.get_plan(self.__nside, self.__lmax)
+            self._load_weights()
             alms = plan.map2alm(stack.reshape(-1, stack.shape[-1]), s, ring_weights=self.ring_weights,
                                 pix_weights=self.pixel_weights, fl=fl, niter=self.niter)
             alms = alms.reshape(*stack.shape[:-1], -1)

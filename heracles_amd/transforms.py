@@ -38,6 +38,28 @@ def wigner_d_table(lmax, a, b, x):
     return out
 
 
+def legendre_funcs(lmax, x, m=(0, 2), lfacs=None, lfacs2=None, lrootfacs=None):
+    """``heracles.transforms.legendre_funcs`` (heracles/transforms.py:46-112) for a scalar ``x``: the list
+    ``[(P, P'), (d11, dm11), (d20, d22, d2m2)]`` restricted to the requested ``m``; P starts at l = 0, the spin-1 arrays at
+    l = 1, the spin-2 arrays at l = 2.  The values come from the Wigner-d tables of the mixing-matrix kernels (three-term
+    recursions in l, stable also where the reference switches to its small-angle series); ``lfacs*`` are accepted and ignored."""
+    xs = np.array([float(x)])
+    res = []
+    if 0 in m:
+        P = wigner_d_table(lmax, 0, 0, xs)[0]
+        dP = np.zeros(lmax + 1)
+        # P'_l = P'_{l-2} + (2l - 1) P_{l-1}
+        inc = (2.0 * np.arange(1, lmax + 1) - 1.0) * P[:-1]
+        dP[1::2] = np.cumsum(inc[0::2])
+        dP[2::2] = np.cumsum(inc[1::2])
+        res.append((P, dP))
+    if 1 in m:
+        res.append((wigner_d_table(lmax, 1, 1, xs)[0, 1:], wigner_d_table(lmax, -1, 1, xs)[0, 1:]))
+    if 2 in m:
+        res.append((wigner_d_table(lmax, 2, 0, xs)[0, 2:], wigner_d_table(lmax, 2, 2, xs)[0, 2:], wigner_d_table(lmax, 2, -2, xs)[0, 2:]))
+    return res
+
+
 def _as4(arr):
     arr = np.asarray(arr, dtype=np.float64)
     if arr.ndim == 1:

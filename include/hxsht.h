@@ -17,6 +17,9 @@
  *  - Calls are synchronous on return unless hx_set_async(1) was called.
  *  - There is NO CPU fallback: every compute entry point fails with HX_ERR_NO_DEVICE when
  *    no gfx950 device is usable.
+ *  - Threading: one host thread per process drives the library (one process per GPU).  Only hx_last_error() is
+ *    thread local and only the host <-> device staging is serialised internally; plans, the runtime and the profile are not
+ *    thread safe.  The library does not survive fork() (HIP does not): a child must not call into it.
  */
 #ifndef HXSHT_H
 #define HXSHT_H
@@ -47,9 +50,10 @@ int hx_synchronize(void);
 /* HIP-event timers on the library stream (bench.py's timed region / roofline). */
 int hx_timer_start(void);
 int hx_timer_stop(float *ms);
-/* per-kernel profile: accumulate HIP-event durations of every launch of the named kernel
- * family ("legendre_analysis", "legendre_synthesis", "ring_fft", "alm2cl", "mixmat_gemm",
- * "wigner_tables").  hx_profile_get returns launches and total milliseconds. */
+/* per-kernel profile: accumulate HIP-event durations of every launch of the named kernel family:
+ * "ring_fft", "fourier_combine", "legendre_analysis" (all analysis kernels; also split into "legendre_analysis_s0" /
+ * "legendre_analysis_s2" by spin and "legendre_valu" for the single-map vector-unit kernel), "alm_reduce", "legendre_synthesis",
+ * "alm2cl", "mixmat_gemm", "wigner_tables".  hx_profile_get returns launches and total milliseconds. */
 int hx_profile_enable(int on);
 int hx_profile_reset(void);
 int hx_profile_get(const char *name, int *launches, double *total_ms);
@@ -81,6 +85,11 @@ double hx_measured_mfma_clock(void);
 int hx_plan_mfma_flops(hx_plan *plan, int spin, int ncomp, double *flops);
 /* out2[0] = the same, out2[1] = FP64 vector flops of the recursions (4 per value of lambda_lm(theta) generated). */
 int hx_plan_executed_flops(hx_plan *plan, int spin, int ncomp, double *out2);
+/* What the Legendre analysis kernels of this process EXECUTED since the last reset, counted by the kernels themselves (one
+ * atomic per wave): out2[0] = FP64 flops of the matrix instructions issued (stages whose rings are all still below 2^-300 issue
+ * none -- the task-list figure above counts them), out2[1] = FP64 flops on the vector unit.  reset != 0 zeroes the counters.
+ * bench.py's roofline.achieved is these / the kernels' HIP-event time; it agrees with the SQ_INSTS_VALU_MFMA_F64 counter. */
+int hx_executed_flops(double *out2, int reset);
 
 /* maps  : [ncomp][npix] double; spin 2: components come in (Q,U) pairs, ncomp even
  * alms  : [ncomp][nlm] complex; spin 2: (E,B) pairs
@@ -106,8 +115,8 @@ int hx_alm2cl_pairs(int ncomp, const int *lmax_i, const double *const *alms, int
  * heracles/transforms.py:25-43. */
 int hx_gauss_legendre(int n, double *x, double *w);
 
-/* D[k][l] = d^l_{ab}(x_k), l = 0..lmax, (a,b) in {(0,0),(2,0),(2,2),(2,-2)};
- * out is [n][lmax+1] row-major.  (Functions of heracles/transforms.py:46-112.)       */
+/* D[k][l] = d^l_{ab}(x_k), l = 0..lmax, (a,b) in {(0,0),(2,0),(2,2),(2,-2),(1,1),(-1,1)} (zero below max(|a|,|b|));
+ * out is [n][lmax+1] row-major.  (Functions of heracles/transforms.py:46-112: P_l, d20, d22, d2m2, d11, dm11.)       */
 int hx_wigner_d_table(int lmax, int a, int b, int n, const double *x, double *out);
 
 /* Replaces convolvecl.mixmat / mixmat_eb as called at heracles/twopoint.py:378-388.
@@ -131,17 +140,17 @@ int hx_fits_pack_f64(int64_t nrows, int nc1, int nc2, int64_t s1, int64_t s2, in
 int hx_region_maps(int64_t npix, int ncomp, const double *maps, const double *region, double k, double *out);
 int hx_alm_subtract(int64_t n, const double *full, int nsub, const double *const *subs, double *out);
 
-/* The loop of heracles/twopoint.py:354-397 (one convolvecl call per mask pair and spin combination) as one call:
- * Gauss-Legendre nodes, Wigner-d tables and the GEMM tile list are built ONCE per (l1max, l2max, l3max); every mask then
- * costs its node weights and one GEMM per product.
- *   cls   [nmask][ncl] mask spectra; kinds [nmask] bit mask: 1 -> spin (0,0) into out00[k]; 2 -> spin (0,2)/(2,0) into
- *   out02[k]; 4 -> spin (2,2) into outeb[k] (3 matrices as hx_mixmat_eb).  Output pointers host or device. */
-/* The same as an object, for jobs whose matrices do not fit in memory together: create once, stream masks through.
+/* The loop of heracles/twopoint.py:354-397 (one convolvecl call per mask pair and spin combination) as an object:
+ * Gauss-Legendre nodes, Wigner-d tables and the GEMM tile list are built ONCE per (l1max, l2max, l3max); every mask streamed
+ * through then costs its node weights and one GEMM per product (for jobs whose matrices do not fit in memory together).
  * kind 1: spin (0,0), 2: spin (0,2)/(2,0) -> out (l1max+1, l2max+1); 4: spin (2,2) -> out (3, l1max+1, l2max+1). */
 typedef struct hx_mixctx hx_mixctx;
 hx_mixctx *hx_mixctx_create(int l1max, int l2max, int l3max);
 int hx_mixctx_apply(hx_mixctx *ctx, const double *cl, int ncl, int kind, double *out);
 void hx_mixctx_destroy(hx_mixctx *ctx);
+/* The same loop as ONE call over a list of masks:
+ *   cls   [nmask][ncl] mask spectra; kinds [nmask] bit mask: 1 -> spin (0,0) into out00[k]; 2 -> spin (0,2)/(2,0) into
+ *   out02[k]; 4 -> spin (2,2) into outeb[k] (3 matrices as hx_mixmat_eb).  Output pointers host or device. */
 int hx_mixmat_batch(int nmask, const double *cls, int ncl, int l1max, int l2max, int l3max, const int *kinds,
                     double *const *out00, double *const *out02, double *const *outeb);
 
@@ -189,6 +198,13 @@ int hx_map_values(int nside, int64_t n, const double *lon, const double *lat, in
  * children; upgrade = replication.  in: [nmaps][12 nside_in^2], out: [nmaps][12 nside_out^2].
  * Both nside must be powers of two (healpy raises ValueError otherwise; here HX_ERR_ARG).   */
 int hx_ud_grade(int nside_in, int nside_out, int nmaps, const double *in, double *out);
+
+/* healpy's pixel-weight files (`healpix_full_weights_nside_NNNN.fits`, the data hp.map2alm(use_pixel_weights=True, datapath=...)
+ * of heracles/healpy.py:183-189 reads): expansion of the compressed half-quadrant weights -- hx_pixel_weights_size(nside) =
+ * (nside + 1)(3 nside + 1) / 4 values -- to the full-sky array [12 nside^2] of multiplicative pixel weights 1 + w that hx_map2alm
+ * takes as `pix_weights`.  compressed / weights host or device.                                                           */
+int64_t hx_pixel_weights_size(int nside);
+int hx_pixel_weights_expand(int nside, int64_t ncompressed, const double *compressed, double *weights);
 
 #ifdef __cplusplus
 }

@@ -770,6 +770,8 @@ void hxo_wigner_d(int lmax, int a, int b, double x, double *out)
     else if (a == 2 && b == 0) d0 = sqrt(6.0) / 4.0 * (1.0 - x) * (1.0 + x);
     else if (a == 2 && b == 2) d0 = 0.25 * (1.0 + x) * (1.0 + x);
     else if (a == 2 && b == -2) d0 = 0.25 * (1.0 - x) * (1.0 - x);
+    else if (a == 1 && b == 1) d0 = 0.5 * (1.0 + x);
+    else if (a * b == -1) d0 = 0.5 * (1.0 - x);
     else { out[0] = NAN; return; }
     out[l0] = d0;
     double dp = 0.0, dc = d0;

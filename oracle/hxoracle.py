@@ -19,7 +19,10 @@ c_double_p = C.POINTER(C.c_double)
 
 
 def build(force: bool = False) -> str:
-    """Compile liboracle if needed (gcc only; no GPU involved)."""
+    """Compile liboracle if needed (gcc only; no GPU involved).  HXORACLE_LIB selects another build of the same source
+    (the AddressSanitizer / UBSan build of `make -C oracle asan`, tests/test_oracle_sanitizers.py)."""
+    if os.environ.get("HXORACLE_LIB"):
+        return os.environ["HXORACLE_LIB"]
     so = os.path.join(_HERE, "libhxoracle.so")
     src = os.path.join(_HERE, "hx_oracle.c")
     hdr = os.path.join(_HERE, "hx_oracle.h")
@@ -423,3 +426,31 @@ def ud_grade(m, nside_out):
     else:
         out_nest = m_nest
     return out_nest[ring2nest(nside_out, np.arange(npix_out))]
+
+
+def expand_full_weights(nside, wgt):
+    """Full-sky multiplicative pixel weights ``1 + w`` from healpy's compressed half-quadrant weights (the values in
+    ``healpix_full_weights_nside_NNNN.fits``), RING order: restatement of the published expansion of healpix_cxx's
+    ``apply_fullweights`` (third-party; not in /root/reference -- "parity unpinned" against healpy itself), ring by ring with
+    plain Python loops."""
+    wgt = np.asarray(wgt, dtype=np.float64)
+    assert wgt.size == ((nside + 1) * (3 * nside + 1)) // 4
+    npix = 12 * nside * nside
+    out = np.zeros(npix)
+    pix = vpix = 0
+    for i in range(2 * nside):
+        shifted = (i < nside - 1) or bool((i + nside) & 1)
+        qpix = min(nside, i + 1)
+        odd = qpix & 1
+        wpix = ((qpix + 1) >> 1) + (0 if (odd or shifted) else 1)
+        psouth = npix - pix - (qpix << 2)
+        for j in range(qpix << 2):
+            j4 = j % qpix
+            rpix = min(j4, qpix - (1 if shifted else 0) - j4)
+            out[pix + j] = 1.0 + wgt[vpix + rpix]
+            if i != 2 * nside - 1:
+                out[psouth + j] = 1.0 + wgt[vpix + rpix]
+        pix += qpix << 2
+        vpix += wpix
+    assert vpix == wgt.size and (out != 0).all()
+    return out

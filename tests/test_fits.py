@@ -112,3 +112,29 @@ def test_maps_and_alms_round_trip_and_bytes(tmp_path):
     table = np.ascontiguousarray(big.reshape(2, -1, 1024).transpose(1, 0, 2)).astype(">f8").tobytes()
     hf._append_table(v, "VMAP", ["T", "Q"], 1024, big.shape[1] // 1024, np.frombuffer(table, dtype=np.uint8), [], {})
     np.testing.assert_array_equal(hf.read_maps(v)["VMAP"], big)
+    # float32 vector columns ('1024E': healpy.write_map's default for masks / visibility maps) are widened to float64
+    v32 = tmp_path / "vec32.fits"
+    hf._new_file(v32, True)
+    big32 = big.astype(np.float32)
+    table32 = np.ascontiguousarray(big32.reshape(2, -1, 1024).transpose(1, 0, 2)).astype(">f4").tobytes()
+    cards = [hf._card("XTENSION", "BINTABLE"), hf._card("BITPIX", 8), hf._card("NAXIS", 2), hf._card("NAXIS1", 2 * 4 * 1024),
+             hf._card("NAXIS2", big.shape[1] // 1024), hf._card("PCOUNT", 0), hf._card("GCOUNT", 1), hf._card("TFIELDS", 2),
+             hf._card("TTYPE1", "T"), hf._card("TFORM1", "1024E"), hf._card("TTYPE2", "Q"), hf._card("TFORM2", "1024E"), hf._card("EXTNAME", "VMAP")]
+    with open(v32, "ab") as f:
+        f.write(hf._header_bytes(cards))
+        f.write(table32)
+        f.write(b"\0" * (-len(table32) % 2880))
+    np.testing.assert_array_equal(hf.read_maps(v32)["VMAP"], big32.astype(np.float64))
+    # alms with two leading axes keep their shape: TDIM carries the reversed leading dimensions of the reference's
+    # moveaxis layout (heracles/io.py:189-218)
+    a3 = rng.standard_normal((3, 2, nlm)) + 1j * rng.standard_normal((3, 2, nlm))
+    hx.update_metadata(a3, spin=2, nside=nside)
+    r = tmp_path / "alms3.fits"
+    hf.write_alms(r, {("SHE", 7): a3}, clobber=True)
+    h3, off3 = hf._scan(r)[1]
+    assert (h3["TFORM1"], h3["TDIM1"], h3["TDIM2"]) == ("6D", "(2,3)", "(2,3)")
+    raw3 = np.fromfile(r, dtype=">f8", count=12 * nlm, offset=off3).reshape(nlm, 2, 3, 2)  # (row, real|imag, a, b)
+    np.testing.assert_array_equal(raw3[:, 0], np.moveaxis(a3.real, -1, 0))
+    back3 = hf.read_alms(r)["SHE", 7]
+    assert back3.shape == (3, 2, nlm)
+    np.testing.assert_array_equal(back3, a3)

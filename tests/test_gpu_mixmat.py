@@ -97,6 +97,24 @@ def test_mixmat_large_properties():
     np.testing.assert_allclose(S, S.T, atol=1e-11 * np.abs(S).max())
 
 
+def test_legendre_funcs_golden(golden):
+    """heracles.transforms.legendre_funcs (transforms.py:46-112), all three groups incl. d11 / dm11 (:68-73), against the
+    values the reference itself produced at 8 nodes (3 of them in its small-angle branch x > 0.998)."""
+    from heracles_amd import transforms as tr
+
+    lmax = 40
+    for i, x in enumerate(golden["leg/x"]):
+        (P, dP), (d11, dm11), (d20, d22, d2m2) = tr.legendre_funcs(lmax, float(x), m=(0, 1, 2))
+        np.testing.assert_allclose(P, golden[f"leg/{i}/P"], atol=1e-13)
+        np.testing.assert_allclose(dP, golden[f"leg/{i}/dP"], rtol=1e-12, atol=1e-11)
+        np.testing.assert_allclose(d11, golden[f"leg/{i}/d11"], atol=1e-12)
+        np.testing.assert_allclose(dm11, golden[f"leg/{i}/dm11"], atol=1e-12)
+        np.testing.assert_allclose(d20, golden[f"leg/{i}/d20"], atol=1e-12)
+        np.testing.assert_allclose(d22, golden[f"leg/{i}/d22"], atol=1e-12)
+        np.testing.assert_allclose(d2m2, golden[f"leg/{i}/d2m2"], atol=1e-11)
+    assert len(tr.legendre_funcs(lmax, 0.3)) == 2 and len(tr.legendre_funcs(lmax, 0.3, m=(1,))) == 1
+
+
 @pytest.mark.parametrize("lm", [12, 40, 97])
 def test_cl2corr_corr2cl_golden(golden, lm):
     import heracles_amd as hx

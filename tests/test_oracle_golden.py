@@ -59,6 +59,8 @@ def test_wigner_d_recursion_vs_closed_forms(oracle, golden):
         np.testing.assert_allclose(oracle.wigner_d(lmax, 2, 0, float(x))[2:], golden[f"leg/{i}/d20"], atol=1e-12)
         np.testing.assert_allclose(oracle.wigner_d(lmax, 2, 2, float(x))[2:], golden[f"leg/{i}/d22"], atol=1e-12)
         np.testing.assert_allclose(oracle.wigner_d(lmax, 2, -2, float(x))[2:], golden[f"leg/{i}/d2m2"], atol=1e-11)
+        np.testing.assert_allclose(oracle.wigner_d(lmax, 1, 1, float(x))[1:], golden[f"leg/{i}/d11"], atol=1e-12)
+        np.testing.assert_allclose(oracle.wigner_d(lmax, -1, 1, float(x))[1:], golden[f"leg/{i}/dm11"], atol=1e-12)
 
 
 @pytest.mark.parametrize("lm", [12, 40, 97])
