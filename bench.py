@@ -5,7 +5,9 @@ Metric (BASELINE.json): "map->Cl pairs/sec + mixing-matrix build sec, nside=4096
 Workload at N = 1 (the north_star target, which fits one GPU): 10 spin-0 + 10 spin-2 maps
 (30 components) at nside=4096, lmax=6144, synthetic Gaussian pixels, resident in HBM when
 the timed region starts.  One "step" = batched map2alm of all maps (niter=0, unit ring
-weights, no pixel weights) + all auto/cross Cl of every map pair + D2H of the Cl blocks.
+weights, a synthetic full-sky pixel-weight array) + all auto/cross Cl of every map pair + D2H of the Cl blocks.
+`value` is that device-resident rate (the task contract: inputs resident in HBM when the timed region starts);
+`value_host_to_host` is SURVEY 8d's definition (pageable host maps in, Cl blocks on the host out; median of --host-steps).
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -32,7 +34,7 @@ if ROOT not in sys.path:
 
 FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 matrix (= vector) peak
 HBM_PEAK_GBS = 8000.0
-PROFILE_ROUND = "r02"    # profiles/<round>_traffic.json holds the committed PMC passes of THIS round's kernels
+PROFILE_ROUND = "r03"    # profiles/<round>_traffic.json holds the committed PMC passes of THIS round's kernels
 
 
 def parse():
@@ -44,6 +46,10 @@ def parse():
     p.add_argument("--lmax", type=int, default=6144)
     p.add_argument("--nbins", type=int, default=10, help="tomographic bins: nbins x (spin-0, spin-2) maps per GPU (weak) / in all (strong)")
     p.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    p.add_argument("--workload", choices=("north_star", "euclid"), default="north_star",
+                   help="north_star: nbins x (spin-0, spin-2) maps (the default line); euclid: BASELINE configs[4] on ONE GPU -- "
+                        "13 bins x (2 spin-0 + 1 spin-2) = 39 maps / 52 components / 780 pairs (not the driver's line)")
+    p.add_argument("--host-steps", type=int, default=5, help="steps of the host -> host leg (median reported)")
     p.add_argument("--mixmat-lmax", type=int, default=None, help="L of the timed mixmat_eb (default: lmax)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-mixmat", action="store_true")
@@ -64,7 +70,7 @@ def cpu_engines():
     return out
 
 
-def oracle_sample(nside, lmax, t_map, qu_map, stride):
+def oracle_sample(nside, lmax, t_map, qu_map, stride, pix_weights=None):
     """Oracle (CPU restatement, kind "port") map2alm of one spin-0 map and one spin-2 map at full size: all rings,
     every `stride`-th m of the Legendre stage.  Returns (alm0, alm2, timings) -- used as the cpu_baseline sample AND as
     the checker of the GPU alms on those m."""
@@ -72,9 +78,9 @@ def oracle_sample(nside, lmax, t_map, qu_map, stride):
 
     ho.set_mstride(stride)
     try:
-        a0 = ho.map2alm(t_map, nside, lmax, spin=0)
+        a0 = ho.map2alm(t_map, nside, lmax, spin=0, pix_weights=pix_weights)
         f0, l0 = ho.last_timings()
-        a2 = ho.map2alm(qu_map, nside, lmax, spin=2)
+        a2 = ho.map2alm(qu_map, nside, lmax, spin=2, pix_weights=pix_weights)
         f2, l2 = ho.last_timings()
     finally:
         ho.set_mstride(1)
@@ -149,7 +155,12 @@ def main():
 
     # ---- the job: maps ordered (spin-0 bins, spin-2 bins) per brought-in set ---------------------------------------
     nsets = world if args.scaling == "weak" else 1
-    spins = ([0] * nbins + [2] * nbins) * nsets
+    if args.workload == "euclid":
+        nbins = 13
+        per_set = [0] * (2 * nbins) + [2] * nbins  # 13 bins x (2 spin-0 fields + 1 spin-2 field): BASELINE configs[4]
+    else:
+        per_set = [0] * nbins + [2] * nbins
+    spins = per_set * nsets
     nmaps_total = len(spins)
     work = hxd.ShardedTwoPoint(spins, world, rank, nlm, lmax)
     mine = work.local_maps
@@ -161,12 +172,16 @@ def main():
     maps0 = torch.randn((n0, npix), dtype=torch.float64, device=dev, generator=gen)
     maps2 = torch.randn((n2, 2, npix), dtype=torch.float64, device=dev, generator=gen)
     alm0, alm2 = work.local_alm_views(dev)
+    # Pixel weights in the timed path: the reference always transforms with use_pixel_weights=True (heracles/healpy.py:186).
+    # healpy's weight files are not available offline; a synthetic full-sky array of the same kind (1 + small, smooth, 8-fold
+    # symmetric is not required by the kernels) stands in: the kernels do the same work whatever the values.
+    pw = 1.0 + 1e-3 * torch.cos(torch.arange(npix, dtype=torch.float64, device=dev) * (2.0 * np.pi / 1024.0))
 
     def step():
-        if n0:
-            plan.map2alm(maps0, 0, out=alm0)
         if n2:
-            plan.map2alm(maps2.view(2 * n2, npix), 2, out=alm2.view(2 * n2, nlm))
+            plan.map2alm(maps2.view(2 * n2, npix), 2, pix_weights=pw, out=alm2.view(2 * n2, nlm))
+        if n0:
+            plan.map2alm(maps0, 0, pix_weights=pw, out=alm0)
         return work.all_pairs_cl()  # rank 0: every Cl block on the host
 
     def sync():
@@ -206,7 +221,7 @@ def main():
     def pmc_traffic(prefix):
         """HBM bytes per launch from the committed PMC passes of this round's kernels (rocprofv3 cannot run inside
         this process); None when the file is missing or belongs to another workload."""
-        if (nside, lmax, nbins, world) != (4096, 6144, 10, 1):
+        if (nside, lmax, nbins, world, args.workload) != (4096, 6144, 10, 1, "north_star"):
             return None, None
         path = os.path.join("profiles", f"{PROFILE_ROUND}_traffic.json")
         try:
@@ -219,16 +234,29 @@ def main():
         sel = [v for k, v in tk.items() if k.startswith(prefix)]
         return (max(v["hbm_bytes_per_launch"] for v in sel) if sel else None), path
 
+    # executed work of ONE step per spin, counted by the kernels themselves (hx_executed_flops: matrix instructions actually
+    # issued -- dead stages skip theirs -- and vector-unit flops); one extra call per spin, outside the timed region
+    def counted(fn):
+        hx._lib.executed_flops(reset=True)
+        fn()
+        return hx._lib.executed_flops(reset=True)
+
+    exec2 = counted(lambda: plan.map2alm(maps2.view(2 * n2, npix), 2, pix_weights=pw, out=alm2.view(2 * n2, nlm))) if n2 else (0.0, 0.0)
+    exec0 = counted(lambda: plan.map2alm(maps0, 0, pix_weights=pw, out=alm0)) if n0 else (0.0, 0.0)
+
     def roof(name, kernel, alg_flops_step, spin, ncomp):
         nl_, ms_ = hx._lib.profile_get(name)
-        mf, vf = plan.executed_flops(spin, ncomp) if ncomp else (0.0, 0.0)
+        mf, vf = exec2 if spin else exec0
+        mf_model = plan.mfma_flops(spin, ncomp) if ncomp else 0.0
         sec = ms_ * 1e-3
         exe = (mf + vf) * args.steps / sec / 1e12 if sec > 0 else 0.0
         traffic, tpath = pmc_traffic("hx::k_legendre_pipe<%d" % spin)
         return {"kernel": kernel, "bound": "mfma", "achieved": exe, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": exe / FP64_PEAK_TFLOPS,
-                "achieved_is": "EXECUTED FP64 flops (matrix instructions of the task list + 4 flops per generated lambda_lm "
-                               "on the vector unit) / kernel time; the two share one FP64 pipe (peak 78.6 either way)",
+                "achieved_is": "EXECUTED FP64 flops, counted by the kernel itself (matrix instructions actually issued -- stages whose "
+                               "rings are all below 2^-300 skip theirs -- + 4 flops per generated lambda_lm on the vector unit) / kernel time; "
+                               "the two share one FP64 pipe (peak 78.6 either way); equals the SQ_INSTS_VALU_MFMA_F64-based figure of profiles/",
+                "task_list_mfma_tflops": mf_model * args.steps / sec / 1e12 if sec > 0 else 0.0,
                 "executed_mfma_tflops": mf * args.steps / sec / 1e12 if sec > 0 else 0.0,
                 "executed_valu_tflops": vf * args.steps / sec / 1e12 if sec > 0 else 0.0,
                 "algorithmic_tflops": alg_flops_step * args.steps / sec / 1e12 if sec > 0 else 0.0,
@@ -254,19 +282,26 @@ def main():
             h2 = maps2.cpu().numpy().reshape(2 * n2, npix)
 
             def host_step():
-                plan.map2alm(h0, 0, out=alm0)       # host maps are staged through HBM by the library; alms stay in HBM
-                plan.map2alm(h2, 2, out=alm2.view(2 * n2, nlm))
+                # ONE call for all transforms: the uploads of the next sweep overlap the transform of the current one across the
+                # two jobs (hx_map2alm_multi); large job first, the last sweep is a small one.  alms stay in HBM.
+                plan.map2alm_multi([(h2, 2, alm2.view(2 * n2, nlm)), (h0, 0, alm0)], pix_weights=pw)
                 return work.all_pairs_cl()          # numpy array on the host
 
             host_step()
-            th = time.perf_counter()
-            nh = 2
+            nh = max(args.host_steps, 1)
+            times = []
             for _ in range(nh):
+                th = time.perf_counter()
                 host_step()
-            dth = (time.perf_counter() - th) / nh
+                times.append(time.perf_counter() - th)
+            dth = float(np.median(times))
             host_leg = {"value": npairs / dth, "unit": "map->Cl pairs/s", "ms_per_step": dth * 1e3, "steps": nh,
-                        "what": "pageable numpy maps on the host -> batched map2alm (H2D through the library's pinned staging) -> "
-                                "all-pairs Cl -> numpy Cl blocks on the host; alms never leave HBM"}
+                        "ms_per_step_all": [t * 1e3 for t in times], "statistic": "median",
+                        "pcie_floor_ms": (n0 + 2 * n2) * npix * 8 / 55e9 * 1e3,
+                        "what": "pageable numpy maps on the host -> ONE hx_map2alm_multi call (H2D through the library's pinned "
+                                "staging, uploads overlapped with the transforms across jobs, pixel weights applied) -> all-pairs Cl -> "
+                                "numpy Cl blocks on the host; alms never leave HBM.  pcie_floor_ms = the maps' bytes at the 55 GB/s the "
+                                "staging sustains"}
             del h0, h2
 
         # ---- verification of what was timed (outside the timed region) --------------------------------------------
@@ -276,7 +311,7 @@ def main():
             stride = (8 if nside >= 2048 else 1) if not args.no_cpu_baseline else (512 if nside >= 2048 else 4)
             t_host = maps0[:1].cpu().numpy()
             qu_host = maps2[0].cpu().numpy()
-            oa0, oa2, tim = oracle_sample(nside, lmax, t_host, qu_host, stride)
+            oa0, oa2, tim = oracle_sample(nside, lmax, t_host, qu_host, stride, pix_weights=pw.cpu().numpy())
             osample = (oa0, oa2, tim, stride)
             del t_host, qu_host
         if not args.no_verify:
@@ -323,7 +358,7 @@ def main():
             del w, idx_l
         if not args.no_cpu_baseline and world == 1 and osample is not None:  # reported on rank 0 at N = 1 only
             oa0, oa2, tim, stride = osample
-            cpu = cpu_baseline(nside, lmax, nbins, nbins, oa0, oa2, tim, stride)
+            cpu = cpu_baseline(nside, lmax, per_set.count(0), per_set.count(2), oa0, oa2, tim, stride)
 
         mix = None
         if not args.no_mixmat:
@@ -348,11 +383,13 @@ def main():
             "value": value, "unit": "map->Cl pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{nbins} bins x (spin-0, spin-2) maps {'per GPU' if args.scaling == 'weak' else 'in all'} = "
+            "config": {"workload": f"{nbins} bins x ({'2 spin-0 + 1 spin-2' if args.workload == 'euclid' else 'spin-0, spin-2'}) maps "
+                                   f"{'per GPU' if args.scaling == 'weak' else 'in all'} = "
                                    f"{nmaps_total} maps / {sum(2 if s else 1 for s in spins)} components over {world} GPU(s), nside={nside}, lmax={lmax}, "
-                                   f"niter=0, ring weights 1, pix_weights: none; {npairs} auto+cross map pairs; inputs resident in HBM",
+                                   f"niter=0, ring weights 1, pix_weights: synthetic full-sky array (healpy's files are not available offline); "
+                                   f"{npairs} auto+cross map pairs; inputs resident in HBM",
                        "nside": nside, "lmax": lmax, "maps_total": nmaps_total, "maps_this_rank": len(mine), "pairs": npairs,
-                       "pix_weights": "none",
+                       "pix_weights": "synthetic full-sky array, applied in the timed path",
                        "parallelism": (f"maps dealt to {world} GPUs by cost, RCCL all-gather of alms, tiled pair split"
                                        if world > 1 else "1 GPU")},
             "verified": (verify or {}).get("ok") if verify is not None else None,

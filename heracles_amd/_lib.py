@@ -26,11 +26,12 @@ SYMBOLS = (
     "hx_version", "hx_last_error", "hx_device_count", "hx_init", "hx_set_stream",
     "hx_get_stream", "hx_set_async", "hx_synchronize", "hx_timer_start", "hx_timer_stop",
     "hx_profile_enable", "hx_profile_reset", "hx_profile_get", "hx_plan_create", "hx_set_max_lds_fft",
-    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_set_scratch_budget", "hx_plan_last_chunks", "hx_plan_mfma_flops", "hx_plan_executed_flops", "hx_executed_flops", "hx_measure_peaks", "hx_measured_mfma_clock", "hx_map2alm", "hx_alm2map",
-    "hx_alm2cl_pairs", "hx_gauss_legendre", "hx_wigner_d_table", "hx_mixmat",
+    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_set_scratch_budget", "hx_plan_last_chunks", "hx_plan_mfma_flops", "hx_plan_executed_flops", "hx_executed_flops", "hx_measure_peaks", "hx_measured_mfma_clock", "hx_map2alm", "hx_map2alm_multi", "hx_alm2map",
+    "hx_alm2cl_pairs", "hx_alm2cl_pairs_range", "hx_gauss_legendre", "hx_wigner_d_table", "hx_mixmat",
     "hx_mixmat_eb", "hx_mixmat_batch", "hx_mixctx_create", "hx_mixctx_apply", "hx_mixctx_destroy", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_alm_resample", "hx_region_maps", "hx_alm_subtract", "hx_fits_unpack_f64", "hx_fits_pack_f64",
     "hx_pointsht_create", "hx_pointsht_destroy", "hx_pointsht_info", "hx_pointsht_adjoint",
     "hx_pixel_weights_size", "hx_pixel_weights_expand",
+    "hx_plan_m_cost", "hx_ring_modes_size", "hx_ring_modes", "hx_legendre_from_modes",
 )
 
 
@@ -86,7 +87,9 @@ def load():
         L.hx_measured_mfma_clock.restype = C.c_double
         L.hx_map2alm.argtypes = [vp, i, i, dp, dp, dp, dp, dp, i]
         L.hx_alm2map.argtypes = [vp, i, i, dp, dp]
+        L.hx_map2alm_multi.argtypes = [vp, i, vp, vp, vp, vp, dp, dp, vp]
         L.hx_alm2cl_pairs.argtypes = [i, vp, vp, i, i, vp, vp, dp]
+        L.hx_alm2cl_pairs_range.argtypes = [i, vp, vp, i, i, vp, vp, i, i, dp]
         L.hx_gauss_legendre.argtypes = [i, dp, dp]
         L.hx_wigner_d_table.argtypes = [i, i, i, i, dp, dp]
         L.hx_mixmat.argtypes = [dp, i, i, i, i, i, i, dp]
@@ -113,6 +116,11 @@ def load():
         L.hx_pointsht_destroy.restype = None
         L.hx_pointsht_info.argtypes = [vp, C.POINTER(C.c_int)]
         L.hx_pointsht_adjoint.argtypes = [vp, i, i, C.c_int64, dp, dp, dp]
+        L.hx_plan_m_cost.argtypes = [vp, i, dp]
+        L.hx_ring_modes_size.argtypes = [vp, i, i]
+        L.hx_ring_modes_size.restype = C.c_int64
+        L.hx_ring_modes.argtypes = [vp, i, dp, dp, dp, i, vp, vp]
+        L.hx_legendre_from_modes.argtypes = [vp, i, i, vp, i, i, dp, dp]
         L.hx_pixel_weights_size.argtypes = [i]
         L.hx_pixel_weights_size.restype = C.c_int64
         L.hx_pixel_weights_expand.argtypes = [i, C.c_int64, dp, dp]

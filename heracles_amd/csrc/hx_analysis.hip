@@ -1628,7 +1628,7 @@ static int analysis_batch_valu(hx_plan *pl, int spin, int nb, const double *d_ma
     if (spin) HX_TRY(ensure_rec2(pl));
     hx_plan::TaskSet &ts = spin ? pl->ts[4] : pl->ts[5];
     HX_TRY(build_task_set(pl, spin, valu_task_blocks(spin), ts));
-    if (pl->hsrc == nullptr) {
+    if (pl->hsrc == nullptr && pl->nssrc == nullptr) {
         HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
         HX_TRY(launch_ring_subdft_maps(pl, nb, d_maps, d_pw, pl->Y.as<double2>()));
     }
@@ -1644,9 +1644,10 @@ static int analysis_batch_valu(hx_plan *pl, int spin, int nb, const double *d_ma
     const std::vector<long long> &prow = ts.rows_before_m;
     std::vector<std::pair<int, int>> chunks;
     size_t maxF = 16, maxP = 16;
-    for (int m0 = 0; m0 <= lmax;) {
+    const int m_end = pl->m_hi < 0 ? lmax + 1 : std::min(pl->m_hi, lmax + 1);
+    for (int m0 = std::max(pl->m_lo, 0); m0 < m_end;) {
         int m1 = m0 + 1;
-        while (m1 <= lmax) {
+        while (m1 < m_end) {
             const double bytes = f_per_m * (m1 + 1 - m0) + (double)(prow[m1 + 1] - prow[m0]) * pcol * sizeof(double);
             if (bytes > budget) break;
             ++m1;
@@ -1694,7 +1695,7 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     if (sh.oneset) HX_TRY(build_task_set(pl, 2, PipeCfg<2>::NW * PipeCfg<2>::RBS, pl->ts[3]));  // one ring set per wave: 4 ring blocks per task
     hx_plan::TaskSet &ts = sh.oneset ? pl->ts[3] : (half ? pl->ts[2] : pl->ts[sidx]);
     const int ncol = sh.ncol;
-    if (pl->hsrc == nullptr) {
+    if (pl->hsrc == nullptr && pl->nssrc == nullptr) {
         HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
         HX_TRY(launch_ring_subdft_maps(pl, nb, d_maps, d_pw, pl->Y.as<double2>()));
     }
@@ -1716,9 +1717,10 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     const int pcol = sh.oneset ? (ncol + 15) / 16 * 16 : ncol;  // doubles per row of the partial buffer (launch_chunk)
     std::vector<std::pair<int, int>> chunks;
     size_t maxF = 16, maxP = 16;
-    for (int m0 = 0; m0 <= lmax;) {
+    const int m_end = pl->m_hi < 0 ? lmax + 1 : std::min(pl->m_hi, lmax + 1);
+    for (int m0 = std::max(pl->m_lo, 0); m0 < m_end;) {
         int m1 = m0 + 1;  // a chunk holds at least one m, whatever the budget
-        while (m1 <= lmax) {
+        while (m1 < m_end) {
             const double bytes = f_per_m * (m1 + 1 - m0) +
                                  (double)(prow[m1 + 1] - prow[m0]) * pcol * sizeof(double);
             if (bytes > budget) break;

@@ -20,6 +20,7 @@
 //   4. k_alm_reduce        rows -> alm layout (x fl); for the small-batch kernels also the fixed-order
 //                          sum of the ring-group partials.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 
@@ -158,18 +159,22 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
     extern __shared__ double2 buf[];  // the padded transform buffer of the class's M, then the phase tables (4 M / 64 + 1 and 64 entries)
     __shared__ double2 tw_hi[TW_HI_MAX], tw_lo[64];
     double2 *ph_hi = buf + lds_fft_slots(Mclass), *ph_lo = ph_hi + ring_ph_hi(Mclass);
-    const int nt = blockDim.x, nrc = nrings * nb;
-    const int nitems = ((nrc + 7) >> 3) * 32;  // (ring, component) pairs padded to whole sets of 8 (one per XCD) x 4 sub-DFTs
+    const int nt = blockDim.x;
+    const int nitems = ((nrings + 7) >> 3) * nb * 32;  // sets of 8 ring pairs (one per XCD) x components x 4 sub-DFTs
     const TwFactored twf = load_tw_factored(tw_hi, tw_lo, P.tw, P.twN);  // visible after the first barrier below
     int tid = threadIdx.x;
 #if HX_FFT_ABL & 32
     unsigned long long fcyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flast = __builtin_amdgcn_s_memtime();
 #endif
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        // item = 8 (4 s + r) + x: sub-DFT r of pair 8 s + x -- the four r of a pair in four groups of XCD x, side by side in time
-        const int r = (item >> 3) & 3, rc = ((item >> 5) << 3) + (item & 7);
-        if (rc >= nrc) continue;  // padding of the last set of 8 pairs
-        const int rp = rp_list[rc / nb], c = rc % nb;
+        // item = 8 (4 s + r) + x: sub-DFT r of set s on XCD x -- the four r of a (ring pair, component) in four groups of that XCD,
+        // side by side in time.  Set s = (ring set s / nb, component s % nb): an XCD walks the COMPONENTS of one ring pair before it
+        // moves to its next ring pair, so that the pair's pixel weights come from HBM once and from that XCD's L2 for every other
+        // component (component-major sets re-read the 1.6 GB weight array per component: +34 ms per step of the bench)
+        const int r = (item >> 3) & 3, set = item >> 5;
+        const int ring = (set / nb) * 8 + (item & 7), c = set % nb;
+        if (ring >= nrings) continue;  // padding of the last set of 8 ring pairs
+        const int rp = rp_list[ring];
         const int n = P.nsub[rp];
         const long long sN = P.startN[rp], sS = P.startS[rp];
         const int M = fft_size_for(n), MP = lds_fft_slots(M);
@@ -544,6 +549,7 @@ PlanDev hx_plan::dev() const
     P.mfac = mfac.as<double>(); P.kfac2 = kfac2.as<double>();
     P.rec0 = nullptr; P.rec2 = nullptr;
     P.wnorm = wnorm; P.hsrc = hsrc; P.hsrc_stride = hsrc_stride; P.hN = eqN;
+    P.nssrc = nssrc; P.ns_m0 = ns_m0;
     return P;
 }
 
@@ -747,7 +753,7 @@ extern "C" void hx_plan_destroy(hx_plan *plan)
 {
     if (!plan) return;
     if (rt().ready) (void)hipStreamSynchronize(rt().stream);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < hx_plan::NSTAGE; ++i) {
         if (plan->stage_up[i]) (void)hipEventDestroy(plan->stage_up[i]);
         if (plan->stage_done[i]) (void)hipEventDestroy(plan->stage_done[i]);
     }
@@ -793,7 +799,7 @@ static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, cons
         const int threads = std::min(RING_NTMAX, std::max(64, c.M / 16));
         const size_t lds = (size_t)(lds_fft_slots(c.M) + ring_ph_hi(c.M) + 64) * sizeof(double2);
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(512 / threads, (160 * 1024) / (lds + 3 * 1024 + 256)));
-        const long long items = ((long long)c.count * nb + 7) / 8 * 32;
+        const long long items = ((long long)c.count + 7) / 8 * nb * 32;
         const unsigned groups = (unsigned)std::min<long long>(items, (long long)rt().cus * per_cu);
         hipLaunchKernelGGL(k_ring_subdft<MODE>, dim3(groups), dim3(threads), lds, rt().stream,
                            pl->dev(), pl->fft_rp_list.as<int>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
@@ -936,6 +942,124 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
         return HX_OK;
     }
     return finish_call();
+}
+
+// Several transforms as ONE call (the loop of heracles/mapping.py:151-172 over the (field, bin) maps of a job): host maps of ALL
+// jobs go through one upload pipeline -- sweep k + 1 is staged (pageable -> pinned -> HBM, second stream) while the GPU transforms
+// sweep k, across job boundaries -- so that the call costs its PCIe time plus the transform of the LAST sweep.  Jobs are cut into
+// sweeps of at most 5 spin-2 fields / 8 spin-0 maps (the first transform starts after a third of the upload at the bench size;
+// smaller sweeps cost more matrix-pipe time than they hide), and the last sweep of the call is halved until it holds at most two units: what is left exposed behind the last byte
+// of the upload is a small transform.  Callers put their large jobs first.  niter = 0 only (iterations need their maps resident).
+// (At the bench size -- 32 GB of spin-2 and 16 GB of spin-0 maps at 55 GB/s -- the sweeps are 5 + 5 fields and 8 + 2 maps: their
+// transforms, 240 + 240 + 100 + 50 ms, ride under the 880 ms of uploads except the last.)
+extern "C" int hx_map2alm_multi(hx_plan *pl, int njobs, const int *spins, const int *ncomps, const double *const *maps, double *const *alms,
+                                const double *ring_weights, const double *pix_weights, const double *const *fls)
+{
+    HX_TRY(ensure_ready());
+    if (!pl || njobs < 1 || !spins || !ncomps || !maps || !alms) return fail(HX_ERR_ARG, "hx_map2alm_multi: bad arguments");
+    for (int j = 0; j < njobs; ++j) HX_TRY(check_sht_args(pl, spins[j], ncomps[j], maps[j], alms[j]));
+    InView vrw, vpw;
+    HX_TRY(vrw.bind(ring_weights, sizeof(double) * pl->nrp));
+    HX_TRY(vpw.bind(pix_weights, sizeof(double) * (size_t)pl->npix));
+    std::vector<InView> vfl(njobs);
+    std::vector<OutView> valm(njobs);
+    struct Sweep { int job, c0, nb; };
+    std::vector<Sweep> sweeps;
+    bool any_host = false;
+    for (int j = 0; j < njobs; ++j) {
+        HX_TRY(vfl[j].bind(fls ? fls[j] : nullptr, sizeof(double) * (pl->lmax + 1)));
+        HX_TRY(valm[j].bind(alms[j], sizeof(double2) * (size_t)ncomps[j] * pl->nlm));
+        const bool host = !is_device_ptr(maps[j]);
+        any_host = any_host || host;
+        const int unit = spins[j] ? 2 : 1, cap = spins[j] ? 10 : 8;  // 5 spin-2 fields / 8 spin-0 maps: one full column group each
+        for (int c0 = 0; c0 < ncomps[j];) {
+            int nb = host ? std::min(cap, ncomps[j] - c0) : analysis_next_batch(spins[j], ncomps[j] - c0);
+            // spin 2: two even sweeps rather than a full and a small one (a sweep costs ~76 ms before its first column);
+            // spin 0: a full group, then the rest -- small spin-0 sweeps run on the vector-unit kernel at 23 ms per map
+            if (host && spins[j] && ncomps[j] - c0 > cap && ncomps[j] - c0 < 2 * cap) nb = ((ncomps[j] - c0) / unit + 1) / 2 * unit;
+            sweeps.push_back({j, c0, nb});
+            c0 += nb;
+        }
+    }
+    if (any_host && !is_device_ptr(maps[sweeps.back().job])) {
+        for (;;) {  // halve the last sweep until it holds at most two units
+            Sweep &l = sweeps.back();
+            const int unit = spins[l.job] ? 2 : 1, units = l.nb / unit;
+            if (units <= 2) break;
+            const int first = (units + 1) / 2 * unit;
+            const Sweep tail = {l.job, l.c0 + first, l.nb - first};
+            l.nb = first;
+            sweeps.push_back(tail);
+        }
+    }
+    hipStream_t cs = any_host ? copy_stream() : nullptr;
+    constexpr int NST = hx_plan::NSTAGE;
+    size_t stage_bytes = 0;
+    for (const Sweep &w : sweeps)
+        if (!is_device_ptr(maps[w.job])) stage_bytes = std::max(stage_bytes, (size_t)(sizeof(double) * (size_t)w.nb * (size_t)pl->npix));
+    if (any_host) {
+        if (!cs) return fail(HX_ERR_HIP, "hx_map2alm_multi: no copy stream");
+        for (int i = 0; i < NST; ++i) {
+            HX_TRY(pl->stage[i].alloc(stage_bytes));
+            if (!pl->stage_up[i]) HX_HIP(hipEventCreateWithFlags(&pl->stage_up[i], hipEventDisableTiming));
+            if (!pl->stage_done[i]) HX_HIP(hipEventCreateWithFlags(&pl->stage_done[i], hipEventDisableTiming));
+        }
+    }
+    // host sweeps are numbered in upload order; buffer h % NST holds host sweep h.  THREE buffers: the upload of sweep h + 1 waits
+    // for the transform of sweep h - 2, not h - 1 -- with two, a 4.8 GB upload sat 130 ms behind the 240 ms transform of the
+    // spin-2 sweep before it (tools/time_host_multi.py)
+    std::vector<int> hidx(sweeps.size(), -1);
+    int nh = 0;
+    for (size_t k = 0; k < sweeps.size(); ++k)
+        if (!is_device_ptr(maps[sweeps[k].job])) hidx[k] = nh++;
+    auto upload = [&](size_t k) -> int {
+        const Sweep &w = sweeps[k];
+        const int b = hidx[k] % NST;
+        if (hidx[k] >= NST) HX_HIP(hipEventSynchronize(pl->stage_done[b]));  // host sweep h - NST has read this buffer
+        HX_TRY(copy_h2d(pl->stage[b].p, maps[w.job] + (size_t)w.c0 * pl->npix, sizeof(double) * (size_t)w.nb * pl->npix, cs));
+        HX_HIP(hipEventRecord(pl->stage_up[b], cs));
+        return HX_OK;
+    };
+    auto next_host = [&](size_t k) -> size_t {  // first host sweep after k
+        for (size_t q = k + 1; q < sweeps.size(); ++q)
+            if (hidx[q] >= 0) return q;
+        return sweeps.size();
+    };
+    // HX_TRACE=1: host-side timeline of the call on stderr (ms since entry): when each sweep's upload was staged and issued
+    const bool trace = getenv("HX_TRACE") != nullptr;
+    const auto t_entry = std::chrono::steady_clock::now();
+    auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count(); };
+    auto traced_upload = [&](size_t k) -> int {
+        const double t0 = now_ms();
+        const int rc = upload(k);
+        if (trace)
+            fprintf(stderr, "[hx] multi: sweep %zu (job %d, spin %d, %d comps, %.1f GB) staged %.0f -> %.0f ms\n", k, sweeps[k].job, spins[sweeps[k].job],
+                    sweeps[k].nb, sizeof(double) * (double)sweeps[k].nb * pl->npix / 1e9, t0, now_ms());
+        return rc;
+    };
+    const size_t first_host = next_host((size_t)-1);
+    if (first_host < sweeps.size()) HX_TRY(traced_upload(first_host));
+    for (size_t k = 0; k < sweeps.size(); ++k) {
+        const Sweep &w = sweeps[k];
+        const double *src = maps[w.job] + (size_t)w.c0 * pl->npix;
+        if (hidx[k] >= 0) {
+            HX_HIP(hipStreamWaitEvent(rt().stream, pl->stage_up[hidx[k] % NST], 0));
+            src = pl->stage[hidx[k] % NST].as<double>();
+        }
+        HX_TRY(analysis_batch(pl, spins[w.job], w.nb, src, valm[w.job].as<double2>() + (size_t)w.c0 * pl->nlm, vrw.as<double>(), vpw.as<double>(),
+                              vfl[w.job].as<double>(), 0));
+        if (hidx[k] >= 0) {
+            HX_HIP(hipEventRecord(pl->stage_done[hidx[k] % NST], rt().stream));
+            const size_t q = next_host(k);
+            if (trace) fprintf(stderr, "[hx] multi: sweep %zu transform queued at %.0f ms\n", k, now_ms());
+            if (q < sweeps.size()) HX_TRY(traced_upload(q));  // the host thread stages the next sweep while this one is transformed
+        }
+    }
+    for (int j = 0; j < njobs; ++j) HX_TRY(valm[j].finish());
+    if (trace) fprintf(stderr, "[hx] multi: everything queued at %.0f ms\n", now_ms());
+    HX_HIP(hipStreamSynchronize(rt().stream));  // staging buffers of host arguments are released on return
+    if (trace) fprintf(stderr, "[hx] multi: done at %.0f ms\n", now_ms());
+    return HX_OK;
 }
 
 extern "C" int hx_alm2map(hx_plan *pl, int spin, int ncomp, const double *alms, double *maps)

@@ -48,6 +48,10 @@ struct PlanDev {
     const double2 *hsrc;       // equiangular plan: ring spectra h_m(theta_j) [component][m][N] of the current call, else null
     long long hsrc_stride;
     int hN;
+    // m-sharded route (hx_legendre_from_modes): per component a block [m - ns_m0][nrp_pad] of (F_N.re, F_N.im, F_S.re, F_S.im) with
+    // phase and quadrature weight applied, as another rank's hx_ring_modes produced it; null otherwise
+    const double4 *const *nssrc;
+    int ns_m0;
 };
 
 __host__ __device__ inline long long almidx(int lmax, int l, int m)
@@ -140,6 +144,12 @@ struct RingAtM {
 __device__ inline void ring_modes_ns(const PlanDev &P, const double2 *__restrict__ Y, int c, int rp, int m,
                                      const RingAtM &r, double2 &FN, double2 &FS)
 {
+    if (P.nssrc) {
+        const double4 v = P.nssrc[c][(long long)(m - P.ns_m0) * P.nrp_pad + rp];
+        FN = make_double2(v.x, v.y);
+        FS = make_double2(v.z, v.w);
+        return;
+    }
     if (P.hsrc) {
         // equiangular rings theta_j = 2 pi (j + 1/2) / N of the point transform: the spectrum h_m is given on the full circle,
         // lambda_lm(2 pi - theta) = (-1)^m lambda_lm(theta) (both spins) folds the second half onto the rings
@@ -280,6 +290,9 @@ struct hx_plan {
     double wnorm = 0.0;
     const double2 *hsrc = nullptr;  // ring spectra of the current point-transform call (equiangular plan)
     long long hsrc_stride = 0;
+    const double4 *const *nssrc = nullptr;  // m-sharded route: device array of per-component mode blocks of the current call
+    int ns_m0 = 0;
+    int m_lo = 0, m_hi = -1;        // orders the analysis sweeps cover: [m_lo, m_hi), m_hi < 0 = lmax + 1 (m-sharded route: this rank's range)
     long long npix = 0, ny = 0, nlm = 0;
     size_t lds_fft = 0;
     hx::DevBuf z, omz, sth, rwdef, nsub, shifted, startN, startS, bhat_off, tw, bhat, mfac, kfac2, rec0, rec2, cn0, al0, cn2, al2;
@@ -298,8 +311,9 @@ struct hx_plan {
     std::vector<FftClass> fft_classes;   // ring pairs grouped by in-LDS FFT length
     hx::DevBuf fft_rp_list;
     hx::DevBuf Y, F, partial, d_dbg, resid, resid_maps, Fsyn;
-    hx::DevBuf stage[2];                      // maps of one sweep each: host input uploaded sweep by sweep (hx_map2alm)
-    hipEvent_t stage_up[2] = {nullptr, nullptr}, stage_done[2] = {nullptr, nullptr};
+    static constexpr int NSTAGE = 3;          // (hx_map2alm uses two of them, hx_map2alm_multi all three)
+    hx::DevBuf stage[NSTAGE];                 // maps of one sweep each: host input uploaded sweep by sweep
+    hipEvent_t stage_up[NSTAGE] = {nullptr, nullptr, nullptr}, stage_done[NSTAGE] = {nullptr, nullptr, nullptr};
     hx::PlanDev dev() const;
 };
 

@@ -24,7 +24,7 @@ struct ClTile {
 
 __global__ __launch_bounds__(CL_WAVES * 64) void k_alm2cl_tiles(
     const double2 *const *__restrict__ comp, const int *__restrict__ comp_lmax, int ncomp,
-    const ClTile *__restrict__ tiles, int lmax_out, int nlblk, double *__restrict__ cls)
+    const ClTile *__restrict__ tiles, int lmax_out, int nlblk, double *__restrict__ cls, int m_lo, int m_hi)
 {
     __shared__ double red[CL_WAVES][CL_T * CL_T][CL_LB];
     // heavy (high-l) blocks first
@@ -49,7 +49,8 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_alm2cl_tiles(
 #pragma unroll
     for (int t = 0; t < CL_T * CL_T; ++t) acc[t] = 0.0;
 
-    for (int m = w; m <= lhi; m += CL_WAVES) {
+    // [m_lo, m_hi): the orders summed (everything for hx_alm2cl_pairs; one rank's range on the m-sharded multi-GPU route)
+    for (int m = m_lo + w; m <= min(lhi, m_hi - 1); m += CL_WAVES) {
         if (m <= l && l <= lmax_out) {
             double2 a[CL_T], b[CL_T];
 #pragma unroll
@@ -88,11 +89,23 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_alm2cl_tiles(
 
 using namespace hx;
 
+extern "C" int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double *const *alms, int lmax_out, int npairs, const int *pair_i,
+                                     const int *pair_j, int m0, int m1, double *cls);
+
 extern "C" int hx_alm2cl_pairs(int ncomp, const int *lmax_i, const double *const *alms,
                                int lmax_out, int npairs, const int *pair_i, const int *pair_j,
                                double *cls)
 {
+    return hx_alm2cl_pairs_range(ncomp, lmax_i, alms, lmax_out, npairs, pair_i, pair_j, 0, lmax_out + 1, cls);
+}
+
+// The same sum restricted to the orders m0 <= m < m1 (still divided by 2l + 1): the partial spectra of disjoint ranges add up to
+// hx_alm2cl_pairs -- what a rank of the m-sharded route contributes before the all-reduce.
+extern "C" int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double *const *alms, int lmax_out, int npairs, const int *pair_i,
+                                     const int *pair_j, int m0, int m1, double *cls)
+{
     HX_TRY(ensure_ready());
+    if (m0 < 0 || m1 < m0) return fail(HX_ERR_ARG, "hx_alm2cl_pairs_range: bad m range [%d, %d)", m0, m1);
     if (ncomp <= 0 || npairs < 0 || !lmax_i || !alms || !pair_i || !pair_j || !cls || lmax_out < 0)
         return fail(HX_ERR_ARG, "hx_alm2cl_pairs: bad argument");
     if (npairs == 0) return HX_OK;
@@ -158,7 +171,7 @@ extern "C" int hx_alm2cl_pairs(int ncomp, const int *lmax_i, const double *const
         ProfScope ps("alm2cl");
         hipLaunchKernelGGL(k_alm2cl_tiles, dim3((unsigned)(nlblk * tiles.size())), dim3(CL_WAVES * 64), 0, st,
                            d_ptrs.as<const double2 *>(), d_lmax.as<int>(), ncomp, d_tiles.as<ClTile>(),
-                           lmax_out, nlblk, out.as<double>());
+                           lmax_out, nlblk, out.as<double>(), m0, m1);
     }
     HX_HIP(hipGetLastError());
     HX_TRY(out.finish());

@@ -194,3 +194,233 @@ class ShardedTwoPoint:
         for r in range(self.world):
             out[self.rows_of[r]] = recv[r, : len(self.rows_of[r])]
         return out
+
+
+# ======================================================================================================================
+# m-sharded route for a FIXED job (strong scaling): SURVEY.md 8e's "lower-traffic alternative"
+# ======================================================================================================================
+def m_ranges(cost, world):
+    """Cut the orders 0 .. lmax into `world` contiguous ranges of (nearly) equal cost: bounds of length world + 1.
+    cost[m] >= 0; every range holds at least one m while there are enough of them."""
+    cost = np.asarray(cost, dtype=np.float64)
+    n = cost.size
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    bounds = [0]
+    for q in range(1, world):
+        target = cum[-1] * q / world
+        b = int(np.searchsorted(cum, target, side="left"))
+        b = min(max(b, bounds[-1] + 1), n - (world - q))  # non-empty ranges, room for the ones that follow
+        bounds.append(max(b, bounds[-1]))
+    bounds.append(n)
+    return [min(b, n) for b in bounds]
+
+
+def assign_maps_by_components(spins, world):
+    """Owner rank of every map for the ring Fourier stage, whose cost is one unit per component: largest first, ties to the
+    lowest rank."""
+    ncomp = [2 if s else 1 for s in spins]
+    order = sorted(range(len(spins)), key=lambda g: (-ncomp[g], g))
+    load = [0] * world
+    owner = [0] * len(spins)
+    for g in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[g] = r
+        load[r] += ncomp[g]
+    return owner
+
+
+class HipStages:
+    """The two halves of the transform on the GPU (hx_ring_modes / hx_legendre_from_modes of libhxsht)."""
+
+    def __init__(self, plan, device="cuda"):
+        self.plan, self.device = plan, device
+
+    def m_cost(self):
+        import ctypes as C
+
+        from . import _lib
+
+        out = np.zeros(self.plan.lmax + 1)
+        c2 = np.zeros(self.plan.lmax + 1)
+        _lib.check(_lib.load().hx_plan_m_cost(self.plan._h, 0, _lib.ptr(out)))
+        _lib.check(_lib.load().hx_plan_m_cost(self.plan._h, 2, _lib.ptr(c2)))
+        del C
+        return out, c2
+
+    def modes_size(self, m0, m1):
+        from . import _lib
+
+        return int(_lib.load().hx_ring_modes_size(self.plan._h, int(m0), int(m1)))
+
+    def ring_modes(self, maps, bounds, pix_weights=None, ring_weights=None):
+        """maps (ncomp, npix) -> one float64 device tensor per range q: (ncomp * modes_size(bounds[q], bounds[q+1]),)."""
+        import ctypes as C
+
+        import torch
+
+        from . import _lib
+
+        ncomp = maps.shape[0]
+        nr = len(bounds) - 1
+        outs = [torch.empty(ncomp * self.modes_size(bounds[q], bounds[q + 1]), dtype=torch.float64, device=self.device) for q in range(nr)]
+        if ncomp == 0:
+            return outs
+        mb = (C.c_int * (nr + 1))(*[int(b) for b in bounds])
+        ptrs = (C.c_void_p * nr)(*[o.data_ptr() for o in outs])
+        maps = maps.contiguous() if hasattr(maps, "data_ptr") else np.ascontiguousarray(maps, dtype=np.float64)
+        _lib.check(_lib.load().hx_ring_modes(self.plan._h, ncomp, _lib.ptr(maps), _lib.ptr(pix_weights), _lib.ptr(ring_weights), nr, mb, ptrs))
+        return outs
+
+    def legendre(self, spin, blocks, m0, m1, alm_out):
+        """blocks: one float64 device tensor per component ([m1 - m0][nrp_pad][4]); alm_out (ncomp, nlm) complex device tensor,
+        written for m in [m0, m1) only."""
+        import ctypes as C
+
+        from . import _lib
+
+        if not blocks or m1 <= m0:
+            return
+        ptrs = (C.c_void_p * len(blocks))(*[b.data_ptr() for b in blocks])
+        _lib.check(_lib.load().hx_legendre_from_modes(self.plan._h, int(spin), len(blocks), ptrs, int(m0), int(m1), _lib.ptr(alm_out), None))
+
+    def zeros_alm(self, ncomp, nlm):
+        import torch
+
+        return torch.zeros((ncomp, nlm), dtype=torch.complex128, device=self.device)
+
+    def to_exchange(self, t):
+        return t
+
+    def synchronize(self):
+        from . import _lib
+
+        _lib.synchronize()
+
+
+class MShardedTwoPoint:
+    """All auto/cross spectra of a FIXED set of maps on `world` ranks, sharded by the order m:
+
+        ring Fourier stage of the rank's own maps  ->  all-to-all of the ring modes by m-range  ->  Legendre stage of EVERY
+        component on the rank's m-range (the full-batch kernels, 1/world of the orders)  ->  all-pairs Cl over the rank's m
+        ->  all-reduce of the Cl blocks.
+
+    Dealing the MAPS of a 20-map job to 8 ranks instead (ShardedTwoPoint) leaves two or three maps per rank: a batch shape the
+    matrix kernels cannot fill.  Replaces the loops of heracles/mapping.py:151-172 and heracles/twopoint.py:198-215.
+
+    spins: spin of every map of the job in its global order (identical on all ranks); stages: HipStages(plan) -- or any object
+    with the same methods (the CPU tests pass an oracle-backed one)."""
+
+    def __init__(self, spins, world, rank, nlm, lmax, stages, kernel=None, group=None):
+        self.spins = [int(s) for s in spins]
+        self.world, self.rank, self.nlm, self.lmax, self.group, self.stages = world, rank, nlm, lmax, group, stages
+        if kernel is None:
+            from .twopoint import alm2cl_pairs as kernel
+        self.kernel = kernel
+        nmaps = len(self.spins)
+        self.owner = assign_maps_by_components(self.spins, world)
+        # per rank: its maps, spin-0 first; the modes of a rank travel in that order, one block per component
+        self.maps_of = [[g for g in range(nmaps) if self.owner[g] == r and self.spins[g] == 0] +
+                        [g for g in range(nmaps) if self.owner[g] == r and self.spins[g] != 0] for r in range(world)]
+        self.n0_of = [sum(1 for g in ms if self.spins[g] == 0) for ms in self.maps_of]
+        self.n2_of = [len(ms) - n0 for ms, n0 in zip(self.maps_of, self.n0_of)]
+        self.ncomp_of = [n0 + 2 * n2 for n0, n2 in zip(self.n0_of, self.n2_of)]
+        # alm buffer: all spin-0 components (rank by rank), then all spin-2 components
+        self.nc0, self.nc2 = sum(self.n0_of), 2 * sum(self.n2_of)
+        self.comps_of_map = {}
+        c0, c2 = 0, self.nc0
+        for r, ms in enumerate(self.maps_of):
+            for g in ms:
+                if self.spins[g] == 0:
+                    self.comps_of_map[g] = [c0]
+                    c0 += 1
+                else:
+                    self.comps_of_map[g] = [c2, c2 + 1]
+                    c2 += 2
+        ncomp = lambda g: 2 if self.spins[g] else 1  # noqa: E731
+        self.pairs = map_pairs(nmaps)
+        self.row0, n = {}, 0
+        for (i, j) in self.pairs:
+            self.row0[i, j] = n
+            n += ncomp(i) * ncomp(j)
+        self.nrows = n
+        self.cpairs = [(a, b) for (i, j) in self.pairs for a in self.comps_of_map[i] for b in self.comps_of_map[j]]
+        cost0, cost2 = stages.m_cost()
+        # the m-ranges are shared by both spins (a cross spectrum needs both partners' m on one rank): cost of an m = its
+        # columns x ring blocks x l blocks, 2 real columns per spin-0 component, and a spin-2 component costs 3/2 of a spin-0 one
+        self.bounds = m_ranges(self.nc0 * np.asarray(cost0) + 1.5 * self.nc2 * np.asarray(cost2) + 1e-9, world)
+        self.m0, self.m1 = self.bounds[rank], self.bounds[rank + 1]
+        self._alm = None
+
+    @property
+    def local_maps(self):
+        """Global indices of this rank's maps: spin-0 maps first, then spin-2 maps."""
+        return self.maps_of[self.rank]
+
+    def buffer(self):
+        """(nc0 + nc2, nlm) alms of ALL components; only the orders of this rank's range are non-zero."""
+        if self._alm is None:
+            self._alm = self.stages.zeros_alm(self.nc0 + self.nc2, self.nlm)
+        return self._alm
+
+    def _all_to_all(self, send_blocks):
+        """send_blocks[q]: flat float64 tensor for rank q -> list recv[s]: what rank s sent to this rank."""
+        import torch
+        import torch.distributed as dist
+
+        sizes_out = [self.ncomp_of[s] * self.stages.modes_size(self.m0, self.m1) for s in range(self.world)]
+        if self.world == 1:
+            return [send_blocks[0]]
+        gloo = dist.get_backend(self.group) == "gloo"
+        send = torch.cat([b.reshape(-1) for b in send_blocks])
+        if gloo and send.is_cuda:
+            send = send.cpu()
+        recv = torch.empty(sum(sizes_out), dtype=torch.float64, device=send.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=sizes_out, input_split_sizes=[int(b.numel()) for b in send_blocks], group=self.group)
+        if gloo and send_blocks[0].is_cuda:
+            recv = recv.to(send_blocks[0].device)
+        elif recv.is_cuda:
+            torch.cuda.current_stream(recv.device).synchronize()
+        out, o = [], 0
+        for s in range(self.world):
+            out.append(recv[o : o + sizes_out[s]])
+            o += sizes_out[s]
+        return out
+
+    def run(self, maps0, maps2, pix_weights=None, ring_weights=None):
+        """maps0 (n0_local, npix), maps2 (n2_local, 2, npix): this rank's maps.  Returns on EVERY rank the array
+        (n_component_pairs_total, lmax + 1) ordered by map pair (combinations_with_replacement order) then component block."""
+        import torch
+
+        n0, n2 = self.n0_of[self.rank], self.n2_of[self.rank]
+        npix = maps0.shape[-1] if n0 else maps2.shape[-1]
+        cat = torch.cat if hasattr(maps0 if n0 else maps2, "data_ptr") else np.concatenate
+        parts = ([maps0.reshape(n0, npix)] if n0 else []) + ([maps2.reshape(2 * n2, npix)] if n2 else [])
+        local = cat(parts) if len(parts) > 1 else parts[0]
+        send = self.stages.ring_modes(local, self.bounds, pix_weights=pix_weights, ring_weights=ring_weights)
+        recv = self._all_to_all([self.stages.to_exchange(b) for b in send])
+        size = self.stages.modes_size(self.m0, self.m1)
+        blocks0, blocks2 = [], []
+        for s in range(self.world):
+            for c in range(self.ncomp_of[s]):
+                (blocks0 if c < self.n0_of[s] else blocks2).append(recv[s][c * size : (c + 1) * size])
+        alm = self.buffer()
+        self.stages.legendre(0, blocks0, self.m0, self.m1, alm[: self.nc0])
+        self.stages.legendre(2, blocks2, self.m0, self.m1, alm[self.nc0 :])
+        self.stages.synchronize()
+        comps = [alm[k] for k in range(alm.shape[0])]
+        # this rank's orders only: the alms are zero elsewhere; a kernel that takes the range does not even read them there
+        try:
+            part = self.kernel(comps, self.cpairs, self.lmax, m_range=(self.m0, self.m1))
+        except TypeError:
+            part = self.kernel(comps, self.cpairs, self.lmax)
+        part = np.ascontiguousarray(part, dtype=np.float64)
+        if self.world > 1:
+            import torch.distributed as dist
+
+            gloo = dist.get_backend(self.group) == "gloo"
+            t = torch.from_numpy(part)
+            if not gloo:
+                t = t.to(alm.device)
+            dist.all_reduce(t, group=self.group)  # alm2cl is a sum over m: the partial spectra add up
+            part = t.cpu().numpy()
+        return part

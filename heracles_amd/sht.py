@@ -106,6 +106,38 @@ class Plan:
                                           _lib.ptr(rw), _lib.ptr(pw), _lib.ptr(flv), int(niter)))
         return out
 
+    def map2alm_multi(self, jobs, *, ring_weights=None, pix_weights=None):
+        """Several transforms in one call: ``jobs`` = [(maps, spin, out_or_None[, fl])]; host maps of all jobs share one upload
+        pipeline (uploads of the next sweep overlap the transform of the current one across jobs).  Returns the list of alms.
+        Put the large jobs first: what stays exposed behind the last uploaded byte is the transform of the last sweep."""
+        import ctypes as C
+
+        n = len(jobs)
+        keep, outs = [], []
+        spins, ncomps = (C.c_int * n)(), (C.c_int * n)()
+        pm, pa, pf = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+        for j, job in enumerate(jobs):
+            maps, spin, out = job[0], job[1], job[2]
+            fl = job[3] if len(job) > 3 else None
+            maps = self._prep(maps, np.float64)
+            if maps.shape[-1] != self.npix:
+                raise ValueError(f"map has {maps.shape[-1]} pixels, plan expects {self.npix}")
+            lead = tuple(maps.shape[:-1])
+            nc = int(np.prod(lead)) if lead else 1
+            if out is None:
+                out = self._out_like(maps, lead + (self.nlm,), True)
+            flv = self._prep(fl, np.float64)
+            if flv is not None and flv.shape[-1] != self.lmax + 1:
+                raise ValueError("fl must have lmax+1 entries")
+            keep += [maps, flv]
+            outs.append(out)
+            spins[j], ncomps[j] = int(spin), nc
+            pm[j], pa[j], pf[j] = _lib.ptr(maps), _lib.ptr(out), _lib.ptr(flv)
+        rw = self._prep(ring_weights, np.float64)
+        pw = self._prep(pix_weights, np.float64)
+        _lib.check(_lib.load().hx_map2alm_multi(self._h, n, spins, ncomps, pm, pa, _lib.ptr(rw), _lib.ptr(pw), pf))
+        return outs
+
     def alm2map(self, alms, spin=0, *, out=None):
         alms = self._prep(alms, np.complex128)
         lead = tuple(alms.shape[:-1])

@@ -31,11 +31,12 @@ def _is_tensor(a):
     return hasattr(a, "data_ptr") and not isinstance(a, np.ndarray)
 
 
-def alm2cl_pairs(comps, pairs, lmax_out):
+def alm2cl_pairs(comps, pairs, lmax_out, m_range=None):
     """All requested component-pair spectra in one launch.
 
     comps: list of 1-D complex128 arrays (numpy, or torch CUDA tensors); pairs: list of
     (i, j) indices into comps.  Returns a float64 array (npairs, lmax_out+1).
+    m_range = (m0, m1): the sum over the orders m0 <= m < m1 only (a rank's share on the m-sharded route).
     """
     L = _lib.load()
     _lib.ensure_init()
@@ -55,8 +56,10 @@ def alm2cl_pairs(comps, pairs, lmax_out):
     pi = (C.c_int * max(npairs, 1))(*[p[0] for p in pairs])
     pj = (C.c_int * max(npairs, 1))(*[p[1] for p in pairs])
     out = np.zeros((npairs, lmax_out + 1))
-    if npairs:
+    if npairs and m_range is None:
         _lib.check(L.hx_alm2cl_pairs(ncomp, lmaxs, ptrs, int(lmax_out), npairs, pi, pj, _lib.ptr(out)))
+    elif npairs:
+        _lib.check(L.hx_alm2cl_pairs_range(ncomp, lmaxs, ptrs, int(lmax_out), npairs, pi, pj, int(m_range[0]), int(m_range[1]), _lib.ptr(out)))
     return out
 
 

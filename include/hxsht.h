@@ -102,6 +102,27 @@ int hx_map2alm(hx_plan *plan, int spin, int ncomp, const double *maps, double *a
                const double *ring_weights, const double *pix_weights, const double *fl,
                int niter);
 int hx_alm2map(hx_plan *plan, int spin, int ncomp, const double *alms, double *maps);
+/* The loop of heracles/mapping.py:151-172 (one transform per (field, bin) map) as ONE call over njobs transforms
+ * (spins[j], ncomps[j], maps[j], alms[j], fls[j] as in hx_map2alm; fls may be NULL; niter = 0): host maps of all jobs share one
+ * upload pipeline, so that the uploads of job j + 1 overlap the transforms of job j and the call costs its PCIe time plus one small
+ * transform.  Put large jobs first.  Results are those of njobs hx_map2alm calls up to the rounding of different sweep sizes. */
+int hx_map2alm_multi(hx_plan *plan, int njobs, const int *spins, const int *ncomps, const double *const *maps, double *const *alms,
+                     const double *ring_weights, const double *pix_weights, const double *const *fls);
+
+/* ---- the two halves of hx_map2alm, for the m-sharded multi-GPU route (heracles/mapping.py:151-172 and
+ * heracles/twopoint.py:198-215 are the loops it shards) -------------------------------------------------------------------
+ * hx_ring_modes: ring Fourier stage of ncomp maps; for every range q < nranges of orders [mbounds[q], mbounds[q+1]) the block
+ *   outs[q][comp][m - mbounds[q]][nrp_pad][4] = (F_N.re, F_N.im, F_S.re, F_S.im)(m, ring pair) with ring phase, pixel and ring
+ *   weights applied (DEVICE buffers of ncomp * hx_ring_modes_size doubles) -- what is sent to the rank that owns the range.
+ * hx_legendre_from_modes: Legendre stage of ALL ncomp components of one spin for the orders [m0, m1): comp_modes[c] points to
+ *   component c's block [m1 - m0][nrp_pad][4] (as received); writes alm[c][idx(l, m)] for m in the range ONLY (device buffer).
+ * hx_plan_m_cost: relative cost of every order m (for cutting [0, lmax] into ranges of equal work). */
+int hx_plan_m_cost(hx_plan *plan, int spin, double *cost);
+int64_t hx_ring_modes_size(const hx_plan *plan, int m0, int m1);
+int hx_ring_modes(hx_plan *plan, int ncomp, const double *maps, const double *pix_weights, const double *ring_weights, int nranges,
+                  const int *mbounds, double *const *outs);
+int hx_legendre_from_modes(hx_plan *plan, int spin, int ncomp, const double *const *comp_modes, int m0, int m1, double *alms,
+                           const double *fl);
 
 /* ---- two-point reduction -------------------------------------------------------- */
 /* Replaces heracles.twopoint.alm2cl (heracles/twopoint.py:63-101) for a whole list of
@@ -109,6 +130,10 @@ int hx_alm2map(hx_plan *plan, int spin, int ncomp, const double *alms, double *m
  * cls is [npairs][lmax_out+1]; requires lmax_out <= min over used components.         */
 int hx_alm2cl_pairs(int ncomp, const int *lmax_i, const double *const *alms, int lmax_out,
                     int npairs, const int *pair_i, const int *pair_j, double *cls);
+/* The same sum over the orders m0 <= m < m1 only (still divided by 2l + 1): partial spectra of disjoint ranges add up to
+ * hx_alm2cl_pairs -- a rank's contribution on the m-sharded multi-GPU route (the loop of heracles/twopoint.py:90-99 cut by m). */
+int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double *const *alms, int lmax_out, int npairs, const int *pair_i,
+                          const int *pair_j, int m0, int m1, double *cls);
 
 /* ---- mixing matrices / Wigner-d ------------------------------------------------- */
 /* Gauss-Legendre nodes (ascending) and weights; the `gauss_legendre` hook of

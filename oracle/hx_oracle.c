@@ -607,6 +607,25 @@ int hxo_map2alm(int nside, int lmax, int spin, int ncomp, const double *maps, cp
     return 0;
 }
 
+/* The two stages of hxo_map2alm on their own (checker of the m-sharded multi-GPU route, tests/test_distributed_cpu.py):
+ * F[comp][ring][m] = ring Fourier stage (all 4 nside - 1 rings, m <= lmax); alm = Legendre stage of a given F. */
+int hxo_fourier_analysis(int nside, int lmax, int ncomp, const double *maps, const double *pix_weights, cplx *F)
+{
+    geom g = make_geom(nside);
+    fourier_analysis(&g, lmax, ncomp, maps, pix_weights, 1, F);
+    free_geom(&g);
+    return 0;
+}
+
+int hxo_legendre_analysis(int nside, int lmax, int spin, int ncomp, const cplx *F, const double *ring_weights, cplx *alms)
+{
+    if ((spin != 0 && spin != 2) || (spin == 2 && (ncomp & 1))) return -1;
+    geom g = make_geom(nside);
+    legendre_analysis(&g, lmax, spin, ncomp, F, ring_weights, alms, 0);
+    free_geom(&g);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------
  * Adjoint synthesis at arbitrary points -- the operation heracles/ducc.py:121-128 asks of
  * ducc0.sht.adjoint_synthesis_general (ducc0 is third-party and absent from the reference tree; the reference holds

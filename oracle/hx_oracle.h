@@ -79,6 +79,10 @@ void hxo_mixmat(const double *cl, int l1max, int l2max, int l3max, int s1, int s
 /* three matrices: [0] EE->EE, [1] EE->BB, [2] EB->EB */
 void hxo_mixmat_eb(const double *cl, int l1max, int l2max, int l3max, double *out);
 
+/* the two stages of hxo_map2alm on their own: F[comp][ring][m] (4 nside - 1 rings, m <= lmax), alm from a given F */
+int hxo_fourier_analysis(int nside, int lmax, int ncomp, const double *maps, const double *pix_weights, double _Complex *F);
+int hxo_legendre_analysis(int nside, int lmax, int spin, int ncomp, const double _Complex *F, const double *ring_weights, double _Complex *alms);
+
 int hxo_num_threads(void);
 /* bench sampling: process only every s-th m in the Legendre stage of map2alm (default 1) */
 void hxo_set_mstride(int s);

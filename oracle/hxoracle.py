@@ -454,3 +454,24 @@ def expand_full_weights(nside, wgt):
         vpix += wpix
     assert vpix == wgt.size and (out != 0).all()
     return out
+
+
+def fourier_analysis(maps, nside, lmax, pix_weights=None):
+    """Ring Fourier stage of map2alm alone: F[comp][ring][m], all 4 nside - 1 rings, m <= lmax (checker of the m-sharded route)."""
+    maps = np.ascontiguousarray(maps, dtype=np.float64).reshape(-1, 12 * nside * nside)
+    F = np.zeros((maps.shape[0], 4 * nside - 1, lmax + 1), dtype=np.complex128)
+    pw = None if pix_weights is None else np.ascontiguousarray(pix_weights, dtype=np.float64)
+    lib().hxo_fourier_analysis(C.c_int(nside), C.c_int(lmax), C.c_int(maps.shape[0]), _p(maps), _p(pw) if pw is not None else None, _p(F))
+    return F
+
+
+def legendre_analysis(F, nside, lmax, spin=0, ring_weights=None):
+    """Legendre stage of map2alm alone on a given F[comp][ring][m]: alm[comp][nlm]."""
+    F = np.ascontiguousarray(F, dtype=np.complex128)
+    alms = np.zeros((F.shape[0], nlm(lmax)), dtype=np.complex128)
+    rw = None if ring_weights is None else np.ascontiguousarray(ring_weights, dtype=np.float64)
+    rc = lib().hxo_legendre_analysis(C.c_int(nside), C.c_int(lmax), C.c_int(spin), C.c_int(F.shape[0]), _p(F), _p(rw) if rw is not None else None,
+                                     _p(alms))
+    if rc != 0:
+        raise ValueError(f"hxo_legendre_analysis failed ({rc})")
+    return alms

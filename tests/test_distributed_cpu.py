@@ -135,3 +135,138 @@ def test_partition_covers_all_pairs():
                 assert max(touched) < 30 and sum(touched) / world <= 22, touched
                 counts = [len(w.my_cpairs) for w in ws]
                 assert max(counts) <= 1.5 * sum(counts) / world, counts
+
+
+# ---- m-sharded route (MShardedTwoPoint): ring modes -> all-to-all -> Legendre on an m-range -> partial Cl -> all-reduce --------
+MS_NSIDE, MS_LMAX = 4, 9
+
+
+class OracleStages:
+    """The two halves of the transform from the oracle (hxo_fourier_analysis / hxo_legendre_analysis), CPU tensors: stands in for
+    HipStages so that the sharding logic -- ranges, block order, all-to-all splits, all-reduce -- runs under gloo without a GPU."""
+
+    def __init__(self, nside, lmax):
+        self.nside, self.lmax = nside, lmax
+        self.nr = 4 * nside - 1
+
+    def m_cost(self):
+        c = np.array([(self.lmax - m + 1.0) for m in range(self.lmax + 1)])
+        return c, c
+
+    def modes_size(self, m0, m1):
+        return self.nr * (m1 - m0) * 2
+
+    def ring_modes(self, maps, bounds, pix_weights=None, ring_weights=None):
+        import torch
+
+        from oracle import hxoracle as ho
+
+        assert ring_weights is None
+        F = ho.fourier_analysis(np.asarray(maps), self.nside, self.lmax, pix_weights=pix_weights)  # [comp][ring][m]
+        return [torch.from_numpy(np.ascontiguousarray(F[:, :, bounds[q] : bounds[q + 1]]).view(np.float64).reshape(-1)) for q in range(len(bounds) - 1)]
+
+    def legendre(self, spin, blocks, m0, m1, alm_out):
+        import torch
+
+        from oracle import hxoracle as ho
+
+        if not blocks or m1 <= m0:
+            return
+        F = np.zeros((len(blocks), self.nr, self.lmax + 1), dtype=np.complex128)
+        for c, b in enumerate(blocks):
+            F[c, :, m0:m1] = b.numpy().view(np.complex128).reshape(self.nr, m1 - m0)
+        alm = ho.legendre_analysis(F, self.nside, self.lmax, spin=spin)
+        for m in range(m0, m1):  # only the orders of the range are written
+            base = m * (2 * self.lmax + 1 - m) // 2
+            alm_out[:, base + m : base + self.lmax + 1] = torch.from_numpy(alm[:, base + m : base + self.lmax + 1])
+
+    def zeros_alm(self, ncomp, nlm):
+        import torch
+
+        return torch.zeros((ncomp, nlm), dtype=torch.complex128)
+
+    def to_exchange(self, t):
+        return t
+
+    def synchronize(self):
+        pass
+
+
+def _ms_map(g, spin):
+    rng = np.random.default_rng(7000 + g)
+    return rng.standard_normal(((2,) if spin else ()) + (12 * MS_NSIDE**2,))
+
+
+def _ms_worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+
+    from heracles_amd.distributed import MShardedTwoPoint
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nlm = (MS_LMAX + 1) * (MS_LMAX + 2) // 2
+    work = MShardedTwoPoint(SPINS, world, rank, nlm, MS_LMAX, OracleStages(MS_NSIDE, MS_LMAX), kernel=_kernel)
+    mine = work.local_maps
+    m0 = np.array([_ms_map(g, 0) for g in mine if SPINS[g] == 0]).reshape(-1, 12 * MS_NSIDE**2)
+    m2 = np.array([_ms_map(g, 2) for g in mine if SPINS[g] == 2]).reshape(-1, 2, 12 * MS_NSIDE**2)
+    pw = 1.0 + 0.01 * np.cos(np.arange(12 * MS_NSIDE**2))
+    for _ in range(2):  # the second step reuses the alm buffer
+        res = work.run(torch.from_numpy(m0), torch.from_numpy(m2), pix_weights=pw)
+    np.save(os.path.join(outdir, f"msharded_{rank}.npy"), res)
+    np.save(os.path.join(outdir, f"bounds_{rank}.npy"), np.array(work.bounds))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_m_sharded_equals_single(tmp_path, world):
+    """The m-sharded job returns, on every rank, the spectra of the single-process job over all maps (the sum over m is split
+    between the ranks: equal to rounding, 1e-12)."""
+    import torch
+    import torch.multiprocessing as mp
+
+    from heracles_amd.distributed import MShardedTwoPoint
+    from oracle import hxoracle as ho
+
+    mp.spawn(_ms_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    pw = 1.0 + 0.01 * np.cos(np.arange(12 * MS_NSIDE**2))
+    alms = [np.atleast_2d(ho.map2alm(_ms_map(g, s), MS_NSIDE, MS_LMAX, spin=s, pix_weights=pw)) for g, s in enumerate(SPINS)]
+    rows = []
+    for i in range(len(SPINS)):
+        for j in range(i, len(SPINS)):
+            for a in alms[i]:
+                for b in alms[j]:
+                    rows.append(ho.alm2cl(a, b, lmax=MS_LMAX))
+    ref = np.array(rows)
+    for r in range(world):
+        got = np.load(tmp_path / f"msharded_{r}.npy")
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-13 * np.abs(ref).max())
+        b = np.load(tmp_path / f"bounds_{r}.npy")
+        assert b[0] == 0 and b[-1] == MS_LMAX + 1 and (np.diff(b) > 0).all() and len(b) == world + 1
+    # world == 1: no communication, same answer
+    nlm = (MS_LMAX + 1) * (MS_LMAX + 2) // 2
+    one = MShardedTwoPoint(SPINS, 1, 0, nlm, MS_LMAX, OracleStages(MS_NSIDE, MS_LMAX), kernel=_kernel)
+    m0 = np.array([_ms_map(g, 0) for g in one.local_maps if SPINS[g] == 0])
+    m2 = np.array([_ms_map(g, 2) for g in one.local_maps if SPINS[g] == 2])
+    np.testing.assert_allclose(one.run(torch.from_numpy(m0), torch.from_numpy(m2), pix_weights=pw), ref, rtol=1e-12, atol=1e-13 * np.abs(ref).max())
+
+
+def test_m_ranges_balance_the_cost():
+    from heracles_amd.distributed import assign_maps_by_components, m_ranges
+
+    lmax = 6144
+    cost = (lmax + 1.0 - np.arange(lmax + 1)) * np.minimum(1.0, 0.2 + np.arange(lmax + 1)[::-1] / lmax)
+    for world in (1, 2, 4, 8):
+        b = m_ranges(cost, world)
+        assert b[0] == 0 and b[-1] == lmax + 1 and len(b) == world + 1 and all(b[q + 1] > b[q] for q in range(world))
+        loads = [cost[b[q] : b[q + 1]].sum() for q in range(world)]
+        assert max(loads) <= 1.02 * sum(loads) / world, (world, loads)
+    assert m_ranges(np.ones(3), 8)[-1] == 3  # more ranks than orders: trailing ranges are empty, nothing is lost
+    # ring Fourier stage: components dealt evenly (30 components of the north-star job: 4, 4, 4, 4, 4, 4, 3, 3 on 8 ranks)
+    spins = [0] * 10 + [2] * 10
+    owner = assign_maps_by_components(spins, 8)
+    loads = [sum((2 if spins[g] else 1) for g in range(20) if owner[g] == r) for r in range(8)]
+    assert sum(loads) == 30 and max(loads) - min(loads) <= 1, loads

@@ -115,3 +115,21 @@ def test_mixed_lmax_in_one_call(oracle):
     np.testing.assert_array_equal(out[0], out[1])
     with pytest.raises(hx.HxError):
         hx.alm2cl_pairs(comps, [(0, 1)], 1000)  # a REQUESTED pair beyond its band limit is an error
+
+
+def test_m_range_partial_sums_add_up(oracle):
+    """hx_alm2cl_pairs_range: the spectra of disjoint m-ranges add up to the full sum (the m-sharded route's all-reduce)."""
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(321)
+    lmax = 70
+    nlm = (lmax + 1) * (lmax + 2) // 2
+    comps = [rng.standard_normal((nlm, 2)) @ [1, 1j] for _ in range(5)]
+    pairs = [(i, j) for i in range(5) for j in range(i, 5)]
+    full = hx.alm2cl_pairs(comps, pairs, lmax)
+    bounds = [0, 1, 9, 40, lmax + 1]
+    parts = [hx.alm2cl_pairs(comps, pairs, lmax, m_range=(bounds[q], bounds[q + 1])) for q in range(4)]
+    np.testing.assert_allclose(sum(parts), full, rtol=1e-13, atol=1e-15)
+    # the first range is m = 0 alone: Re a Re b / (2l + 1)
+    np.testing.assert_allclose(parts[0][3], comps[0][: lmax + 1].real * comps[3][: lmax + 1].real / (2 * np.arange(lmax + 1) + 1), rtol=1e-14)
+    assert not hx.alm2cl_pairs(comps, pairs, lmax, m_range=(5, 5)).any()

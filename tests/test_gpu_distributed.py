@@ -81,3 +81,94 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path):
     assert got.shape == ref.shape == (3 * 4 // 2 + 3 * 4 * 2 + 4 * 5 // 2 * 4, LMAX + 1)
     # a map's sweep differs with the number of maps a rank holds (other kernel variant, other summation order): not bitwise
     np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
+
+
+# ---- m-sharded route: hx_ring_modes -> (all-to-all) -> hx_legendre_from_modes on an m-range -> partial Cl -> all-reduce ----
+def _all_maps():
+    import torch
+
+    m0 = [_map_of(g, 0) for g, s in enumerate(SPINS) if s == 0]
+    m2 = [_map_of(g, 2) for g, s in enumerate(SPINS) if s == 2]
+    return torch.as_tensor(np.stack(m0)).cuda(), torch.as_tensor(np.stack(m2)).cuda()
+
+
+@pytest.mark.parametrize("nside,lmax", [(32, 64), (256, 400)])
+def test_modes_then_legendre_on_m_ranges_equals_map2alm(nside, lmax):
+    """The two halves of the transform as the m-sharded route uses them, in ONE process: the mode blocks of hx_ring_modes for a
+    partition of the orders into 5 uneven ranges, then hx_legendre_from_modes range by range into one alm buffer, give the alms
+    of hx_map2alm (same kernels, same operands: to rounding of nothing -- bit for bit).  At nside 256 polar pruning is active and
+    the scratch budget cuts every range into several m-chunks."""
+    import torch
+
+    import heracles_amd as hx
+    from heracles_amd.distributed import HipStages
+
+    rng = np.random.default_rng(11)
+    npix = 12 * nside**2
+    plan = hx.get_plan(nside, lmax)
+    st = HipStages(plan)
+    pw = torch.as_tensor(1.0 + 1e-2 * rng.standard_normal(npix)).cuda()
+    rw = torch.as_tensor(1.0 + 1e-2 * rng.standard_normal(2 * nside)).cuda()
+    bounds = [0, 1, 7, lmax // 3, lmax - 2, lmax + 1]
+    for spin, ncomp in ((0, 5), (2, 6), (0, 1), (2, 2), (0, 10)):
+        maps = torch.as_tensor(rng.standard_normal((ncomp, npix))).cuda()
+        ref = plan.map2alm(maps, spin, pix_weights=pw, ring_weights=rw)
+        blocks = st.ring_modes(maps, bounds, pix_weights=pw, ring_weights=rw)
+        alm = st.zeros_alm(ncomp, plan.nlm)
+        if nside >= 256:
+            hx._lib.set_scratch_budget(4e6)
+        try:
+            for q in range(len(bounds) - 1):
+                size = st.modes_size(bounds[q], bounds[q + 1])
+                st.legendre(spin, [blocks[q][c * size : (c + 1) * size] for c in range(ncomp)], bounds[q], bounds[q + 1], alm)
+        finally:
+            hx._lib.set_scratch_budget(0)
+        np.testing.assert_array_equal(alm.cpu().numpy(), ref.cpu().numpy())
+    c0, c2 = st.m_cost()
+    assert c0.shape == (lmax + 1,) and (c0 > 0).all() and (np.diff(c0) <= 0).all() and (c2 > 0).all()
+
+
+def _ms_worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+
+    import heracles_amd as hx
+    from heracles_amd.distributed import HipStages, MShardedTwoPoint
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    hx.init(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = hx.Plan(NSIDE, LMAX)
+    work = MShardedTwoPoint(SPINS, world, rank, plan.nlm, LMAX, HipStages(plan))
+    m0 = [_map_of(g, 0) for g in work.local_maps if SPINS[g] == 0]
+    m2 = [_map_of(g, 2) for g in work.local_maps if SPINS[g] == 2]
+    t0 = torch.as_tensor(np.stack(m0)).cuda() if m0 else torch.empty((0, 12 * NSIDE**2), dtype=torch.float64, device="cuda")
+    t2 = torch.as_tensor(np.stack(m2)).cuda() if m2 else torch.empty((0, 2, 12 * NSIDE**2), dtype=torch.float64, device="cuda")
+    for _ in range(2):
+        res = work.run(t0, t2)
+    np.save(os.path.join(outdir, f"ms_{rank}.npy"), res)
+    dist.barrier()
+    dist.destroy_process_group()
+    plan.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_m_sharded_ranks_on_one_gpu_equal_single_process(tmp_path, world):
+    """MShardedTwoPoint with the HIP stages on 2 / 3 ranks that share the one GPU (all-to-all and all-reduce over gloo through
+    host copies): every rank ends with the spectra of the single-process job."""
+    import torch.multiprocessing as mp
+
+    import heracles_amd as hx
+    from heracles_amd.distributed import ShardedTwoPoint
+
+    mp.spawn(_ms_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    plan = hx.get_plan(NSIDE, LMAX)
+    one = ShardedTwoPoint(SPINS, 1, 0, plan.nlm, LMAX)
+    _transform_local(one, plan)
+    ref = one.all_pairs_cl()
+    for r in range(world):
+        got = np.load(tmp_path / f"ms_{r}.npy")
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())

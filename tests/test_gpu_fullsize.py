@@ -251,3 +251,78 @@ def test_nside_8192_against_oracle_on_sampled_m(oracle):
             assert np.abs(got - exp).max() <= 1e-9 * max(np.abs(exp).max(), 1.0), rings[k]
     finally:
         plan.close()
+
+
+def test_config5_euclid_job_on_one_gpu(oracle):
+    """BASELINE configs[4] in its own shape on ONE GPU: 13 bins x (2 spin-0 + 1 spin-2) at nside 4096 / lmax 6144 = 39 maps / 52
+    components / 780 map pairs (sizes: heracles/examples/heracles.cfg:28-62; ~100 GB of maps and alms, 288 GB on the device).
+    Its sweeps -- 26 spin-0 maps = 13 + 13 (two 16-column groups each, the second partly filled), 13 spin-2 fields = 7 + 6 -- are
+    not the bench's: components of different sweeps and column groups against the oracle on every 512th m, spectra of map pairs
+    against a direct device-side sum, and the L = 6144 mixing matrices against the 3j oracle on a corner."""
+    import torch
+
+    import heracles_amd as hx
+    from heracles_amd import distributed as hxd
+
+    torch.cuda.empty_cache()
+    plan = hx.get_plan(NSIDE, LMAX)  # (the nside-8192 tests above release the module's plan to make room)
+    nb = 13
+    spins = [0] * (2 * nb) + [2] * nb
+    work = hxd.ShardedTwoPoint(spins, 1, 0, NLM, LMAX)
+    alm0, alm2 = work.local_alm_views("cuda")
+    g = torch.Generator(device="cuda").manual_seed(555)
+    maps0 = torch.randn((2 * nb, NPIX), dtype=torch.float64, device="cuda", generator=g)
+    maps2 = torch.randn((nb, 2, NPIX), dtype=torch.float64, device="cuda", generator=g)
+    plan.map2alm(maps0, 0, out=alm0)
+    plan.map2alm(maps2.view(2 * nb, NPIX), 2, out=alm2.view(2 * nb, NLM))
+    stride = 512
+
+    def check(got, x, spin, tag):
+        oracle.set_mstride(stride)
+        try:
+            ref = oracle.map2alm(x.cpu().numpy(), NSIDE, LMAX, spin=spin)
+        finally:
+            oracle.set_mstride(1)
+        got = got.cpu().numpy()
+        scale = np.abs(got).max()
+        for m in range(0, LMAX + 1, stride):
+            base = m * (2 * LMAX + 1 - m) // 2
+            sl = slice(base + m, base + LMAX + 1)
+            assert np.abs(got[:, sl] - ref[:, sl]).max() <= 1e-10 * scale, (tag, m)
+
+    # spin 0: map 9 (first sweep, second column group), map 20 (second sweep); spin 2: field 6 (first sweep, second group),
+    # field 12 (second sweep, last field)
+    check(alm0[9:10], maps0[9:10], 0, "spin0 map 9")
+    check(alm0[20:21], maps0[20:21], 0, "spin0 map 20")
+    check(alm2[6], maps2[6], 2, "spin2 field 6")
+    check(alm2[12], maps2[12], 2, "spin2 field 12")
+    del maps0, maps2
+    torch.cuda.empty_cache()
+    cls = work.all_pairs_cl()
+    assert len(work.pairs) == 780 and cls.shape == (work.nrows, LMAX + 1) and work.nrows == 26 * 27 // 2 + 26 * 13 * 2 + 4 * (13 * 14 // 2)
+    w = _mweights(torch)
+    idx_l = torch.cat([torch.arange(m, LMAX + 1, device="cuda") for m in range(LMAX + 1)])
+    buf = work.buffer()
+    nchk = 0
+    for (i, j) in ((0, 0), (3, 25), (25, 26), (12, 38), (30, 38), (38, 38)):
+        row = work.row0[i, j]
+        for ka, ca in enumerate(work.comps_of_map[i]):
+            for kb, cb in enumerate(work.comps_of_map[j]):
+                a, b_ = buf[ca], buf[cb]
+                ref = torch.zeros(LMAX + 1, dtype=torch.float64, device="cuda").index_add_(0, idx_l, w * (a.real * b_.real + a.imag * b_.imag))
+                ref = (ref / (2.0 * torch.arange(LMAX + 1, device="cuda") + 1.0)).cpu().numpy()
+                got = cls[row + ka * len(work.comps_of_map[j]) + kb]
+                assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max(), (i, j, ka, kb)
+                nchk += 1
+    assert nchk >= 8
+    del buf, w, idx_l, work, alm0, alm2
+    torch.cuda.empty_cache()
+    # mixing matrices of the job: L = 6144
+    L = LMAX
+    ell = np.arange(L + 1)
+    wl = 4 * np.pi * 0.35 * np.exp(-ell * (ell + 1) / 3000.0) + 1e-3 / (1.0 + ell) ** 2
+    eb = hx.mixmat_eb(wl)
+    assert eb.shape == (3, L + 1, L + 1)
+    np.testing.assert_allclose(eb[2], eb[0] - eb[1], atol=1e-12 * np.abs(eb[0]).max())
+    ref = oracle.mixmat_eb(wl, l1max=23, l2max=200)
+    np.testing.assert_allclose(eb[:, :24, :201], ref, atol=1e-12 * np.abs(ref).max())

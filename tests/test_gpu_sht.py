@@ -329,3 +329,40 @@ def test_split_bluestein_rings(oracle, nside, cap):
     close(back, oracle.alm2map(a0, nside, lmax), 1e-11)
     with pytest.raises(hx.HxError):
         hx._lib.check(L.hx_set_max_lds_fft(100))
+
+
+def test_map2alm_multi_matches_separate_calls(oracle):
+    """hx_map2alm_multi (the loop of heracles/mapping.py:151-172 as one call with one upload pipeline across jobs): device
+    inputs give bit-identical results to separate hx_map2alm calls; host inputs (cut into sweeps of <= 5 fields / 8 maps, the
+    last sweep halved down to <= 2 units) agree with them to rounding and with the oracle; pixel weights and fl are applied."""
+    import torch
+
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(2024)
+    nside, lmax = 32, 64
+    npix = 12 * nside**2
+    plan = hx.get_plan(nside, lmax)
+    m2 = rng.standard_normal((14, npix))   # 7 spin-2 fields: two sweeps (4 + 3 fields)
+    m0 = rng.standard_normal((11, npix))   # 11 spin-0 maps: 8 + 3, the last sweep halved: 2 + 1
+    pw = 1.0 + 1e-2 * rng.standard_normal(npix)
+    fl = 1.0 / (1.0 + 0.01 * np.arange(lmax + 1))
+    sep2 = plan.map2alm(m2, 2, pix_weights=pw)
+    sep0 = plan.map2alm(m0, 0, pix_weights=pw, fl=fl)
+    got2, got0 = plan.map2alm_multi([(m2, 2, None), (m0, 0, None, fl)], pix_weights=pw)
+    for got, sep in ((got2, sep2), (got0, sep0)):
+        assert np.abs(got - sep).max() <= 1e-13 * np.abs(sep).max()
+    close(got0[:3], oracle.map2alm(m0[:3], nside, lmax, spin=0, pix_weights=pw) * np.concatenate([fl[m:] for m in range(lmax + 1)]))
+    close(got2[-2:], oracle.map2alm(m2[-2:], nside, lmax, spin=2, pix_weights=pw))
+    # device-resident jobs: the sweeps of hx_map2alm itself, bit for bit; outputs written in place
+    d2, d0, dpw = torch.as_tensor(m2).cuda(), torch.as_tensor(m0).cuda(), torch.as_tensor(pw).cuda()
+    o2 = torch.empty((14, plan.nlm), dtype=torch.complex128, device="cuda")
+    o0 = torch.empty((11, plan.nlm), dtype=torch.complex128, device="cuda")
+    r2, r0 = plan.map2alm_multi([(d2, 2, o2), (d0, 0, o0)], pix_weights=dpw)
+    assert r2 is o2 and r0 is o0
+    np.testing.assert_array_equal(o2.cpu().numpy(), plan.map2alm(d2, 2, pix_weights=dpw).cpu().numpy())
+    np.testing.assert_array_equal(o0.cpu().numpy(), plan.map2alm(d0, 0, pix_weights=dpw).cpu().numpy())
+    # a mixed call: one host job, one device job
+    h2, e0 = plan.map2alm_multi([(m2[:2], 2, None), (d0, 0, None)], pix_weights=pw)
+    assert np.abs(h2 - sep2[:2]).max() <= 1e-13 * np.abs(sep2).max()
+    np.testing.assert_array_equal(e0.cpu().numpy(), o0.cpu().numpy())
