@@ -31,7 +31,7 @@ SYMBOLS = (
     "hx_mixmat_eb", "hx_mixmat_batch", "hx_mixctx_create", "hx_mixctx_apply", "hx_mixctx_destroy", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_alm_resample", "hx_region_maps", "hx_alm_subtract", "hx_fits_unpack_f64", "hx_fits_pack_f64",
     "hx_pointsht_create", "hx_pointsht_destroy", "hx_pointsht_info", "hx_pointsht_adjoint",
     "hx_pixel_weights_size", "hx_pixel_weights_expand",
-    "hx_plan_m_cost", "hx_ring_modes_size", "hx_ring_modes", "hx_legendre_from_modes",
+    "hx_ring_modes_size", "hx_ring_modes", "hx_legendre_from_modes",
 )
 
 
@@ -89,7 +89,7 @@ def load():
         L.hx_alm2map.argtypes = [vp, i, i, dp, dp]
         L.hx_map2alm_multi.argtypes = [vp, i, vp, vp, vp, vp, dp, dp, vp]
         L.hx_alm2cl_pairs.argtypes = [i, vp, vp, i, i, vp, vp, dp]
-        L.hx_alm2cl_pairs_range.argtypes = [i, vp, vp, i, i, vp, vp, i, i, dp]
+        L.hx_alm2cl_pairs_range.argtypes = [i, vp, vp, i, i, vp, vp, i, i, i, dp]
         L.hx_gauss_legendre.argtypes = [i, dp, dp]
         L.hx_wigner_d_table.argtypes = [i, i, i, i, dp, dp]
         L.hx_mixmat.argtypes = [dp, i, i, i, i, i, i, dp]
@@ -116,11 +116,10 @@ def load():
         L.hx_pointsht_destroy.restype = None
         L.hx_pointsht_info.argtypes = [vp, C.POINTER(C.c_int)]
         L.hx_pointsht_adjoint.argtypes = [vp, i, i, C.c_int64, dp, dp, dp]
-        L.hx_plan_m_cost.argtypes = [vp, i, dp]
-        L.hx_ring_modes_size.argtypes = [vp, i, i]
+        L.hx_ring_modes_size.argtypes = [vp, i]
         L.hx_ring_modes_size.restype = C.c_int64
-        L.hx_ring_modes.argtypes = [vp, i, dp, dp, dp, i, vp, vp]
-        L.hx_legendre_from_modes.argtypes = [vp, i, i, vp, i, i, dp, dp]
+        L.hx_ring_modes.argtypes = [vp, i, dp, dp, dp, i, vp, vp, i, vp]
+        L.hx_legendre_from_modes.argtypes = [vp, i, i, vp, i, i, i, dp, dp]
         L.hx_pixel_weights_size.argtypes = [i]
         L.hx_pixel_weights_size.restype = C.c_int64
         L.hx_pixel_weights_expand.argtypes = [i, C.c_int64, dp, dp]

@@ -61,7 +61,7 @@ struct LegParams {
     const LegTask *__restrict__ tasks;
     const double *__restrict__ F;      // [m - m0][rp][par][op][16*NG]
     double *__restrict__ partial;      // [row - row0][16*NG]
-    int m0;                            // first m of the chunk held in F
+    int m0, ms;                        // the chunk holds the orders m0 + k ms; F row block k
     long long row0;                    // first partial row of the chunk
     int ng;                            // active column groups (<= NG, + 1 if there are extra 4-column blocks)
     int ncol;                          // doubles per F / partial row: 16 per full group + 4 per extra block
@@ -82,13 +82,13 @@ struct LegParams {
 // Component c lives in column group c/8, slot c%8 (spin 2: field f = c/2 in group f/4).
 template <int SPIN>
 __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double2 *__restrict__ Y, int ncomp, int ng,
-                                                         int ncol, int m0, const double *__restrict__ rw,
+                                                         int ncol, int m0, int ms, const double *__restrict__ rw,
                                                          const LegTask *__restrict__ tasks, const MTasks *__restrict__ of_m,
                                                          double *__restrict__ F)
 {
     constexpr int NOP = LegCfg<SPIN>::NOP;
     __shared__ RingAtM ring_at_m[32];
-    const int m = m0 + blockIdx.x;
+    const int m = m0 + blockIdx.x * ms;
     // ring blocks in front of the first task of this m are pruned (m beyond what their rings resolve): their rows of F are
     // never read
     const MTasks mt = of_m[m];
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV < LegCfg<SPIN>::NW ? 2 : 1)) void k_
     {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const long long row = (long long)(m - A.m0) * P.nrp_pad + rb * RBLK + ringsel(q, ak);
+            const long long row = (long long)((m - A.m0) / A.ms) * P.nrp_pad + rb * RBLK + ringsel(q, ak);
 #pragma unroll
             for (int par = 0; par < 2; ++par)
 #pragma unroll
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV < LegCfg<SPIN>::NW ? 2 : 1)) void k_
     if (NBX > 0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const long long row = (long long)(m - A.m0) * P.nrp_pad + rb * RBLK + ringsel(q, ak);
+            const long long row = (long long)((m - A.m0) / A.ms) * P.nrp_pad + rb * RBLK + ringsel(q, ak);
 #pragma unroll
             for (int par = 0; par < 2; ++par)
 #pragma unroll
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
     // into the one span of rows the m owns (global_atomic_add_f64 without return, executed in this XCD's L2):
     // every row element is touched by one thread of one work-group only, in program order, so the sum over ring groups has
     // a fixed order (bit-reproducible) although no partial row per ring group ever exists in HBM.
-    const int m = A.m0 + blockIdx.x, lmax = P.lmax;
+    const int m = A.m0 + blockIdx.x * A.ms, lmax = P.lmax;
     const MTasks mt = A.of_m[m];
     const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
     const int off = (l0 + m) & 1;              // parity (l + m) & 1 of position 0
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
             const int op = SPIN == 0 ? 0 : sp & 1, q = SPIN == 0 ? sp : sp >> 1;
             const int rbi = SPIN == 0 ? 2 * (s * NW + w) + (q >> 3) : s * NW + w;
             const bool on = rbi < task.nrb;
-            const long long row = (long long)(m - A.m0) * P.nrp_pad + (task.rb0 + rbi) * RBLK + pipe_rho(q & 7, ak);
+            const long long row = (long long)blockIdx.x * P.nrp_pad + (task.rb0 + rbi) * RBLK + pipe_rho(q & 7, ak);
 #pragma unroll
             for (int pos = 0; pos < 2; ++pos) {
                 const double *f = A.F + ((row * 2 + (pos ^ off)) * NOP + op) * A.ncol;
@@ -1023,6 +1023,8 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         }
         HX_STAMP(7);
         lds_barrier();  // D tiles consumed: tileB may be overwritten by the recursion of the next stage
+        // (taking this barrier inside the next stage instead -- behind its first vector block, in front of its first store to tile B --
+        // was measured: 412 vs 401 ms for the 40-column sweep, 117.1 vs 115.5 for 10 spin-0 maps, same device: not kept)
         HX_STAMP(6);
     }
     if (DEFER && pend) {
@@ -1056,12 +1058,12 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
 template <int SPIN>
 __global__ __launch_bounds__(256) void k_alm_reduce(PlanDev P, const LegTask *__restrict__ tasks,
                                                     const MTasks *__restrict__ of_m,
-                                                    const double *__restrict__ partial, long long row0, int m0,
+                                                    const double *__restrict__ partial, long long row0, int m0, int ms,
                                                     int ncomp, int ng, int ncol, const double *__restrict__ fl, int add,
                                                     double2 *__restrict__ alm, long long alm_stride,
                                                     const long long *__restrict__ arow)
 {
-    const int m = m0 + blockIdx.x, lmax = P.lmax;
+    const int m = m0 + blockIdx.x * ms, lmax = P.lmax;
     const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
     const MTasks mt = of_m[m];
     const int nl = lmax - m + 1, nc = 8 * ng;
@@ -1519,10 +1521,11 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
     PlanDev P = pl->dev();
     const int t0 = ts.of_m[m0].first;
     const int t1 = ts.of_m[m1 - 1].first + ts.of_m[m1 - 1].count;
+    const int ms = std::max(pl->m_step, 1), nm = (m1 - m0 + ms - 1) / ms;  // the orders m0 + k ms < m1
     {
         ProfScope ps("fourier_combine");
-        dim3 grid(m1 - m0, pl->nrp_pad / 32);
-        hipLaunchKernelGGL(k_fourier_combine<SPIN>, grid, dim3(256), 0, st, P, pl->Y.as<double2>(), nb, ng, ncol, m0, d_rw,
+        dim3 grid(nm, pl->nrp_pad / 32);
+        hipLaunchKernelGGL(k_fourier_combine<SPIN>, grid, dim3(256), 0, st, P, pl->Y.as<double2>(), nb, ng, ncol, m0, ms, d_rw,
                            ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(), pl->F.as<double>());
     }
     if (t1 > t0) {
@@ -1530,7 +1533,7 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         ProfScope ps2(SPIN == 0 ? "legendre_analysis_s0" : "legendre_analysis_s2");
         LegParams A;
         A.P = P; A.tasks = ts.d_tasks.as<LegTask>() + t0; A.F = pl->F.as<double>(); A.partial = pl->partial.as<double>();
-        A.m0 = m0; A.row0 = ts.rows_before_m[m0]; A.ng = ng; A.ncol = ncol; A.pcol = pcol;
+        A.m0 = m0; A.ms = ms; A.row0 = ts.rows_before_m[m0]; A.ng = ng; A.ncol = ncol; A.pcol = pcol;
         A.ablate = 0;
         A.counters = nullptr;
         A.of_m = ts.d_of_m.as<MTasks>(); A.arow = ts.d_arow.as<long long>(); A.arow0 = ts.arow[m0];
@@ -1553,7 +1556,7 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         const double2 *cn = SPIN == 0 ? pl->cn0.as<double2>() : pl->cn2.as<double2>();
         const double *al = SPIN == 0 ? pl->al0.as<double>() : pl->al2.as<double>();
         constexpr int NW = LegCfg<SPIN>::NW;
-        dim3 grid((unsigned)(t1 - t0)), block(NW * 64), pblock(PipeCfg<SPIN>::NW * 64), pgrid((unsigned)(m1 - m0));
+        dim3 grid((unsigned)(t1 - t0)), block(NW * 64), pblock(PipeCfg<SPIN>::NW * 64), pgrid((unsigned)nm);
         constexpr int QSUB = SPIN == 2 ? HX_QSUB2 : HX_QSUB0;
         constexpr int QNW = SPIN == 0 ? HX_QNW0 : NW;  // waves per work-group of the 4x4x4 variants
         if (sh.quad == 1)
@@ -1601,8 +1604,8 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
     }
     {
         ProfScope ps("alm_reduce");
-        hipLaunchKernelGGL(k_alm_reduce<SPIN>, dim3(m1 - m0), dim3(256), 0, st, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
-                           pl->partial.as<double>(), sh.quad ? ts.rows_before_m[m0] : ts.arow[m0], m0, nb, ng, pcol, d_fl, add, d_alms, pl->nlm,
+        hipLaunchKernelGGL(k_alm_reduce<SPIN>, dim3(nm), dim3(256), 0, st, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
+                           pl->partial.as<double>(), sh.quad ? ts.rows_before_m[m0] : ts.arow[m0], m0, ms, nb, ng, pcol, d_fl, add, d_alms, pl->nlm,
                            sh.quad ? nullptr : ts.d_arow.as<long long>());
     }
     HX_HIP(hipGetLastError());
@@ -1644,18 +1647,20 @@ static int analysis_batch_valu(hx_plan *pl, int spin, int nb, const double *d_ma
     const std::vector<long long> &prow = ts.rows_before_m;
     std::vector<std::pair<int, int>> chunks;
     size_t maxF = 16, maxP = 16;
-    const int m_end = pl->m_hi < 0 ? lmax + 1 : std::min(pl->m_hi, lmax + 1);
+    // a chunk [m0, m1) holds the orders m0, m0 + ms, ... < m1 (ms = 1 but on the m-sharded route); m1 - 1 is its last order
+    const int m_end = pl->m_hi < 0 ? lmax + 1 : std::min(pl->m_hi, lmax + 1), ms = std::max(pl->m_step, 1);
     for (int m0 = std::max(pl->m_lo, 0); m0 < m_end;) {
-        int m1 = m0 + 1;
-        while (m1 < m_end) {
-            const double bytes = f_per_m * (m1 + 1 - m0) + (double)(prow[m1 + 1] - prow[m0]) * pcol * sizeof(double);
+        int last = m0;  // a chunk holds at least one m, whatever the budget
+        while (last + ms < m_end) {
+            const double bytes = f_per_m * ((last + ms - m0) / ms + 1) + (double)(prow[last + ms + 1] - prow[m0]) * pcol * sizeof(double);
             if (bytes > budget) break;
-            ++m1;
+            last += ms;
         }
+        const int m1 = last + 1;
         chunks.emplace_back(m0, m1);
-        maxF = std::max(maxF, (size_t)(f_per_m * (m1 - m0)));
+        maxF = std::max(maxF, (size_t)(f_per_m * ((m1 - m0 + ms - 1) / ms)));
         maxP = std::max(maxP, (size_t)(prow[m1] - prow[m0]) * pcol * sizeof(double));
-        m0 = m1;
+        m0 = last + ms;
     }
     HX_TRY(pl->F.alloc(maxF));
     HX_TRY(pl->partial.alloc(maxP));
@@ -1663,15 +1668,15 @@ static int analysis_batch_valu(hx_plan *pl, int spin, int nb, const double *d_ma
     PlanDev P = pl->dev();
     for (int c0 = 0; c0 < nb; c0 += unit)
         for (auto &ch : chunks) {
-            const int m0 = ch.first, m1 = ch.second;
+            const int m0 = ch.first, m1 = ch.second, nm = (m1 - m0 + ms - 1) / ms;
             HX_TRY(launch_valu_chunk(pl, spin, ts, m0, m1, c0, d_rw));
             ProfScope ps("alm_reduce");
             if (spin == 0)
-                hipLaunchKernelGGL(k_alm_reduce<0>, dim3(m1 - m0), dim3(256), 0, rt().stream, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
-                                   pl->partial.as<double>(), ts.rows_before_m[m0], m0, 1, 1, pcol, d_fl, add, d_alms + (size_t)c0 * pl->nlm, pl->nlm, nullptr);
+                hipLaunchKernelGGL(k_alm_reduce<0>, dim3(nm), dim3(256), 0, rt().stream, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
+                                   pl->partial.as<double>(), ts.rows_before_m[m0], m0, ms, 1, 1, pcol, d_fl, add, d_alms + (size_t)c0 * pl->nlm, pl->nlm, nullptr);
             else
-                hipLaunchKernelGGL(k_alm_reduce<2>, dim3(m1 - m0), dim3(256), 0, rt().stream, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
-                                   pl->partial.as<double>(), ts.rows_before_m[m0], m0, 2, 1, pcol, d_fl, add, d_alms + (size_t)c0 * pl->nlm, pl->nlm, nullptr);
+                hipLaunchKernelGGL(k_alm_reduce<2>, dim3(nm), dim3(256), 0, rt().stream, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
+                                   pl->partial.as<double>(), ts.rows_before_m[m0], m0, ms, 2, 1, pcol, d_fl, add, d_alms + (size_t)c0 * pl->nlm, pl->nlm, nullptr);
             HX_HIP(hipGetLastError());
         }
     return HX_OK;
@@ -1717,19 +1722,20 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     const int pcol = sh.oneset ? (ncol + 15) / 16 * 16 : ncol;  // doubles per row of the partial buffer (launch_chunk)
     std::vector<std::pair<int, int>> chunks;
     size_t maxF = 16, maxP = 16;
-    const int m_end = pl->m_hi < 0 ? lmax + 1 : std::min(pl->m_hi, lmax + 1);
+    // a chunk [m0, m1) holds the orders m0, m0 + ms, ... < m1 (ms = 1 but on the m-sharded route); m1 - 1 is its last order
+    const int m_end = pl->m_hi < 0 ? lmax + 1 : std::min(pl->m_hi, lmax + 1), ms = std::max(pl->m_step, 1);
     for (int m0 = std::max(pl->m_lo, 0); m0 < m_end;) {
-        int m1 = m0 + 1;  // a chunk holds at least one m, whatever the budget
-        while (m1 < m_end) {
-            const double bytes = f_per_m * (m1 + 1 - m0) +
-                                 (double)(prow[m1 + 1] - prow[m0]) * pcol * sizeof(double);
+        int last = m0;  // a chunk holds at least one m, whatever the budget
+        while (last + ms < m_end) {
+            const double bytes = f_per_m * ((last + ms - m0) / ms + 1) + (double)(prow[last + ms + 1] - prow[m0]) * pcol * sizeof(double);
             if (bytes > budget) break;
-            ++m1;
+            last += ms;
         }
+        const int m1 = last + 1;
         chunks.emplace_back(m0, m1);
-        maxF = std::max(maxF, (size_t)(f_per_m * (m1 - m0)));
+        maxF = std::max(maxF, (size_t)(f_per_m * ((m1 - m0 + ms - 1) / ms)));
         maxP = std::max(maxP, (size_t)(prow[m1] - prow[m0]) * pcol * sizeof(double));
-        m0 = m1;
+        m0 = last + ms;
     }
     HX_TRY(pl->F.alloc(maxF));
     HX_TRY(pl->partial.alloc(maxP));

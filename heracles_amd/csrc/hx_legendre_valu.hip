@@ -53,9 +53,9 @@ __device__ unsigned long long g_valu_flops;
 struct ValuParams {
     PlanDev P;
     const LegTask *__restrict__ tasks;  // tasks [t0, t1) of the m-chunk
-    const double *__restrict__ F;       // [m - m0][rp][NF]
+    const double *__restrict__ F;       // [(m - m0) / ms][rp][NF]
     double *__restrict__ partial;       // [row - row0][NA]
-    int m0;
+    int m0, ms;                         // the chunk holds the orders m0 + k ms (tasks of other orders in the list return at once)
     long long row0;
 };
 
@@ -68,12 +68,12 @@ struct ValuParams {
 // grid: x = m - m0, y = blocks of 256 ring pairs; one thread per ring pair.
 // =====================================================================================
 template <int SPIN>
-__global__ __launch_bounds__(256) void k_fourier_combine_valu(PlanDev P, const double2 *__restrict__ Y, int c0, int m0,
+__global__ __launch_bounds__(256) void k_fourier_combine_valu(PlanDev P, const double2 *__restrict__ Y, int c0, int m0, int ms,
                                                               const double *__restrict__ rw, const LegTask *__restrict__ tasks,
                                                               const MTasks *__restrict__ of_m, double *__restrict__ F)
 {
     constexpr int NF = ValuCfg<SPIN>::NF;
-    const int m = m0 + blockIdx.x;
+    const int m = m0 + blockIdx.x * ms;
     const MTasks mt = of_m[m];
     if (mt.count == 0 || ((int)blockIdx.y + 1) * 256 <= tasks[mt.first].rb0 * RBLK) return;  // pruned ring pairs: never read
     const int rp = blockIdx.y * 256 + threadIdx.x;
@@ -193,6 +193,7 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_valu(ValuParams 
     const PlanDev &P = A.P;
     const LegTask task = A.tasks[blockIdx.x];
     const int m = task.m, lmax = P.lmax, lane = threadIdx.x;
+    if ((m - A.m0) % A.ms) return;       // an order of another rank (m-sharded route: every ms-th order is ours)
     const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
     const int off = (l0 + m) & 1;        // parity of l + m at the first l (spin 2, m = 1 only)
     const long long cb = almidx(lmax, 0, m);
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_valu(ValuParams 
 
     // ---- rings, operands, seeds ----
     double xx[R], vc[R][NCH], vp[R][NCH], f[R][NF];
-    const double *fm = A.F + (long long)(m - A.m0) * P.nrp_pad * NF;  // operand rows of this m: [rp][NF]
+    const double *fm = A.F + (long long)((m - A.m0) / A.ms) * P.nrp_pad * NF;  // operand rows of this m: [rp][NF]
     int sc[R][NCH];
     unsigned vmask = 0;
 #pragma unroll
@@ -426,10 +427,11 @@ static int launch_valu_chunk_t(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1
     PlanDev P = pl->dev();
     const int t0 = ts.of_m[m0].first;
     const int t1 = ts.of_m[m1 - 1].first + ts.of_m[m1 - 1].count;
+    const int ms = std::max(pl->m_step, 1);
     {
         ProfScope ps("fourier_combine");
-        dim3 grid(m1 - m0, (pl->nrp_pad + 255) / 256);
-        hipLaunchKernelGGL(k_fourier_combine_valu<SPIN>, grid, dim3(256), 0, st, P, pl->Y.as<double2>(), c0, m0, d_rw,
+        dim3 grid((m1 - m0 + ms - 1) / ms, (pl->nrp_pad + 255) / 256);
+        hipLaunchKernelGGL(k_fourier_combine_valu<SPIN>, grid, dim3(256), 0, st, P, pl->Y.as<double2>(), c0, m0, ms, d_rw,
                            ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(), pl->F.as<double>());
     }
     if (t1 > t0) {
@@ -438,7 +440,7 @@ static int launch_valu_chunk_t(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1
         ProfScope ps3("legendre_valu");
         ValuParams A;
         A.P = P; A.tasks = ts.d_tasks.as<LegTask>() + t0; A.F = pl->F.as<double>(); A.partial = pl->partial.as<double>();
-        A.m0 = m0; A.row0 = ts.rows_before_m[m0];
+        A.m0 = m0; A.ms = ms; A.row0 = ts.rows_before_m[m0];
         const double2 *cn = SPIN == 0 ? pl->cn0.as<double2>() : pl->cn2.as<double2>();
         const double *al = SPIN == 0 ? pl->al0.as<double>() : pl->al2.as<double>();
         hipLaunchKernelGGL(k_legendre_valu<SPIN>, dim3((unsigned)(t1 - t0)), dim3(64), 0, st, A, cn, al);

@@ -17,14 +17,18 @@
 namespace hx {
 using namespace hxfft;
 
-// out[(c (m1 - m0) + (m - m0)) nrp_pad + rp] = (F_N.re, F_N.im, F_S.re, F_S.im) of component c0 + c
-// grid: x = m - m0, y = blocks of 256 ring pairs; one thread per ring pair, looping over the components of the batch
-__global__ __launch_bounds__(256) void k_ring_modes(PlanDev P, const double2 *__restrict__ Y, int nb, int c0, int ncomp, int m0, int m1,
+// A set of orders is (first, count, step): m = first + k step, k < count.  Rank q of N owns (q, ., N): every rank gets work-groups
+// of every length (the cost of an order falls steadily with m) and as many of them as one GPU's launch / N -- contiguous ranges of
+// equal cost gave the rank of the lowest orders 317 work-groups for 256 compute units (108 ms against 78 on the others).
+//
+// out[(c count + k) nrp_pad + rp] = (F_N.re, F_N.im, F_S.re, F_S.im) of component c0 + c at order first + k step
+// grid: x = k, y = blocks of 256 ring pairs; one thread per ring pair, looping over the components of the batch
+__global__ __launch_bounds__(256) void k_ring_modes(PlanDev P, const double2 *__restrict__ Y, int nb, int c0, int first, int count, int step,
                                                     const double *__restrict__ rw, const LegTask *__restrict__ tasks,
                                                     const MTasks *__restrict__ of_m, const LegTask *__restrict__ tasks2,
                                                     const MTasks *__restrict__ of_m2, double4 *__restrict__ out)
 {
-    const int m = m0 + blockIdx.x;
+    const int m = first + blockIdx.x * step;
     const MTasks mt = of_m[m], mt2 = of_m2[m];
     // ring pairs in front of the first task of this m -- of the spin-0 AND of the spin-2 list: their pruning limits differ by a
     // ring or two -- are pruned by every Legendre kernel: never read by the receiver
@@ -38,48 +42,35 @@ __global__ __launch_bounds__(256) void k_ring_modes(PlanDev P, const double2 *__
     for (int c = 0; c < nb; ++c) {
         double2 fn = make_double2(0.0, 0.0), fs = fn;
         if (rp < P.nrp) ring_modes_ns(P, Y, c, rp, m, ram, fn, fs);
-        out[((long long)(c0 + c) * (m1 - m0) + (m - m0)) * P.nrp_pad + rp] = make_double4(fn.x, fn.y, fs.x, fs.y);
+        out[((long long)(c0 + c) * count + blockIdx.x) * P.nrp_pad + rp] = make_double4(fn.x, fn.y, fs.x, fs.y);
     }
-    (void)ncomp;
 }
 
 }  // namespace hx
 
 using namespace hx;
 
-// Relative cost of order m in the Legendre stage (ring blocks that are not pruned x 32-l blocks), for cutting [0, lmax] into
-// ranges of equal work.
-extern "C" int hx_plan_m_cost(hx_plan *pl, int spin, double *cost)
+static int check_orders(const hx_plan *pl, int first, int count, int step, const char *who)
 {
-    if (!pl || !cost || (spin != 0 && spin != 2)) return fail(HX_ERR_ARG, "hx_plan_m_cost: bad arguments");
-    HX_TRY(ensure_ready());
-    HX_TRY(build_tasks(pl, spin));
-    const hx_plan::TaskSet &ts = pl->ts[spin ? 1 : 0];
-    const int l0min = spin ? 2 : 0;
-    for (int m = 0; m <= pl->lmax; ++m) {
-        double c = 0.0;
-        const int l0 = std::max(m, l0min);
-        for (int t = ts.of_m[m].first; t < ts.of_m[m].first + ts.of_m[m].count; ++t)
-            c += (double)ts.tasks[t].nrb * ((pl->lmax - l0) / LBLK + 1);
-        cost[m] = c;
-    }
+    if (first < 0 || count < 0 || step < 1 || (count > 0 && first + (long long)(count - 1) * step > pl->lmax))
+        return fail(HX_ERR_ARG, "%s: bad set of orders (first %d, count %d, step %d, lmax %d)", who, first, count, step, pl->lmax);
     return HX_OK;
 }
 
-extern "C" int64_t hx_ring_modes_size(const hx_plan *pl, int m0, int m1)
+extern "C" int64_t hx_ring_modes_size(const hx_plan *pl, int count)
 {
-    if (!pl || m0 < 0 || m1 < m0 || m1 > pl->lmax + 1) return -1;
-    return (int64_t)(m1 - m0) * pl->nrp_pad * 4;
+    if (!pl || count < 0) return -1;
+    return (int64_t)count * pl->nrp_pad * 4;
 }
 
-extern "C" int hx_ring_modes(hx_plan *pl, int ncomp, const double *maps, const double *pix_weights, const double *ring_weights, int nranges,
-                             const int *mbounds, double *const *outs)
+extern "C" int hx_ring_modes(hx_plan *pl, int ncomp, const double *maps, const double *pix_weights, const double *ring_weights, int nsets,
+                             const int *m_first, const int *m_count, int m_step, double *const *outs)
 {
     HX_TRY(ensure_ready());
-    if (!pl || pl->nside < 1 || ncomp < 1 || !maps || nranges < 1 || !mbounds || !outs) return fail(HX_ERR_ARG, "hx_ring_modes: bad arguments");
-    for (int q = 0; q < nranges; ++q) {
-        if (mbounds[q] < 0 || mbounds[q + 1] < mbounds[q] || mbounds[q + 1] > pl->lmax + 1) return fail(HX_ERR_ARG, "hx_ring_modes: bad m ranges");
-        if (mbounds[q + 1] > mbounds[q] && (!outs[q] || !is_device_ptr(outs[q]))) return fail(HX_ERR_ARG, "hx_ring_modes: outputs must be device buffers");
+    if (!pl || pl->nside < 1 || ncomp < 1 || !maps || nsets < 1 || !m_first || !m_count || !outs) return fail(HX_ERR_ARG, "hx_ring_modes: bad arguments");
+    for (int q = 0; q < nsets; ++q) {
+        HX_TRY(check_orders(pl, m_first[q], m_count[q], m_step, "hx_ring_modes"));
+        if (m_count[q] > 0 && (!outs[q] || !is_device_ptr(outs[q]))) return fail(HX_ERR_ARG, "hx_ring_modes: outputs must be device buffers");
     }
     HX_TRY(build_tasks(pl, 0));
     HX_TRY(build_tasks(pl, 2));
@@ -97,12 +88,11 @@ extern "C" int hx_ring_modes(hx_plan *pl, int ncomp, const double *maps, const d
         HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
         HX_TRY(launch_ring_subdft_maps(pl, nb, vmaps.as<double>() + (size_t)c0 * pl->npix, vpw.as<double>(), pl->Y.as<double2>()));
         ProfScope ps("ring_modes");
-        for (int q = 0; q < nranges; ++q) {
-            const int m0 = mbounds[q], m1 = mbounds[q + 1];
-            if (m1 <= m0) continue;
-            dim3 grid(m1 - m0, (pl->nrp_pad + 255) / 256);
-            hipLaunchKernelGGL(k_ring_modes, grid, dim3(256), 0, rt().stream, P, pl->Y.as<double2>(), nb, c0, ncomp, m0, m1, vrw.as<double>(),
-                               ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(), ts2.d_tasks.as<LegTask>(), ts2.d_of_m.as<MTasks>(),
+        for (int q = 0; q < nsets; ++q) {
+            if (m_count[q] <= 0) continue;
+            dim3 grid(m_count[q], (pl->nrp_pad + 255) / 256);
+            hipLaunchKernelGGL(k_ring_modes, grid, dim3(256), 0, rt().stream, P, pl->Y.as<double2>(), nb, c0, m_first[q], m_count[q], m_step,
+                               vrw.as<double>(), ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(), ts2.d_tasks.as<LegTask>(), ts2.d_of_m.as<MTasks>(),
                                reinterpret_cast<double4 *>(outs[q]));
         }
         HX_HIP(hipGetLastError());
@@ -111,15 +101,16 @@ extern "C" int hx_ring_modes(hx_plan *pl, int ncomp, const double *maps, const d
     return HX_OK;
 }
 
-extern "C" int hx_legendre_from_modes(hx_plan *pl, int spin, int ncomp, const double *const *comp_modes, int m0, int m1, double *alms,
-                                      const double *fl)
+extern "C" int hx_legendre_from_modes(hx_plan *pl, int spin, int ncomp, const double *const *comp_modes, int m_first, int m_count, int m_step,
+                                      double *alms, const double *fl)
 {
     HX_TRY(ensure_ready());
     if (!pl || pl->nside < 1 || !comp_modes || !alms) return fail(HX_ERR_ARG, "hx_legendre_from_modes: bad arguments");
     if (spin != 0 && spin != 2) return fail(HX_ERR_UNSUPPORTED, "spin-%d maps not yet supported", spin);
     if (ncomp < 1 || (spin == 2 && (ncomp & 1))) return fail(HX_ERR_ARG, "bad component count %d for spin %d", ncomp, spin);
-    if (m0 < 0 || m1 <= m0 || m1 > pl->lmax + 1) return fail(HX_ERR_ARG, "hx_legendre_from_modes: bad m range [%d, %d)", m0, m1);
-    if (!is_device_ptr(alms)) return fail(HX_ERR_ARG, "hx_legendre_from_modes: alms must be a device buffer (only m in the range is written)");
+    HX_TRY(check_orders(pl, m_first, m_count, m_step, "hx_legendre_from_modes"));
+    if (m_count == 0) return HX_OK;
+    if (!is_device_ptr(alms)) return fail(HX_ERR_ARG, "hx_legendre_from_modes: alms must be a device buffer (only the given orders are written)");
     for (int c = 0; c < ncomp; ++c)
         if (!comp_modes[c] || !is_device_ptr(comp_modes[c])) return fail(HX_ERR_ARG, "hx_legendre_from_modes: mode blocks must be device buffers");
     InView vfl;
@@ -129,9 +120,10 @@ extern "C" int hx_legendre_from_modes(hx_plan *pl, int spin, int ncomp, const do
     HX_HIP(hipMemcpy(d_tab.p, comp_modes, sizeof(void *) * ncomp, hipMemcpyHostToDevice));
     const double4 *const *tab = d_tab.as<const double4 *>();
     int rc = HX_OK;
-    pl->ns_m0 = m0;
-    pl->m_lo = m0;
-    pl->m_hi = m1;
+    pl->ns_m0 = m_first;
+    pl->m_lo = m_first;
+    pl->m_hi = m_first + (m_count - 1) * m_step + 1;
+    pl->m_step = m_step;
     for (int c0 = 0, nb = 0; c0 < ncomp && rc == HX_OK; c0 += nb) {
         nb = analysis_next_batch(spin, ncomp - c0);
         pl->nssrc = tab + c0;
@@ -140,6 +132,7 @@ extern "C" int hx_legendre_from_modes(hx_plan *pl, int spin, int ncomp, const do
     pl->nssrc = nullptr;
     pl->m_lo = 0;
     pl->m_hi = -1;
+    pl->m_step = 1;
     if (hipStreamSynchronize(rt().stream) != hipSuccess && rc == HX_OK) rc = fail(HX_ERR_HIP, "hx_legendre_from_modes: stream error");  // d_tab dies here
     return rc;
 }

@@ -549,7 +549,7 @@ PlanDev hx_plan::dev() const
     P.mfac = mfac.as<double>(); P.kfac2 = kfac2.as<double>();
     P.rec0 = nullptr; P.rec2 = nullptr;
     P.wnorm = wnorm; P.hsrc = hsrc; P.hsrc_stride = hsrc_stride; P.hN = eqN;
-    P.nssrc = nssrc; P.ns_m0 = ns_m0;
+    P.nssrc = nssrc; P.ns_m0 = ns_m0; P.ns_ms = m_step;
     return P;
 }
 

@@ -51,7 +51,7 @@ struct PlanDev {
     // m-sharded route (hx_legendre_from_modes): per component a block [m - ns_m0][nrp_pad] of (F_N.re, F_N.im, F_S.re, F_S.im) with
     // phase and quadrature weight applied, as another rank's hx_ring_modes produced it; null otherwise
     const double4 *const *nssrc;
-    int ns_m0;
+    int ns_m0, ns_ms;          // the block holds the orders ns_m0 + k ns_ms
 };
 
 __host__ __device__ inline long long almidx(int lmax, int l, int m)
@@ -145,7 +145,7 @@ __device__ inline void ring_modes_ns(const PlanDev &P, const double2 *__restrict
                                      const RingAtM &r, double2 &FN, double2 &FS)
 {
     if (P.nssrc) {
-        const double4 v = P.nssrc[c][(long long)(m - P.ns_m0) * P.nrp_pad + rp];
+        const double4 v = P.nssrc[c][(long long)((m - P.ns_m0) / P.ns_ms) * P.nrp_pad + rp];
         FN = make_double2(v.x, v.y);
         FS = make_double2(v.z, v.w);
         return;
@@ -292,7 +292,9 @@ struct hx_plan {
     long long hsrc_stride = 0;
     const double4 *const *nssrc = nullptr;  // m-sharded route: device array of per-component mode blocks of the current call
     int ns_m0 = 0;
-    int m_lo = 0, m_hi = -1;        // orders the analysis sweeps cover: [m_lo, m_hi), m_hi < 0 = lmax + 1 (m-sharded route: this rank's range)
+    // orders the analysis sweeps cover: m_lo, m_lo + m_step, ... < m_hi (m_hi < 0 = lmax + 1).  The m-sharded route gives rank q of N
+    // the orders q, q + N, ...: every rank gets every size of work-group, and as many of them as a single GPU's launch / N
+    int m_lo = 0, m_hi = -1, m_step = 1;
     long long npix = 0, ny = 0, nlm = 0;
     size_t lds_fft = 0;
     hx::DevBuf z, omz, sth, rwdef, nsub, shifted, startN, startS, bhat_off, tw, bhat, mfac, kfac2, rec0, rec2, cn0, al0, cn2, al2;

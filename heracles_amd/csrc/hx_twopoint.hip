@@ -24,12 +24,17 @@ struct ClTile {
 
 __global__ __launch_bounds__(CL_WAVES * 64) void k_alm2cl_tiles(
     const double2 *const *__restrict__ comp, const int *__restrict__ comp_lmax, int ncomp,
-    const ClTile *__restrict__ tiles, int lmax_out, int nlblk, double *__restrict__ cls, int m_lo, int m_hi)
+    const ClTile *__restrict__ tiles, int ntiles, int lmax_out, int nlblk, double *__restrict__ cls, int m_lo, int m_hi, int m_step)
 {
     __shared__ double red[CL_WAVES][CL_T * CL_T][CL_LB];
-    // heavy (high-l) blocks first
-    const int lblk = nlblk - 1 - (int)(blockIdx.x % nlblk);
-    const ClTile tile = tiles[blockIdx.x / nlblk];
+    // Work-groups are dispatched to the 8 XCDs round-robin: XCD x = blockIdx % 8 walks the l-blocks 8 k + x, and for each of them
+    // ALL tiles back to back -- the tiles of one l-block read the same rows of the same alms at about the same time, so a row comes
+    // from HBM once and from that XCD's L2 for the other tiles (tile-major order re-read every alm ncomp / 6 times from HBM:
+    // 50 GB for the 9 GB of the bench).  Heavy (high-l) blocks first.
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int lblk = nlblk - 1 - ((seq / ntiles) * 8 + xcd);
+    if (lblk < 0) return;
+    const ClTile tile = tiles[seq % ntiles];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int l = lblk * CL_LB + lane;
     const int lhi = min(lblk * CL_LB + CL_LB - 1, lmax_out);
@@ -49,8 +54,8 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_alm2cl_tiles(
 #pragma unroll
     for (int t = 0; t < CL_T * CL_T; ++t) acc[t] = 0.0;
 
-    // [m_lo, m_hi): the orders summed (everything for hx_alm2cl_pairs; one rank's range on the m-sharded multi-GPU route)
-    for (int m = m_lo + w; m <= min(lhi, m_hi - 1); m += CL_WAVES) {
+    // the orders summed: m_lo, m_lo + m_step, ... < m_hi (everything for hx_alm2cl_pairs; one rank's share on the m-sharded route)
+    for (int m = m_lo + w * m_step; m <= min(lhi, m_hi - 1); m += CL_WAVES * m_step) {
         if (m <= l && l <= lmax_out) {
             double2 a[CL_T], b[CL_T];
 #pragma unroll
@@ -90,22 +95,22 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_alm2cl_tiles(
 using namespace hx;
 
 extern "C" int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double *const *alms, int lmax_out, int npairs, const int *pair_i,
-                                     const int *pair_j, int m0, int m1, double *cls);
+                                     const int *pair_j, int m0, int m1, int mstep, double *cls);
 
 extern "C" int hx_alm2cl_pairs(int ncomp, const int *lmax_i, const double *const *alms,
                                int lmax_out, int npairs, const int *pair_i, const int *pair_j,
                                double *cls)
 {
-    return hx_alm2cl_pairs_range(ncomp, lmax_i, alms, lmax_out, npairs, pair_i, pair_j, 0, lmax_out + 1, cls);
+    return hx_alm2cl_pairs_range(ncomp, lmax_i, alms, lmax_out, npairs, pair_i, pair_j, 0, lmax_out + 1, 1, cls);
 }
 
-// The same sum restricted to the orders m0 <= m < m1 (still divided by 2l + 1): the partial spectra of disjoint ranges add up to
-// hx_alm2cl_pairs -- what a rank of the m-sharded route contributes before the all-reduce.
+// The same sum restricted to the orders m0, m0 + mstep, ... < m1 (still divided by 2l + 1): the partial spectra of disjoint sets add
+// up to hx_alm2cl_pairs -- what a rank of the m-sharded route contributes before the all-reduce.
 extern "C" int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double *const *alms, int lmax_out, int npairs, const int *pair_i,
-                                     const int *pair_j, int m0, int m1, double *cls)
+                                     const int *pair_j, int m0, int m1, int mstep, double *cls)
 {
     HX_TRY(ensure_ready());
-    if (m0 < 0 || m1 < m0) return fail(HX_ERR_ARG, "hx_alm2cl_pairs_range: bad m range [%d, %d)", m0, m1);
+    if (m0 < 0 || m1 < m0 || mstep < 1) return fail(HX_ERR_ARG, "hx_alm2cl_pairs_range: bad orders %d, %d + %d, ... < %d", m0, m0, mstep, m1);
     if (ncomp <= 0 || npairs < 0 || !lmax_i || !alms || !pair_i || !pair_j || !cls || lmax_out < 0)
         return fail(HX_ERR_ARG, "hx_alm2cl_pairs: bad argument");
     if (npairs == 0) return HX_OK;
@@ -169,9 +174,10 @@ extern "C" int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double 
     const int nlblk = (lmax_out + CL_LB) / CL_LB;
     {
         ProfScope ps("alm2cl");
-        hipLaunchKernelGGL(k_alm2cl_tiles, dim3((unsigned)(nlblk * tiles.size())), dim3(CL_WAVES * 64), 0, st,
-                           d_ptrs.as<const double2 *>(), d_lmax.as<int>(), ncomp, d_tiles.as<ClTile>(),
-                           lmax_out, nlblk, out.as<double>(), m0, m1);
+        const unsigned nlb8 = (unsigned)((nlblk + 7) / 8);  // l-blocks per XCD
+        hipLaunchKernelGGL(k_alm2cl_tiles, dim3(nlb8 * 8u * (unsigned)tiles.size()), dim3(CL_WAVES * 64), 0, st,
+                           d_ptrs.as<const double2 *>(), d_lmax.as<int>(), ncomp, d_tiles.as<ClTile>(), (int)tiles.size(),
+                           lmax_out, nlblk, out.as<double>(), m0, m1, mstep);
     }
     HX_HIP(hipGetLastError());
     HX_TRY(out.finish());

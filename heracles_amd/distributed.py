@@ -199,20 +199,12 @@ class ShardedTwoPoint:
 # ======================================================================================================================
 # m-sharded route for a FIXED job (strong scaling): SURVEY.md 8e's "lower-traffic alternative"
 # ======================================================================================================================
-def m_ranges(cost, world):
-    """Cut the orders 0 .. lmax into `world` contiguous ranges of (nearly) equal cost: bounds of length world + 1.
-    cost[m] >= 0; every range holds at least one m while there are enough of them."""
-    cost = np.asarray(cost, dtype=np.float64)
-    n = cost.size
-    cum = np.concatenate([[0.0], np.cumsum(cost)])
-    bounds = [0]
-    for q in range(1, world):
-        target = cum[-1] * q / world
-        b = int(np.searchsorted(cum, target, side="left"))
-        b = min(max(b, bounds[-1] + 1), n - (world - q))  # non-empty ranges, room for the ones that follow
-        bounds.append(max(b, bounds[-1]))
-    bounds.append(n)
-    return [min(b, n) for b in bounds]
+def order_sets(lmax, world):
+    """The orders of every rank: rank q owns m = q, q + world, ...  Returns [(first, count, step)] -- the cost of an order falls
+    steadily with m, so a cyclic deal balances the work to a fraction of a percent AND gives every rank work-groups of every
+    length, as many as one GPU's launch / world (contiguous ranges of equal cost left the rank of the lowest orders with 317
+    work-groups for 256 compute units: 108 ms against 78 on the other ranks of 8)."""
+    return [(q, max(0, (lmax - q) // world + 1) if q <= lmax else 0, world) for q in range(world)]
 
 
 def assign_maps_by_components(spins, world):
@@ -235,25 +227,13 @@ class HipStages:
     def __init__(self, plan, device="cuda"):
         self.plan, self.device = plan, device
 
-    def m_cost(self):
-        import ctypes as C
-
+    def modes_size(self, count):
         from . import _lib
 
-        out = np.zeros(self.plan.lmax + 1)
-        c2 = np.zeros(self.plan.lmax + 1)
-        _lib.check(_lib.load().hx_plan_m_cost(self.plan._h, 0, _lib.ptr(out)))
-        _lib.check(_lib.load().hx_plan_m_cost(self.plan._h, 2, _lib.ptr(c2)))
-        del C
-        return out, c2
+        return int(_lib.load().hx_ring_modes_size(self.plan._h, int(count)))
 
-    def modes_size(self, m0, m1):
-        from . import _lib
-
-        return int(_lib.load().hx_ring_modes_size(self.plan._h, int(m0), int(m1)))
-
-    def ring_modes(self, maps, bounds, pix_weights=None, ring_weights=None):
-        """maps (ncomp, npix) -> one float64 device tensor per range q: (ncomp * modes_size(bounds[q], bounds[q+1]),)."""
+    def ring_modes(self, maps, sets, pix_weights=None, ring_weights=None):
+        """maps (ncomp, npix) -> one float64 device tensor per set of orders (first, count, step): (ncomp * modes_size(count),)."""
         import ctypes as C
 
         import torch
@@ -261,35 +241,37 @@ class HipStages:
         from . import _lib
 
         ncomp = maps.shape[0]
-        nr = len(bounds) - 1
-        outs = [torch.empty(ncomp * self.modes_size(bounds[q], bounds[q + 1]), dtype=torch.float64, device=self.device) for q in range(nr)]
+        ns = len(sets)
+        outs = [torch.empty(ncomp * self.modes_size(c), dtype=torch.float64, device=self.device) for (_, c, _) in sets]
         if ncomp == 0:
             return outs
-        mb = (C.c_int * (nr + 1))(*[int(b) for b in bounds])
-        ptrs = (C.c_void_p * nr)(*[o.data_ptr() for o in outs])
+        step = sets[0][2]
+        assert all(s[2] == step for s in sets)
+        first = (C.c_int * ns)(*[int(s[0]) for s in sets])
+        count = (C.c_int * ns)(*[int(s[1]) for s in sets])
+        ptrs = (C.c_void_p * ns)(*[o.data_ptr() for o in outs])
         maps = maps.contiguous() if hasattr(maps, "data_ptr") else np.ascontiguousarray(maps, dtype=np.float64)
-        _lib.check(_lib.load().hx_ring_modes(self.plan._h, ncomp, _lib.ptr(maps), _lib.ptr(pix_weights), _lib.ptr(ring_weights), nr, mb, ptrs))
+        _lib.check(_lib.load().hx_ring_modes(self.plan._h, ncomp, _lib.ptr(maps), _lib.ptr(pix_weights), _lib.ptr(ring_weights), ns, first, count,
+                                             int(step), ptrs))
         return outs
 
-    def legendre(self, spin, blocks, m0, m1, alm_out):
-        """blocks: one float64 device tensor per component ([m1 - m0][nrp_pad][4]); alm_out (ncomp, nlm) complex device tensor,
-        written for m in [m0, m1) only."""
+    def legendre(self, spin, blocks, orders, alm_out):
+        """blocks: one float64 device tensor per component ([count][nrp_pad][4]); alm_out (ncomp, nlm) complex device tensor,
+        written for the orders (first, count, step) only."""
         import ctypes as C
 
         from . import _lib
 
-        if not blocks or m1 <= m0:
+        if not blocks or orders[1] <= 0:
             return
         ptrs = (C.c_void_p * len(blocks))(*[b.data_ptr() for b in blocks])
-        _lib.check(_lib.load().hx_legendre_from_modes(self.plan._h, int(spin), len(blocks), ptrs, int(m0), int(m1), _lib.ptr(alm_out), None))
+        _lib.check(_lib.load().hx_legendre_from_modes(self.plan._h, int(spin), len(blocks), ptrs, int(orders[0]), int(orders[1]), int(orders[2]),
+                                                      _lib.ptr(alm_out), None))
 
     def zeros_alm(self, ncomp, nlm):
         import torch
 
         return torch.zeros((ncomp, nlm), dtype=torch.complex128, device=self.device)
-
-    def to_exchange(self, t):
-        return t
 
     def synchronize(self):
         from . import _lib
@@ -300,9 +282,9 @@ class HipStages:
 class MShardedTwoPoint:
     """All auto/cross spectra of a FIXED set of maps on `world` ranks, sharded by the order m:
 
-        ring Fourier stage of the rank's own maps  ->  all-to-all of the ring modes by m-range  ->  Legendre stage of EVERY
-        component on the rank's m-range (the full-batch kernels, 1/world of the orders)  ->  all-pairs Cl over the rank's m
-        ->  all-reduce of the Cl blocks.
+        ring Fourier stage of the rank's own maps  ->  all-to-all of the ring modes by owner of the order  ->  Legendre stage of
+        EVERY component on the rank's orders (the full-batch kernels, 1/world of the orders)  ->  all-pairs Cl over the rank's
+        orders  ->  all-reduce of the Cl blocks.
 
     Dealing the MAPS of a 20-map job to 8 ranks instead (ShardedTwoPoint) leaves two or three maps per rank: a batch shape the
     matrix kernels cannot fill.  Replaces the loops of heracles/mapping.py:151-172 and heracles/twopoint.py:198-215.
@@ -344,11 +326,8 @@ class MShardedTwoPoint:
             n += ncomp(i) * ncomp(j)
         self.nrows = n
         self.cpairs = [(a, b) for (i, j) in self.pairs for a in self.comps_of_map[i] for b in self.comps_of_map[j]]
-        cost0, cost2 = stages.m_cost()
-        # the m-ranges are shared by both spins (a cross spectrum needs both partners' m on one rank): cost of an m = its
-        # columns x ring blocks x l blocks, 2 real columns per spin-0 component, and a spin-2 component costs 3/2 of a spin-0 one
-        self.bounds = m_ranges(self.nc0 * np.asarray(cost0) + 1.5 * self.nc2 * np.asarray(cost2) + 1e-9, world)
-        self.m0, self.m1 = self.bounds[rank], self.bounds[rank + 1]
+        self.sets = order_sets(lmax, world)      # (first, count, step) of every rank: the same for both spins
+        self.orders = self.sets[rank]
         self._alm = None
 
     @property
@@ -357,7 +336,7 @@ class MShardedTwoPoint:
         return self.maps_of[self.rank]
 
     def buffer(self):
-        """(nc0 + nc2, nlm) alms of ALL components; only the orders of this rank's range are non-zero."""
+        """(nc0 + nc2, nlm) alms of ALL components; only the orders of this rank are non-zero."""
         if self._alm is None:
             self._alm = self.stages.zeros_alm(self.nc0 + self.nc2, self.nlm)
         return self._alm
@@ -367,19 +346,21 @@ class MShardedTwoPoint:
         import torch
         import torch.distributed as dist
 
-        sizes_out = [self.ncomp_of[s] * self.stages.modes_size(self.m0, self.m1) for s in range(self.world)]
+        size = self.stages.modes_size(self.orders[1])
+        sizes_out = [self.ncomp_of[s] * size for s in range(self.world)]
         if self.world == 1:
             return [send_blocks[0]]
         gloo = dist.get_backend(self.group) == "gloo"
+        on_dev = send_blocks[0].is_cuda
         send = torch.cat([b.reshape(-1) for b in send_blocks])
-        if gloo and send.is_cuda:
+        if gloo and on_dev:
             send = send.cpu()
         recv = torch.empty(sum(sizes_out), dtype=torch.float64, device=send.device)
         dist.all_to_all_single(recv, send, output_split_sizes=sizes_out, input_split_sizes=[int(b.numel()) for b in send_blocks], group=self.group)
-        if gloo and send_blocks[0].is_cuda:
+        if gloo and on_dev:
             recv = recv.to(send_blocks[0].device)
         elif recv.is_cuda:
-            torch.cuda.current_stream(recv.device).synchronize()
+            torch.cuda.current_stream(recv.device).synchronize()  # libhxsht reads the blocks on its own stream
         out, o = [], 0
         for s in range(self.world):
             out.append(recv[o : o + sizes_out[s]])
@@ -396,21 +377,22 @@ class MShardedTwoPoint:
         cat = torch.cat if hasattr(maps0 if n0 else maps2, "data_ptr") else np.concatenate
         parts = ([maps0.reshape(n0, npix)] if n0 else []) + ([maps2.reshape(2 * n2, npix)] if n2 else [])
         local = cat(parts) if len(parts) > 1 else parts[0]
-        send = self.stages.ring_modes(local, self.bounds, pix_weights=pix_weights, ring_weights=ring_weights)
-        recv = self._all_to_all([self.stages.to_exchange(b) for b in send])
-        size = self.stages.modes_size(self.m0, self.m1)
+        send = self.stages.ring_modes(local, self.sets, pix_weights=pix_weights, ring_weights=ring_weights)
+        recv = self._all_to_all(send)
+        size = self.stages.modes_size(self.orders[1])
         blocks0, blocks2 = [], []
         for s in range(self.world):
             for c in range(self.ncomp_of[s]):
                 (blocks0 if c < self.n0_of[s] else blocks2).append(recv[s][c * size : (c + 1) * size])
         alm = self.buffer()
-        self.stages.legendre(0, blocks0, self.m0, self.m1, alm[: self.nc0])
-        self.stages.legendre(2, blocks2, self.m0, self.m1, alm[self.nc0 :])
+        self.stages.legendre(0, blocks0, self.orders, alm[: self.nc0])
+        self.stages.legendre(2, blocks2, self.orders, alm[self.nc0 :])
         self.stages.synchronize()
         comps = [alm[k] for k in range(alm.shape[0])]
-        # this rank's orders only: the alms are zero elsewhere; a kernel that takes the range does not even read them there
+        # this rank's orders only: the alms are zero elsewhere; a kernel that takes the set does not even read them there
+        first, count, step = self.orders
         try:
-            part = self.kernel(comps, self.cpairs, self.lmax, m_range=(self.m0, self.m1))
+            part = self.kernel(comps, self.cpairs, self.lmax, m_range=(first, first + max(count - 1, 0) * step + (1 if count else 0), step))
         except TypeError:
             part = self.kernel(comps, self.cpairs, self.lmax)
         part = np.ascontiguousarray(part, dtype=np.float64)

@@ -36,7 +36,7 @@ def alm2cl_pairs(comps, pairs, lmax_out, m_range=None):
 
     comps: list of 1-D complex128 arrays (numpy, or torch CUDA tensors); pairs: list of
     (i, j) indices into comps.  Returns a float64 array (npairs, lmax_out+1).
-    m_range = (m0, m1): the sum over the orders m0 <= m < m1 only (a rank's share on the m-sharded route).
+    m_range = (m0, m1[, step]): the sum over the orders m0, m0 + step, ... < m1 only (a rank's share on the m-sharded route).
     """
     L = _lib.load()
     _lib.ensure_init()
@@ -59,7 +59,8 @@ def alm2cl_pairs(comps, pairs, lmax_out, m_range=None):
     if npairs and m_range is None:
         _lib.check(L.hx_alm2cl_pairs(ncomp, lmaxs, ptrs, int(lmax_out), npairs, pi, pj, _lib.ptr(out)))
     elif npairs:
-        _lib.check(L.hx_alm2cl_pairs_range(ncomp, lmaxs, ptrs, int(lmax_out), npairs, pi, pj, int(m_range[0]), int(m_range[1]), _lib.ptr(out)))
+        step = int(m_range[2]) if len(m_range) > 2 else 1
+        _lib.check(L.hx_alm2cl_pairs_range(ncomp, lmaxs, ptrs, int(lmax_out), npairs, pi, pj, int(m_range[0]), int(m_range[1]), step, _lib.ptr(out)))
     return out
 
 

@@ -111,18 +111,17 @@ int hx_map2alm_multi(hx_plan *plan, int njobs, const int *spins, const int *ncom
 
 /* ---- the two halves of hx_map2alm, for the m-sharded multi-GPU route (heracles/mapping.py:151-172 and
  * heracles/twopoint.py:198-215 are the loops it shards) -------------------------------------------------------------------
- * hx_ring_modes: ring Fourier stage of ncomp maps; for every range q < nranges of orders [mbounds[q], mbounds[q+1]) the block
- *   outs[q][comp][m - mbounds[q]][nrp_pad][4] = (F_N.re, F_N.im, F_S.re, F_S.im)(m, ring pair) with ring phase, pixel and ring
- *   weights applied (DEVICE buffers of ncomp * hx_ring_modes_size doubles) -- what is sent to the rank that owns the range.
- * hx_legendre_from_modes: Legendre stage of ALL ncomp components of one spin for the orders [m0, m1): comp_modes[c] points to
- *   component c's block [m1 - m0][nrp_pad][4] (as received); writes alm[c][idx(l, m)] for m in the range ONLY (device buffer).
- * hx_plan_m_cost: relative cost of every order m (for cutting [0, lmax] into ranges of equal work). */
-int hx_plan_m_cost(hx_plan *plan, int spin, double *cost);
-int64_t hx_ring_modes_size(const hx_plan *plan, int m0, int m1);
-int hx_ring_modes(hx_plan *plan, int ncomp, const double *maps, const double *pix_weights, const double *ring_weights, int nranges,
-                  const int *mbounds, double *const *outs);
-int hx_legendre_from_modes(hx_plan *plan, int spin, int ncomp, const double *const *comp_modes, int m0, int m1, double *alms,
-                           const double *fl);
+ * A set of orders is (first, count, step): m = first + k step, k < count; rank q of N owns (q, ., N).
+ * hx_ring_modes: ring Fourier stage of ncomp maps; for every set q < nsets = (m_first[q], m_count[q], m_step) the block
+ *   outs[q][comp][k][nrp_pad][4] = (F_N.re, F_N.im, F_S.re, F_S.im)(m, ring pair) with ring phase, pixel and ring weights
+ *   applied (DEVICE buffers of ncomp * hx_ring_modes_size(count) doubles) -- what is sent to the rank that owns the set.
+ * hx_legendre_from_modes: Legendre stage of ALL ncomp components of one spin for one set of orders: comp_modes[c] points to
+ *   component c's block [count][nrp_pad][4] (as received); writes alm[c][idx(l, m)] for the orders of the set ONLY (device buffer). */
+int64_t hx_ring_modes_size(const hx_plan *plan, int count);
+int hx_ring_modes(hx_plan *plan, int ncomp, const double *maps, const double *pix_weights, const double *ring_weights, int nsets,
+                  const int *m_first, const int *m_count, int m_step, double *const *outs);
+int hx_legendre_from_modes(hx_plan *plan, int spin, int ncomp, const double *const *comp_modes, int m_first, int m_count, int m_step,
+                           double *alms, const double *fl);
 
 /* ---- two-point reduction -------------------------------------------------------- */
 /* Replaces heracles.twopoint.alm2cl (heracles/twopoint.py:63-101) for a whole list of
@@ -130,10 +129,10 @@ int hx_legendre_from_modes(hx_plan *plan, int spin, int ncomp, const double *con
  * cls is [npairs][lmax_out+1]; requires lmax_out <= min over used components.         */
 int hx_alm2cl_pairs(int ncomp, const int *lmax_i, const double *const *alms, int lmax_out,
                     int npairs, const int *pair_i, const int *pair_j, double *cls);
-/* The same sum over the orders m0 <= m < m1 only (still divided by 2l + 1): partial spectra of disjoint ranges add up to
+/* The same sum over the orders m0, m0 + mstep, ... < m1 only (still divided by 2l + 1): partial spectra of disjoint sets add up to
  * hx_alm2cl_pairs -- a rank's contribution on the m-sharded multi-GPU route (the loop of heracles/twopoint.py:90-99 cut by m). */
 int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double *const *alms, int lmax_out, int npairs, const int *pair_i,
-                          const int *pair_j, int m0, int m1, double *cls);
+                          const int *pair_j, int m0, int m1, int mstep, double *cls);
 
 /* ---- mixing matrices / Wigner-d ------------------------------------------------- */
 /* Gauss-Legendre nodes (ascending) and weights; the `gauss_legendre` hook of

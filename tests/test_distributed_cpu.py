@@ -143,40 +143,42 @@ MS_NSIDE, MS_LMAX = 4, 9
 
 class OracleStages:
     """The two halves of the transform from the oracle (hxo_fourier_analysis / hxo_legendre_analysis), CPU tensors: stands in for
-    HipStages so that the sharding logic -- ranges, block order, all-to-all splits, all-reduce -- runs under gloo without a GPU."""
+    HipStages so that the sharding logic -- order sets, block order, all-to-all splits, all-reduce -- runs under gloo without a GPU."""
 
     def __init__(self, nside, lmax):
         self.nside, self.lmax = nside, lmax
         self.nr = 4 * nside - 1
 
-    def m_cost(self):
-        c = np.array([(self.lmax - m + 1.0) for m in range(self.lmax + 1)])
-        return c, c
+    def modes_size(self, count):
+        return self.nr * count * 2
 
-    def modes_size(self, m0, m1):
-        return self.nr * (m1 - m0) * 2
+    @staticmethod
+    def _ms(orders):
+        first, count, step = orders
+        return np.arange(first, first + count * step, step)
 
-    def ring_modes(self, maps, bounds, pix_weights=None, ring_weights=None):
+    def ring_modes(self, maps, sets, pix_weights=None, ring_weights=None):
         import torch
 
         from oracle import hxoracle as ho
 
         assert ring_weights is None
         F = ho.fourier_analysis(np.asarray(maps), self.nside, self.lmax, pix_weights=pix_weights)  # [comp][ring][m]
-        return [torch.from_numpy(np.ascontiguousarray(F[:, :, bounds[q] : bounds[q + 1]]).view(np.float64).reshape(-1)) for q in range(len(bounds) - 1)]
+        return [torch.from_numpy(np.ascontiguousarray(F[:, :, self._ms(o)]).view(np.float64).reshape(-1)) for o in sets]
 
-    def legendre(self, spin, blocks, m0, m1, alm_out):
+    def legendre(self, spin, blocks, orders, alm_out):
         import torch
 
         from oracle import hxoracle as ho
 
-        if not blocks or m1 <= m0:
+        ms = self._ms(orders)
+        if not blocks or ms.size == 0:
             return
         F = np.zeros((len(blocks), self.nr, self.lmax + 1), dtype=np.complex128)
         for c, b in enumerate(blocks):
-            F[c, :, m0:m1] = b.numpy().view(np.complex128).reshape(self.nr, m1 - m0)
+            F[c][:, ms] = b.numpy().view(np.complex128).reshape(self.nr, ms.size)
         alm = ho.legendre_analysis(F, self.nside, self.lmax, spin=spin)
-        for m in range(m0, m1):  # only the orders of the range are written
+        for m in ms:  # only the orders of the set are written
             base = m * (2 * self.lmax + 1 - m) // 2
             alm_out[:, base + m : base + self.lmax + 1] = torch.from_numpy(alm[:, base + m : base + self.lmax + 1])
 
@@ -184,9 +186,6 @@ class OracleStages:
         import torch
 
         return torch.zeros((ncomp, nlm), dtype=torch.complex128)
-
-    def to_exchange(self, t):
-        return t
 
     def synchronize(self):
         pass
@@ -215,7 +214,7 @@ def _ms_worker(rank, world, port, outdir):
     for _ in range(2):  # the second step reuses the alm buffer
         res = work.run(torch.from_numpy(m0), torch.from_numpy(m2), pix_weights=pw)
     np.save(os.path.join(outdir, f"msharded_{rank}.npy"), res)
-    np.save(os.path.join(outdir, f"bounds_{rank}.npy"), np.array(work.bounds))
+    np.save(os.path.join(outdir, f"orders_{rank}.npy"), np.array(work.sets))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -244,8 +243,9 @@ def test_m_sharded_equals_single(tmp_path, world):
         got = np.load(tmp_path / f"msharded_{r}.npy")
         assert got.shape == ref.shape
         np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-13 * np.abs(ref).max())
-        b = np.load(tmp_path / f"bounds_{r}.npy")
-        assert b[0] == 0 and b[-1] == MS_LMAX + 1 and (np.diff(b) > 0).all() and len(b) == world + 1
+        sets = np.load(tmp_path / f"orders_{r}.npy")
+        ms = sorted(m for (f, c, st) in sets for m in range(f, f + c * st, st))
+        assert ms == list(range(MS_LMAX + 1)) and len(sets) == world  # every order owned exactly once
     # world == 1: no communication, same answer
     nlm = (MS_LMAX + 1) * (MS_LMAX + 2) // 2
     one = MShardedTwoPoint(SPINS, 1, 0, nlm, MS_LMAX, OracleStages(MS_NSIDE, MS_LMAX), kernel=_kernel)
@@ -254,17 +254,19 @@ def test_m_sharded_equals_single(tmp_path, world):
     np.testing.assert_allclose(one.run(torch.from_numpy(m0), torch.from_numpy(m2), pix_weights=pw), ref, rtol=1e-12, atol=1e-13 * np.abs(ref).max())
 
 
-def test_m_ranges_balance_the_cost():
-    from heracles_amd.distributed import assign_maps_by_components, m_ranges
+def test_order_sets_cover_and_balance():
+    from heracles_amd.distributed import assign_maps_by_components, order_sets
 
     lmax = 6144
     cost = (lmax + 1.0 - np.arange(lmax + 1)) * np.minimum(1.0, 0.2 + np.arange(lmax + 1)[::-1] / lmax)
     for world in (1, 2, 4, 8):
-        b = m_ranges(cost, world)
-        assert b[0] == 0 and b[-1] == lmax + 1 and len(b) == world + 1 and all(b[q + 1] > b[q] for q in range(world))
-        loads = [cost[b[q] : b[q + 1]].sum() for q in range(world)]
-        assert max(loads) <= 1.02 * sum(loads) / world, (world, loads)
-    assert m_ranges(np.ones(3), 8)[-1] == 3  # more ranks than orders: trailing ranges are empty, nothing is lost
+        sets = order_sets(lmax, world)
+        ms = [np.arange(f, f + c * st, st) for (f, c, st) in sets]
+        assert sorted(np.concatenate(ms).tolist()) == list(range(lmax + 1))
+        loads = [cost[m].sum() for m in ms]
+        assert max(loads) <= 1.005 * sum(loads) / world, (world, loads)
+        assert max(len(m) for m in ms) - min(len(m) for m in ms) <= 1
+    assert [c for (_, c, _) in order_sets(2, 8)] == [1, 1, 1, 0, 0, 0, 0, 0]  # more ranks than orders: empty sets, nothing lost
     # ring Fourier stage: components dealt evenly (30 components of the north-star job: 4, 4, 4, 4, 4, 4, 3, 3 on 8 ranks)
     spins = [0] * 10 + [2] * 10
     owner = assign_maps_by_components(spins, 8)

@@ -133,3 +133,6 @@ def test_m_range_partial_sums_add_up(oracle):
     # the first range is m = 0 alone: Re a Re b / (2l + 1)
     np.testing.assert_allclose(parts[0][3], comps[0][: lmax + 1].real * comps[3][: lmax + 1].real / (2 * np.arange(lmax + 1) + 1), rtol=1e-14)
     assert not hx.alm2cl_pairs(comps, pairs, lmax, m_range=(5, 5)).any()
+    # strided sets (the orders of rank q of 3: q, q + 3, ...) add up as well
+    strided = [hx.alm2cl_pairs(comps, pairs, lmax, m_range=(q, lmax + 1, 3)) for q in range(3)]
+    np.testing.assert_allclose(sum(strided), full, rtol=1e-13, atol=1e-15)

@@ -93,15 +93,15 @@ def _all_maps():
 
 
 @pytest.mark.parametrize("nside,lmax", [(32, 64), (256, 400)])
-def test_modes_then_legendre_on_m_ranges_equals_map2alm(nside, lmax):
-    """The two halves of the transform as the m-sharded route uses them, in ONE process: the mode blocks of hx_ring_modes for a
-    partition of the orders into 5 uneven ranges, then hx_legendre_from_modes range by range into one alm buffer, give the alms
-    of hx_map2alm (same kernels, same operands: to rounding of nothing -- bit for bit).  At nside 256 polar pruning is active and
-    the scratch budget cuts every range into several m-chunks."""
+def test_modes_then_legendre_on_order_sets_equals_map2alm(nside, lmax):
+    """The two halves of the transform as the m-sharded route uses them, in ONE process: the mode blocks of hx_ring_modes for the
+    orders dealt cyclically to 5 virtual ranks (and for uneven contiguous ranges, step 1), then hx_legendre_from_modes set by set
+    into one alm buffer, give the alms of hx_map2alm (same kernels, same operands: bit for bit).  At nside 256 polar pruning is
+    active and the scratch budget cuts every set into several m-chunks."""
     import torch
 
     import heracles_amd as hx
-    from heracles_amd.distributed import HipStages
+    from heracles_amd.distributed import HipStages, order_sets
 
     rng = np.random.default_rng(11)
     npix = 12 * nside**2
@@ -110,22 +110,22 @@ def test_modes_then_legendre_on_m_ranges_equals_map2alm(nside, lmax):
     pw = torch.as_tensor(1.0 + 1e-2 * rng.standard_normal(npix)).cuda()
     rw = torch.as_tensor(1.0 + 1e-2 * rng.standard_normal(2 * nside)).cuda()
     bounds = [0, 1, 7, lmax // 3, lmax - 2, lmax + 1]
-    for spin, ncomp in ((0, 5), (2, 6), (0, 1), (2, 2), (0, 10)):
-        maps = torch.as_tensor(rng.standard_normal((ncomp, npix))).cuda()
-        ref = plan.map2alm(maps, spin, pix_weights=pw, ring_weights=rw)
-        blocks = st.ring_modes(maps, bounds, pix_weights=pw, ring_weights=rw)
-        alm = st.zeros_alm(ncomp, plan.nlm)
-        if nside >= 256:
-            hx._lib.set_scratch_budget(4e6)
-        try:
-            for q in range(len(bounds) - 1):
-                size = st.modes_size(bounds[q], bounds[q + 1])
-                st.legendre(spin, [blocks[q][c * size : (c + 1) * size] for c in range(ncomp)], bounds[q], bounds[q + 1], alm)
-        finally:
-            hx._lib.set_scratch_budget(0)
-        np.testing.assert_array_equal(alm.cpu().numpy(), ref.cpu().numpy())
-    c0, c2 = st.m_cost()
-    assert c0.shape == (lmax + 1,) and (c0 > 0).all() and (np.diff(c0) <= 0).all() and (c2 > 0).all()
+    contiguous = [(bounds[q], bounds[q + 1] - bounds[q], 1) for q in range(5)]
+    for sets in (order_sets(lmax, 5), contiguous, order_sets(lmax, 8)[:3] + order_sets(lmax, 8)[3:]):
+        for spin, ncomp in ((0, 5), (2, 6), (0, 1), (2, 2), (0, 10)):
+            maps = torch.as_tensor(rng.standard_normal((ncomp, npix))).cuda()
+            ref = plan.map2alm(maps, spin, pix_weights=pw, ring_weights=rw)
+            blocks = st.ring_modes(maps, sets, pix_weights=pw, ring_weights=rw)
+            alm = st.zeros_alm(ncomp, plan.nlm)
+            if nside >= 256:
+                hx._lib.set_scratch_budget(4e6)
+            try:
+                for q, orders in enumerate(sets):
+                    size = st.modes_size(orders[1])
+                    st.legendre(spin, [blocks[q][c * size : (c + 1) * size] for c in range(ncomp)], orders, alm)
+            finally:
+                hx._lib.set_scratch_budget(0)
+            np.testing.assert_array_equal(alm.cpu().numpy(), ref.cpu().numpy())
 
 
 def _ms_worker(rank, world, port, outdir):
