@@ -18,11 +18,11 @@
 //                16 real columns, x NG column groups) stays in registers for the whole l sweep.
 //   flush      per 32-l block the waves' D tiles are summed through LDS in fixed order
 //                (bit-reproducible) and scaled by alpha_l into `partial`.
-// Two generations of the kernel live here: k_legendre_analysis (batches of <= 2 maps / fields, the 4x4x4 instruction; one
-// work-group per (m, ring group), one span of `partial` rows per group, summed over the groups by k_alm_reduce) and the
-// software-pipelined k_legendre_pipe (every larger batch; one work-group per m that walks its ring groups and adds them in
-// place with f64 atomics in a fixed order -- `partial` then holds ONE span of rows per m and k_alm_reduce only changes the
-// layout).
+// The kernel here is the software-pipelined k_legendre_pipe (batches of 5 or more spin-0 maps / 3 or more spin-2 fields: one
+// work-group per m that walks its ring groups and adds them in place with f64 atomics in a fixed order -- `partial` holds ONE span of
+// rows per m and k_alm_reduce only changes the layout).  Smaller batches run on the vector unit (hx_legendre_valu.hip: one span of
+// rows per ring group, summed by k_alm_reduce).  Round 1's barrier-phased kernel on the 4x4x4 instruction (k_legendre_analysis)
+// was retired in round 3: 61 / 108 ms for one spin-0 map / spin-2 field against 23 / 65 ms.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -31,23 +31,6 @@
 
 namespace hx {
 using namespace hxfft;
-
-// 32-l sub-blocks swept per flush (NSUB) of the variants whose D tiles leave room in the wave's LDS tile
-// and whose registers hold NSUB accumulator sets: measured against NSUB = 1 at nside 4096 --
-// <2,-1> 117 -> 107 ms, <2,-2> 147 -> 141, <2,1> 195 -> 188, <0,-1> 76 -> 70, <0,-2> 95 -> 91, <0,1> 117 -> 112.
-// <2,2> (registers) and the spin-0 hybrid <0,1,x> (its two D groups fill the 8 KiB tile) stay at 1.
-#ifndef HX_QSUB2
-#define HX_QSUB2 4   // spin-2 4x4x4 variants
-#define HX_QSUB0 2   // spin-0 4x4x4 variants
-#define HX_FSUB0 2   // <0,1>
-#define HX_FSUB2 2   // <2,1>
-#endif
-#ifndef HX_QNW0
-#define HX_QNW0 8   // waves per work-group of the spin-0 one-block 4x4x4 variant <0,-1> (half of LegCfg<0>::NW)
-#endif
-#ifndef HX_GSUB2
-#define HX_GSUB2 1   // <2,2>: a second accumulator set spills 42 VGPRs: 354 ms against 329 ms per sweep
-#endif
 
 template <int SPIN>
 struct LegCfg {
@@ -166,291 +149,6 @@ __device__ inline int opaque(int v)
 {
     asm("; opaque %1" : "+v"(v) : "n"(K));
     return v;
-}
-
-// NGQ > 0: NGQ groups of 16 columns on v_mfma_f64_16x16x4_f64.
-// NGQ < 0: -NGQ blocks of 4 columns on v_mfma_f64_4x4x4_4b_f64 (small batches: the four 4x4x4
-//          blocks take the four 4-row groups of the same [16 l x 4 rings] A operand, so the A
-//          layout -- row = lane&15, k = lane>>4 -- is unchanged; B lane (k, b, j) = F[ring k][col j],
-//          D lane (i, b, j) = row 4b+i, col j; measured 16 cycles / instruction).
-template <int SPIN, int NGQ, int NBX = 0, int NSUB = 1, int NWV = LegCfg<SPIN>::NW>
-__global__ __launch_bounds__(NWV * 64, (NWV < LegCfg<SPIN>::NW ? 2 : 1)) void k_legendre_analysis(LegParams A,
-                                                                           const double2 *__restrict__ coefn,
-                                                                           const double *__restrict__ alphan)
-{
-    using C = LegCfg<SPIN>;
-    // NWV waves per work-group: C::NW, or half of it for the spin-0 variant of one or two maps (<0,-1>):
-    // its 64 KiB of tiles and 100 VGPRs let two work-groups share a CU, and with hardly any matrix work
-    // to wait for, one group's recursion fills the other's flush (70 -> 61 ms)
-    constexpr int NW = NWV, NT = C::NT, NOP = C::NOP;
-    constexpr bool QUAD = NGQ < 0;            // 4-column MFMA path
-    constexpr int NG = QUAD ? 1 : NGQ;        // 16-column groups held in the partial rows
-    constexpr int NB = QUAD ? -NGQ : NGQ;     // B-operand register sets per (par, op, q)
-    // NBX > 0 (hybrid): after the NG full groups, NBX more blocks of 4 columns on the 4x4x4 MFMA --
-    // they share the recursion, the tiles and the flush of the full groups (e.g. 10 spin-0 maps =
-    // one 16-column group + one 4-column block in ONE sweep instead of two launches)
-    constexpr int NGT = NG + (NBX > 0 ? 1 : 0);
-    static_assert(!(QUAD && NBX > 0), "extra blocks only next to full groups");
-    static_assert(NGT * 512 <= LegCfg<SPIN>::NT * 1024, "D tiles must fit the wave's tile");
-    __shared__ double tiles[NW][NT][16][64];  // 128 KiB; after the MFMA phase each wave's tiles carry its D tiles
-    // NSUB 32-l sub-blocks are swept between two flushes (their D tiles kept in registers): one work-group
-    // reduction, one pair of barriers per NSUB * 32 l
-    static_assert(NSUB * (NG + (NBX > 0 ? 1 : 0)) * 512 <= LegCfg<SPIN>::NT * 1024, "D tiles of all sub-blocks must fit the wave's tile");
-    __shared__ double2 coefs[2][NSUB * LBLK]; // recursion coefficients of this / the next block
-    __shared__ double alphas[2][NSUB * LBLK]; // output scalings alpha_l of this / the next block
-    const PlanDev &P = A.P;
-    const LegTask task = A.tasks[blockIdx.x];
-    const int m = task.m, lmax = P.lmax;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int h = lane >> 5, r32 = lane & 31;
-    const bool wave_on = w < task.nrb;
-    const int rb = task.rb0 + (wave_on ? w : 0);
-    const int rp = rb * RBLK + r32;
-    const bool valid = wave_on && rp < P.nrp;
-    const double x = valid ? P.z[rp] : 0.0;
-    const double xx = SPIN == 0 ? x * x : x;  // the variable of the recursion
-    const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
-    const int off = (l0 + m) & 1;
-    const long long cb = almidx(lmax, 0, m);
-    const long long cbs = __builtin_amdgcn_readfirstlane((int)cb);  // nlm < 2^31 for every supported lmax
-    const int ai = lane & 15, ak = lane >> 4;
-
-    // ---- B operands: F[m - m0][rp][par][op][g*16 + j], lane (k = lane>>4, j = lane&15) ----
-    double fr[NB][2][NOP][8];
-    {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const long long row = (long long)((m - A.m0) / A.ms) * P.nrp_pad + rb * RBLK + ringsel(q, ak);
-#pragma unroll
-            for (int par = 0; par < 2; ++par)
-#pragma unroll
-                for (int op = 0; op < NOP; ++op)
-#pragma unroll
-                    for (int g = 0; g < NB; ++g) {
-                        // 16-col path: group g, column lane&15;  4-col path: block g, column lane&3
-                        const int col = QUAD ? 4 * g + (lane & 3) : g * NCOL + ai;
-                        fr[g][par][op][q] = (wave_on && (QUAD || (g < A.ng && col < A.ncol)))
-                                                ? A.F[((row * 2 + par) * NOP + op) * A.ncol + col]
-                                                : 0.0;
-                    }
-        }
-    }
-    double frx[NBX > 0 ? NBX : 1][2][NOP][8];
-    if (NBX > 0) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const long long row = (long long)((m - A.m0) / A.ms) * P.nrp_pad + rb * RBLK + ringsel(q, ak);
-#pragma unroll
-            for (int par = 0; par < 2; ++par)
-#pragma unroll
-                for (int op = 0; op < NOP; ++op)
-#pragma unroll
-                    for (int g = 0; g < NBX; ++g)
-                        frx[g][par][op][q] = wave_on ? A.F[((row * 2 + par) * NOP + op) * A.ncol + NG * NCOL + 4 * g + (lane & 3)] : 0.0;
-        }
-    }
-
-    // ---- seed of this lane's chain -------------------------------------------------------
-    double vc = 0.0, vp = 0.0;
-    int sc = -100;
-    if (valid) {
-        if (SPIN == 0) {
-            SVal s = spow(P.sth[rp], m);
-            s.v *= P.mfac[m];
-            if (h) s.v *= sqrt(2.0 * m + 3.0) * x;  // lambda_{m+1,m} = sqrt(2m+3) x lambda_mm
-            snorm_small(s);
-            vc = s.v; sc = s.e;
-        } else {
-            SVal sp, sm;
-            spin2_seeds(m, P.sth[rp], P.omz[rp], P.kfac2[m], sp, sm);
-            vc = h ? sm.v : sp.v;
-            sc = h ? sm.e : sp.e;
-        }
-    }
-    const double sgn = (SPIN == 2 && h) ? -1.0 : 1.0;  // q' enters with opposite sign for d_{m,+2}
-
-    double *mytile = &tiles[w][0][0][0];
-
-    // The coefficients are the same for every wave: each block's 32 entries are fetched one
-    // block ahead by threads 0..63 (one double each) and handed over through LDS.
-    const int coff = SPIN == 0 ? 0 : 1;  // spin-2 coefficients are indexed by the target l
-    // Work-group barrier that waits for this wave's LDS traffic only: global stores / loads in
-    // flight (partial sums, prefetches) must not hold every wave at the barrier.
-    auto lds_barrier = []() {
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-    };
-    constexpr int LB = NSUB * LBLK;  // l values per flush; threads 0..2LB-1 stage coefficients, 2LB..3LB-1 alphas
-    double cpre = 0.0, apre = 0.0;
-    if (threadIdx.x < 2 * LB)
-        (&coefs[0][0].x)[threadIdx.x] = reinterpret_cast<const double *>(coefn + cb + l0 + coff)[threadIdx.x];
-    else if (threadIdx.x < 3 * LB)
-        alphas[0][threadIdx.x - 2 * LB] = alphan[cb + l0 + (threadIdx.x - 2 * LB)];
-    __syncthreads();
-    int cbuf = 0;
-    for (int lb = l0; lb <= lmax; lb += LB, cbuf ^= 1) {
-        if (threadIdx.x < 2 * LB)
-            cpre = reinterpret_cast<const double *>(coefn + cb + lb + LB + coff)[threadIdx.x];
-        else if (threadIdx.x < 3 * LB)
-            apre = alphan[cb + lb + LB + (threadIdx.x - 2 * LB)];
-        double4_t accs[NSUB][NG][2];
-        double accqs[NSUB][NB][2];
-        double accxs[NSUB][NBX > 0 ? NBX : 1][2];
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                accs[sub][g][0] = (double4_t){0.0, 0.0, 0.0, 0.0};
-                accs[sub][g][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
-            }
-#pragma unroll
-            for (int g = 0; g < NB; ++g) accqs[sub][g][0] = accqs[sub][g][1] = 0.0;
-#pragma unroll
-            for (int g = 0; g < (NBX > 0 ? NBX : 1); ++g) accxs[sub][g][0] = accxs[sub][g][1] = 0.0;
-        }
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-        double4_t (&acc)[NG][2] = accs[sub];
-        double (&accq)[NB][2] = accqs[sub];
-        double (&accx)[NBX > 0 ? NBX : 1][2] = accxs[sub];
-        const int lbs = lb + sub * LBLK;                 // first l of this sub-block (beyond lmax: skipped)
-        const double2 *cf = coefs[cbuf] + sub * LBLK;
-        if (wave_on && (NSUB == 1 || lbs <= lmax) && !(A.ablate & 2)) {
-            // A chain is LIVE when its scale exponent is 0: its true value is >= 2^-300 and from
-            // there on a plain double.  Below that it contributes nothing at double precision
-            // and the tile gets an exact zero; such a chain is only stepped and, every 4 steps,
-            // promoted once it has grown past 1 (value *= 2^-300, exponent += 1).
-            const bool all_live = __all(sc == 0 || !valid);
-            const bool all_dead = __all(sc < 0 || !valid);
-            if ((A.ablate & 8) && lane == 0) atomicAdd(&A.counters[all_dead ? 0 : (all_live ? 1 : 2)], 1ULL);
-            // one recursion step of this lane's chain: spin 0 advances l by 2 (entry 2j+h),
-            // spin 2 advances l by 1 (entry s)
-            auto advance = [&](int e) {
-                // spin 2: the entry is the same for every lane -> scalar loads (s_load_dwordx16, four
-                // steps each) through the constant cache instead of 64-lane LDS broadcasts, which
-                // cost the LDS pipe as much as the tile stores (measured -10 % kernel time).
-                // spin 0: entry 2j+h differs between the lane halves and stays in LDS.
-                const double2 c = SPIN == 2 ? coefn[cbs + lbs + coff + e] : cf[e];
-                const double vn = fma(fma(c.x, xx, sgn * c.y), vc, -vp);
-                vp = vc;
-                vc = vn;
-            };
-            auto promote = [&]() {
-                const bool up = sc < 0 && fabs(vc) > 1.0;
-                if (__any(up)) {
-                    if (up) {
-                        vc *= SC_SMALL; vp *= SC_SMALL;
-                        sc += 1;
-                    }
-                }
-            };
-            constexpr int NSTEP = SPIN == 0 ? LBLK / 2 : LBLK;
-            if (all_dead) {
-#pragma unroll 4
-                for (int s = 0; s < NSTEP; ++s) {
-                    advance(SPIN == 0 ? 2 * s + h : s);
-                    if ((s & 3) == 3) promote();
-                }
-            } else {
-                // row r of tile t, lane c  lives at  ((t*16 + r)*64 + (c ^ swz(r)))
-                if (all_live) {
-#pragma unroll
-                    for (int s = 0; s < NSTEP; ++s) {
-                        const int t = SPIN == 0 ? 0 : ((s + off) & 1), r = SPIN == 0 ? s : (s >> 1);
-                        mytile[(t * 16 + r) * 64 + ((SPIN == 0 ? opaque<0>(lane) : lane) ^ tile_swz(r))] = vc;
-                        advance(SPIN == 0 ? 2 * s + h : s);
-                    }
-                } else {
-#pragma unroll
-                    for (int s = 0; s < NSTEP; ++s) {
-                        const int t = SPIN == 0 ? 0 : ((s + off) & 1), r = SPIN == 0 ? s : (s >> 1);
-                        mytile[(t * 16 + r) * 64 + ((SPIN == 0 ? opaque<1>(lane) : lane) ^ tile_swz(r))] = sc == 0 ? vc : 0.0;
-                        advance(SPIN == 0 ? 2 * s + h : s);
-                        if ((s & 3) == 3) promote();
-                    }
-                }
-                // the tile is private to the wave: order its LDS writes before the reads
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (!(A.ablate & 1)) {
-                    // A[i][k] = tile value of row i, ring q+8k of half hh:
-                    //   spin 0: hh = parity (tile 0);  spin 2: hh = function, tile = parity
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-#pragma unroll
-                        for (int par = 0; par < 2; ++par)
-#pragma unroll
-                            for (int op = 0; op < NOP; ++op) {
-                                const int t = SPIN == 0 ? 0 : par, hh = SPIN == 0 ? par : op;
-                                const double a = mytile[(t * 16 + ai) * 64 + ((hh * 32 + ringsel(q, ak)) ^ tile_swz(ai))];
-#pragma unroll
-                                for (int g = 0; g < NB; ++g) {
-                                    if (QUAD)
-                                        accq[g][par] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, fr[g][par][op][q], accq[g][par], 0, 0, 0);
-                                    else
-                                        acc[g][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[g][par][op][q], acc[g][par], 0, 0, 0);
-                                }
-#pragma unroll
-                                for (int g = 0; g < NBX; ++g)
-                                    accx[g][par] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[g][par][op][q], accx[g][par], 0, 0, 0);
-                            }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        }  // sub-blocks
-        // ---- flush: combine the waves' D tiles through LDS (fixed order) --------------------
-        // D layout of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4*reg, col = lane&15
-        if (threadIdx.x < 2 * LB)
-            (&coefs[cbuf ^ 1][0].x)[threadIdx.x] = cpre;
-        else if (threadIdx.x < 3 * LB)
-            alphas[cbuf ^ 1][threadIdx.x - 2 * LB] = apre;
-        // sub-block `sub` of this wave sits at doubles [sub * NGT * 512, (sub + 1) * NGT * 512) of its tile
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-            double *dt = mytile + sub * NGT * 512;
-            if (QUAD) {
-                // D lane (i = lane>>4, b = (lane>>2)&3, j = lane&3): row 4b+i, column 4g+j
-#pragma unroll
-                for (int g = 0; g < NB; ++g)
-#pragma unroll
-                    for (int par = 0; par < 2; ++par)
-                        dt[par * 256 + (4 * ((lane >> 2) & 3) + ak) * 16 + 4 * g + (lane & 3)] = accqs[sub][g][par];
-            } else {
-#pragma unroll
-                for (int g = 0; g < NG; ++g)
-#pragma unroll
-                    for (int par = 0; par < 2; ++par)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            dt[(g * 2 + par) * 256 + (ak + 4 * r) * 16 + ai] = accs[sub][g][par][r];
-#pragma unroll
-                for (int g = 0; g < NBX; ++g)
-#pragma unroll
-                    for (int par = 0; par < 2; ++par)
-                        dt[(NG * 2 + par) * 256 + (4 * ((lane >> 2) & 3) + ak) * 16 + 4 * g + (lane & 3)] = accxs[sub][g][par];
-            }
-        }
-        lds_barrier();
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-            for (int t = threadIdx.x; t < NGT * 512; t += NW * 64) {
-                const int g = t >> 9, par = (t >> 8) & 1, r16 = (t >> 4) & 15, col = t & 15;
-                if (g >= A.ng || g * NCOL + col >= A.ncol || (QUAD && col >= 4 * NB)) continue;
-                // fixed association (bit-reproducible), four independent chains for latency
-                double s4[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int ww = 0; ww < NW; ++ww) s4[ww & 3] += (&tiles[ww][0][0][0])[sub * NGT * 512 + (g * 2 + par) * 256 + r16 * 16 + col];
-                const double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-                const int l = lb + sub * LBLK + 2 * r16 + (par ^ off);
-                if (l <= lmax)
-                    A.partial[(task.pout - A.row0 + (l - l0)) * A.ncol + g * NCOL + col] = s * alphas[cbuf][l - lb];
-            }
-        }
-        lds_barrier();  // D tiles consumed: the tile buffers may be overwritten by the next block
-    }
 }
 
 // =====================================================================================
@@ -1388,12 +1086,12 @@ static int ring_mlim(int lmax, int spin, double sth, double cth)
 }
 
 // Column layout of one sweep over nb components (2 real columns per spin-0 map, 4 per spin-2 field):
-//   cols <= 8 : 4-column blocks on v_mfma_f64_4x4x4_4b, first kernel (quad = blocks);
+//   cols <= 8 : no matrix instruction at all -- one sweep per map / field of the vector-unit kernel (valu);
 //   else      : ng full 16-column groups + nbx extra 4-column blocks on the pipelined kernel.
 // The pipelined kernel is matrix-bound, so a sweep costs what its (4-column padded) columns cost whatever the
 // split; 32 columns is what the B operands of two ring sets leave of the register file.
 struct SweepShape {
-    int ng, nbx, quad, ncol, oneset;
+    int ng, nbx, valu, ncol, oneset;
 };
 // HX_PIPE_ONESET=0 keeps ten spin-2 fields as two sweeps of five (the kernel of the first half of round 2): A/B switch
 static bool oneset_enabled()
@@ -1416,9 +1114,8 @@ static SweepShape sweep_shape(int spin, int nb)
         sh.ncol = cols;
         return sh;
     }
-    if (cols <= 8) {
-        sh.quad = (cols + 3) / 4;
-        sh.ncol = 4 * sh.quad;
+    if (cols <= 8) {  // <= 4 spin-0 maps / <= 2 spin-2 fields: one sweep per map / field on the vector unit (hx_legendre_valu.hip)
+        sh.valu = 1;
         return sh;
     }
     sh.ng = cols / NCOL;
@@ -1447,8 +1144,7 @@ int analysis_next_batch(int spin, int remaining, bool from_host)
     return unit * ((units + nsweep - 1) / nsweep);
 }
 
-// ts[0], ts[1]: spin 0 / spin 2 tasks of NW ring blocks;  ts[2]: spin 0 tasks of NW / 2 ring blocks
-// (half-size work-groups of the 4x4x4 variants)
+// ts[0], ts[1]: spin 0 / spin 2 tasks of NW ring blocks (ts[3]: one ring set per wave; ts[4], ts[5]: the vector-unit kernel)
 static int build_task_set(hx_plan *pl, int spin, int nw, hx_plan::TaskSet &ts);
 int build_tasks(hx_plan *pl, int spin)
 {
@@ -1512,8 +1208,8 @@ template <int SPIN>
 static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int nb, const SweepShape &sh, const double *d_rw,
                         const double *d_fl, int add, double2 *d_alms)
 {
-    // column groups of the F / partial rows: full groups (+ 1 holding the extra blocks); the 4x4x4 path has one
-    const int ng = sh.quad ? 1 : sh.ng + (sh.nbx > 0 ? 1 : 0), ncol = sh.ncol;
+    // column groups of the F / partial rows: full groups (+ 1 holding the extra blocks)
+    const int ng = sh.ng + (sh.nbx > 0 ? 1 : 0), ncol = sh.ncol;
     // rows of the one-ring-set kernel start on 128-byte lines: the atomics of a flush (16 lanes x 8 B per row and column group)
     // then touch whole aligned lines instead of straddling two (-10 ms for its 40-column sweep; nothing for the other shapes)
     const int pcol = sh.oneset ? (ncol + 15) / 16 * 16 : ncol;
@@ -1537,33 +1233,17 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         A.ablate = 0;
         A.counters = nullptr;
         A.of_m = ts.d_of_m.as<MTasks>(); A.arow = ts.d_arow.as<long long>(); A.arow0 = ts.arow[m0];
-        if (!sh.quad) A.tasks = ts.d_tasks.as<LegTask>();  // the pipelined kernel indexes the whole list through of_m
-        if (!sh.quad) HX_HIP(hipMemsetAsync(pl->partial.p, 0, (size_t)(ts.arow[m1] - ts.arow[m0]) * pcol * sizeof(double), st));
+        A.tasks = ts.d_tasks.as<LegTask>();  // the pipelined kernel indexes the whole list through of_m
+        HX_HIP(hipMemsetAsync(pl->partial.p, 0, (size_t)(ts.arow[m1] - ts.arow[m0]) * pcol * sizeof(double), st));
 #if defined(HX_DIAG) && (HX_PIPE_ABL & 8)
         HX_TRY(pl->d_dbg.alloc(144));
         HX_HIP(hipMemsetAsync(pl->d_dbg.p, 0, 144, st));
         A.counters = pl->d_dbg.as<unsigned long long>();
 #endif
-#ifdef HX_DIAG  // diagnostic builds only (tools/): phases of the first kernel can be switched off, results are then wrong
-        const char *e = getenv("HX_ABLATE");
-        A.ablate = e ? atoi(e) : 0;
-        if (A.ablate & 8) {
-            HX_TRY(pl->d_dbg.alloc(64));
-            HX_HIP(hipMemsetAsync(pl->d_dbg.p, 0, 64, st));
-            A.counters = pl->d_dbg.as<unsigned long long>();
-        }
-#endif
         const double2 *cn = SPIN == 0 ? pl->cn0.as<double2>() : pl->cn2.as<double2>();
         const double *al = SPIN == 0 ? pl->al0.as<double>() : pl->al2.as<double>();
-        constexpr int NW = LegCfg<SPIN>::NW;
-        dim3 grid((unsigned)(t1 - t0)), block(NW * 64), pblock(PipeCfg<SPIN>::NW * 64), pgrid((unsigned)nm);
-        constexpr int QSUB = SPIN == 2 ? HX_QSUB2 : HX_QSUB0;
-        constexpr int QNW = SPIN == 0 ? HX_QNW0 : NW;  // waves per work-group of the 4x4x4 variants
-        if (sh.quad == 1)
-            hipLaunchKernelGGL((k_legendre_analysis<SPIN, -1, 0, QSUB, QNW>), grid, dim3(QNW * 64), 0, st, A, cn, al);
-        else if (sh.quad == 2)  // 140 VGPRs: two half-size groups do not fit a CU (104 vs 91 ms)
-            hipLaunchKernelGGL((k_legendre_analysis<SPIN, -2, 0, QSUB>), grid, block, 0, st, A, cn, al);
-        else if (sh.ng == 1 && sh.nbx == 0 && pipe_nsub(SPIN) == 2)
+        dim3 pblock(PipeCfg<SPIN>::NW * 64), pgrid((unsigned)nm);
+        if (sh.ng == 1 && sh.nbx == 0 && pipe_nsub(SPIN) == 2)
             hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 0, 2>), pgrid, pblock, 0, st, A, cn, al);
         else if (sh.ng == 1 && sh.nbx == 0)
             hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 0, 1>), pgrid, pblock, 0, st, A, cn, al);
@@ -1580,7 +1260,7 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         else
             return fail(HX_ERR_ARG, "legendre analysis: no kernel for %d groups + %d blocks", sh.ng, sh.nbx);
 #if defined(HX_DIAG) && (HX_PIPE_ABL & 8)
-        if (!sh.quad) {
+        {
             unsigned long long hc[18];
             HX_HIP(hipStreamSynchronize(st));
             HX_HIP(hipMemcpy(hc, pl->d_dbg.p, 144, hipMemcpyDeviceToHost));
@@ -1593,37 +1273,19 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
                         100.0 * hc[i] / tot, hc[8 + i], hc[8 + i] ? (double)hc[i] / hc[8 + i] : 0.0);
         }
 #endif
-#ifdef HX_DIAG
-        if (A.ablate & 8) {
-            unsigned long long hc[4] = {0, 0, 0, 0};
-            HX_HIP(hipStreamSynchronize(st));
-            HX_HIP(hipMemcpy(hc, pl->d_dbg.p, 32, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[hx] spin %d m [%d,%d) legendre wave-blocks: dead %llu live %llu mixed %llu\n", SPIN, m0, m1, hc[0], hc[1], hc[2]);
-        }
-#endif
     }
     {
         ProfScope ps("alm_reduce");
         hipLaunchKernelGGL(k_alm_reduce<SPIN>, dim3(nm), dim3(256), 0, st, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
-                           pl->partial.as<double>(), sh.quad ? ts.rows_before_m[m0] : ts.arow[m0], m0, ms, nb, ng, pcol, d_fl, add, d_alms, pl->nlm,
-                           sh.quad ? nullptr : ts.d_arow.as<long long>());
+                           pl->partial.as<double>(), ts.arow[m0], m0, ms, nb, ng, pcol, d_fl, add, d_alms, pl->nlm, ts.d_arow.as<long long>());
     }
     HX_HIP(hipGetLastError());
     return HX_OK;
 }
 
 // Batches of <= 4 spin-0 maps / <= 2 spin-2 fields: one sweep PER MAP / FIELD of the vector-unit kernel (hx_legendre_valu.hip).
-// The ring Fourier stage runs once for the whole batch.  HX_VALU=0 keeps the 4x4x4 kernels of round 1 (A/B switch).
-static bool valu_enabled()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("HX_VALU");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return v == 1;
-}
-static bool valu_batch(int spin, int nb) { return valu_enabled() && nb <= 4; }
+// The ring Fourier stage runs once for the whole batch.
+static bool valu_batch(int spin, int nb) { return sweep_shape(spin, nb).valu != 0; }
 
 static int analysis_batch_valu(hx_plan *pl, int spin, int nb, const double *d_maps, double2 *d_alms, const double *d_rw,
                                const double *d_pw, const double *d_fl, int add)
@@ -1695,10 +1357,8 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     // doubles per F / partial row: only the columns in use are stored -- 4-column granularity on the
     // 4x4x4 path (<= 8 columns), 16 per full group + 4 per extra block on the pipelined kernel
     const SweepShape sh = sweep_shape(spin, nb);
-    const bool half = sh.quad == 1 && spin == 0 && HX_QNW0 < LegCfg<0>::NW;
-    if (half) HX_TRY(build_task_set(pl, 0, HX_QNW0, pl->ts[2]));
     if (sh.oneset) HX_TRY(build_task_set(pl, 2, PipeCfg<2>::NW * PipeCfg<2>::RBS, pl->ts[3]));  // one ring set per wave: 4 ring blocks per task
-    hx_plan::TaskSet &ts = sh.oneset ? pl->ts[3] : (half ? pl->ts[2] : pl->ts[sidx]);
+    hx_plan::TaskSet &ts = sh.oneset ? pl->ts[3] : pl->ts[sidx];
     const int ncol = sh.ncol;
     if (pl->hsrc == nullptr && pl->nssrc == nullptr) {
         HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
@@ -1717,8 +1377,8 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     }
     const double f_per_m = (double)pl->nrp_pad * 2 * nop * ncol * sizeof(double);
     const int lmax = pl->lmax;
-    // rows of the partial buffer: one span per (m, ring group) on the 4x4x4 kernels, one per m on the pipelined kernel
-    const std::vector<long long> &prow = sh.quad ? ts.rows_before_m : ts.arow;
+    // rows of the partial buffer: one span per m (the pipelined kernel adds its ring groups in place)
+    const std::vector<long long> &prow = ts.arow;
     const int pcol = sh.oneset ? (ncol + 15) / 16 * 16 : ncol;  // doubles per row of the partial buffer (launch_chunk)
     std::vector<std::pair<int, int>> chunks;
     size_t maxF = 16, maxP = 16;
@@ -1772,7 +1432,7 @@ extern "C" int hx_plan_mfma_flops(hx_plan *pl, int spin, int ncomp, double *flop
     for (int c0 = 0, nb = 0; c0 < ncomp; c0 += nb) {
         nb = analysis_next_batch(spin, ncomp - c0);
         const SweepShape sh = sweep_shape(spin, nb);
-        per_wave_block += 16.0 * nop * (sh.ng * 2048.0 + (sh.nbx + sh.quad) * 512.0);
+        per_wave_block += 16.0 * nop * (sh.ng * 2048.0 + sh.nbx * 512.0);  // (sweeps on the vector unit issue none)
     }
     *flops = wave_blocks * per_wave_block;
     return HX_OK;

@@ -195,22 +195,43 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
         const double *pwN = pixw + sN, *pwS = pixw + (haveS ? sS : sN);
         const double2 *zp = zin + (long long)c * P.ny + sN;
         double2 z[RING_FB][4];
+        // A thread takes PAIRS of neighbouring j (j = 2 p, 2 p + 1, p = tid + k nt): one 16-byte load per ring, segment q and pair
+        // instead of two 8-byte ones -- with pixel weights a batch is 64 loads, not 128 (the fill is bound by the number of load
+        // instructions in flight, not by bytes).  An odd n leaves a last pair of one element: it reads the pair before it and
+        // shifts (the segment [q n, (q + 1) n) is followed by the next one -- or, for q = 3, by the next ring, which the last
+        // ring of the map does not have).
+        struct __attribute__((aligned(8))) Pair { double x, y; };
         auto load_batch = [&](int u0) __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < RING_FB; ++u) {
-                const int j = tid + (u0 + u) * nt, jj = j < n ? j : 0;
+            for (int u = 0; u < RING_FB; u += 2) {
+                const int j = 2 * (tid + ((u0 + u) >> 1) * nt);      // first j of the pair; the batch covers j < (u0 + RING_FB) nt
+                const bool tail = j == n - 1 && n >= 2;              // (n = 1: the scalar path below)
+                const int jj = tail ? n - 2 : (j + 1 < n ? j : 0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int i = jj + q * n;
                     if (MODE == 0) {
 #if HX_FFT_ABL & 16
-                        z[u][q] = make_double2(1.0 + j, 2.0 + q); continue;
+                        z[u][q] = make_double2(1.0 + j, 2.0 + q); z[u + 1][q] = z[u][q]; continue;
 #endif
-                        double fn = mpN[i], fs = mpS[i];
-                        if (pw) { fn *= pwN[i]; fs *= pwS[i]; }
-                        z[u][q] = make_double2(fn, haveS ? fs : 0.0);
+                        Pair fn, fs;
+                        if (n >= 2) {
+                            fn = *reinterpret_cast<const Pair *>(mpN + i);
+                            fs = *reinterpret_cast<const Pair *>(mpS + i);
+                            if (pw) {
+                                const Pair wn = *reinterpret_cast<const Pair *>(pwN + i), ws = *reinterpret_cast<const Pair *>(pwS + i);
+                                fn.x *= wn.x; fn.y *= wn.y; fs.x *= ws.x; fs.y *= ws.y;
+                            }
+                        } else {
+                            fn.x = fn.y = mpN[q]; fs.x = fs.y = mpS[q];
+                            if (pw) { fn.x *= pwN[q]; fs.x *= pwS[q]; fn.y = fn.x; fs.y = fs.x; }
+                        }
+                        z[u][q] = make_double2(tail ? fn.y : fn.x, haveS ? (tail ? fs.y : fs.x) : 0.0);
+                        z[u + 1][q] = make_double2(fn.y, haveS ? fs.y : 0.0);
                     } else {
-                        z[u][q] = zp[i];
+                        const int i0 = (j < n ? j : 0) + q * n, i1 = (j + 1 < n ? j + 1 : 0) + q * n;
+                        z[u][q] = zp[i0];
+                        z[u + 1][q] = zp[i1];
                     }
                 }
             }
@@ -239,7 +260,7 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
             for (int u0 = 0;;) {
 #pragma unroll
                 for (int u = 0; u < RING_FB; ++u) {
-                    const int j = tid + (u0 + u) * nt;
+                    const int j = 2 * (tid + ((u0 + u) >> 1) * nt) + (u & 1);  // the pairs of load_batch
                     const double2 e0 = odd ? csub(z[u][0], z[u][2]) : cadd(z[u][0], z[u][2]);
                     const double2 e1 = odd ? mul_mi(csub(z[u][1], z[u][3])) : cadd(z[u][1], z[u][3]);
                     const double2 t = make_double2(fma(sg, e1.x, e0.x), fma(sg, e1.y, e0.y));

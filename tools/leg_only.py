@@ -10,12 +10,13 @@ nside, lmax = int(os.environ.get("NSIDE", 2048)), int(os.environ.get("LMAX", 307
 spin = int(os.environ.get("SPIN", 0))
 plan = hx.Plan(nside, lmax)
 m = torch.randn((int(os.environ.get("NCOMP", 8)), 12 * nside * nside), dtype=torch.float64, device="cuda")
+pw = torch.ones(12 * nside * nside, dtype=torch.float64, device="cuda") if os.environ.get("PW") == "1" else None  # PW=1: with pixel weights
 for _ in range(2):
-    plan.map2alm(m, spin)
+    plan.map2alm(m, spin, pix_weights=pw)
 hx._lib.profile_enable(True); hx._lib.profile_reset()
-plan.map2alm(m, spin)
+plan.map2alm(m, spin, pix_weights=pw)
 out = []
 for fam in ("ring_fft", "fourier_combine", "legendre_analysis", "alm_reduce"):
     n, ms = hx._lib.profile_get(fam)
     out.append("%s %.2f ms / %d" % (fam, ms, n))
-print("spin", spin, "ncomp", m.shape[0], "|", " | ".join(out), "| lib", os.environ.get("HX_LIBRARY", "default"))
+print("spin", spin, "ncomp", m.shape[0], "pw" if pw is not None else "", "|", " | ".join(out), "| lib", os.environ.get("HX_LIBRARY", "default"))
