@@ -188,8 +188,13 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_valu(ValuParams 
 {
     using C = ValuCfg<SPIN>;
     constexpr int R = C::R, LB = C::LB, NA = C::NA, NF = C::NF, NCH = 2;
-    __shared__ double2 cfs[2][LB];  // recursion coefficients of this / the next block
-    __shared__ double als[2][LB];   // output scalings alpha_l
+    // recursion coefficients and output scalings alpha_l arrive in CHUNKS of CH = 32 l (this / the next chunk): the next chunk is
+    // requested when a chunk starts and stored when it ends -- four (spin 0) / eight (spin 2) blocks later.  Handed over block by
+    // block, the request had one block (~1300 cycles) to come back from L2 / HBM and every block ended waiting for it.
+    constexpr int CH = 32, NSB = CH / LB;
+    static_assert(CH % LB == 0, "a chunk is a whole number of blocks");
+    __shared__ double2 cfs[2][CH];
+    __shared__ double als[2][CH];
     const PlanDev &P = A.P;
     const LegTask task = A.tasks[blockIdx.x];
     const int m = task.m, lmax = P.lmax, lane = threadIdx.x;
@@ -286,30 +291,33 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_valu(ValuParams 
     using BT = std::integral_constant<bool, true>;
     using BF = std::integral_constant<bool, false>;
 
-    if (lane < LB) {
+    if (lane < CH) {
         cfs[0][lane] = coefn[cb + l0 + coff + lane];
         als[0][lane] = alphan[cb + l0 + lane];
     }
     __syncthreads();
     double *prow = A.partial + (task.pout - A.row0) * NA;
-    int buf = 0, lb = l0;
+    int buf = 0, lb = l0, sb = 0;  // sb: block within the chunk
     constexpr int SH = LB * NA == 32 ? 1 : 2;  // after the butterfly lane L holds accumulator L >> SH = (l - lb) NA + a
-    // coefficient hand-over of a block: the next block's values are requested at its start and stored to LDS at its end
+    // coefficient hand-over: the next chunk's values are requested at the start of a chunk and stored to LDS at its end
     double2 cpre = make_double2(0.0, 0.0);
     double apre = 0.0;
     auto stage_begin = [&]() __attribute__((always_inline)) {
-        if (lane < LB) {
-            cpre = coefn[cb + lb + LB + coff + lane];
-            apre = alphan[cb + lb + LB + lane];
+        if (sb == 0 && lane < CH) {  // (lb is the first l of the chunk here)
+            cpre = coefn[cb + lb + CH + coff + lane];
+            apre = alphan[cb + lb + CH + lane];
         }
     };
     auto stage_end = [&]() __attribute__((always_inline)) {
-        if (lane < LB) {
-            cfs[buf ^ 1][lane] = cpre;
-            als[buf ^ 1][lane] = apre;
+        if (++sb == NSB) {
+            sb = 0;
+            if (lane < CH) {
+                cfs[buf ^ 1][lane] = cpre;
+                als[buf ^ 1][lane] = apre;
+            }
+            __syncthreads();
+            buf ^= 1;
         }
-        __syncthreads();
-        buf ^= 1;
     };
     // Scaled chains are promoted (and the state of the wave is looked at) every CHK l: the 16 promotions of a check cost as much
     // as a block of recursions.  A chain grows by less than ~2^7 per step (lambda_{m+1,m} / lambda_mm = sqrt(2m+3) x at worst), i.e.
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_valu(ValuParams 
             if (HX_VALU_NODEAD || !__all(dead)) break;
         }
         stage_begin();
-        const double2 *cf = cfs[buf];
+        const double2 *cf = cfs[buf] + sb * LB;
 #pragma unroll
         for (int s = 0; s < LB; ++s) {
             const double2 c = cf[s];
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_valu(ValuParams 
         stage_begin();
 #pragma unroll
         for (int i = 0; i < LB * NA; ++i) acc[i] = 0.0;
-        const double2 *cf = cfs[buf];
+        const double2 *cf = cfs[buf] + sb * LB;
         if (!steady && bk % CHK == 0) {
             bool live = true;
 #pragma unroll
@@ -396,7 +404,7 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_valu(ValuParams 
         // ---- sum over the lanes, scale, store ----
         wave_reduce<LB * NA>(acc, lane);
         const int idx = lane >> SH, s = idx / NA, a = idx % NA;
-        double out = acc[0] * als[buf][s];
+        double out = acc[0] * als[buf][sb * LB + s];
         int col = a;
         if (SPIN == 2) {
             // lanes of accumulator a and a ^ 2 (G <-> K) differ in lane bit SH + 1: E = G + K, B = -i (G - K)

@@ -5,43 +5,46 @@
 // (the imaginary part of m=0 is ignored, twopoint.py:88).
 //
 // Layout: alm is m-major, so for fixed m consecutive l are contiguous: lanes map to l
-// (1 KiB coalesced per wave-load), the sum over m runs in-lane; the waves of a
-// workgroup split m round-robin and are combined through LDS in a fixed order, so results
-// are bit-reproducible run to run.  Components are tiled T x T so every alm value loaded is
-// used for T products (the reference re-reads each alm once per partner).
+// (1 KiB coalesced per wave-load), the sum over m runs in-lane.  Components are tiled 6 x 6, one wave per tile, 16 tiles per
+// work-group walking the orders together, so that a row is fetched from HBM once per l-block; the orders are split over a few
+// work-groups whose partial sums are added in a fixed order (bit-reproducible run to run).
+#include <algorithm>
+
 #include "hx_common.h"
 
 namespace hx {
 
-constexpr int CL_T = 6;        // component tile edge (4 -> 6: each alm is fetched ncomp/6 times; 13.4 -> 9.7 ms, 8 gains no more)
-constexpr int CL_WAVES = 3;    // waves per workgroup (m split); 3 x 36 x 64 doubles of LDS
-constexpr int CL_LB = 64;      // l values per workgroup
+constexpr int CL_T = 6;        // component tile edge: 36 accumulators per lane
+constexpr int CL_TW = 8;       // tiles (= waves) per work-group (16 would leave each wave 128 registers: 90 spilled)
+constexpr int CL_LB = 64;      // l values per work-group
+constexpr int CL_SYNC = 8;     // orders between two work-group barriers (keeps the waves on the same rows)
 
 struct ClTile {
     int i0, j0;               // first component of the tile along each axis
     int out[CL_T * CL_T];     // pair index of (i0+a, j0+b) or -1
 };
 
-__global__ __launch_bounds__(CL_WAVES * 64) void k_alm2cl_tiles(
+// A work-group = one block of 64 l x one share of the orders m x up to 8 component tiles, ONE WAVE PER TILE: the waves walk the
+// orders together (a barrier every CL_SYNC orders), so a row of an alm -- 64 consecutive l of one m, 1 KiB -- is fetched from HBM by
+// the first wave that needs it and comes from the CU's L1 / the XCD's L2 for the other tiles that share the component.  Every
+// (l, m) of every component belongs to exactly one work-group: HBM traffic = the alms once (30 GB -> 9 GB for the bench's 30
+// components; tiles as independent work-groups re-read each alm ncomp / 6 times: 50 GB, 30 GB with XCD-aware ordering).
+// The shares of the orders (msplit) are summed in a fixed order by k_alm2cl_finish: bitwise repeatable.
+__global__ __launch_bounds__(CL_TW * 64) void k_alm2cl_rows(
     const double2 *const *__restrict__ comp, const int *__restrict__ comp_lmax, int ncomp,
-    const ClTile *__restrict__ tiles, int ntiles, int lmax_out, int nlblk, double *__restrict__ cls, int m_lo, int m_hi, int m_step)
+    const ClTile *__restrict__ tiles, int ntiles, int ngroups, int nmsplit, int lmax_out, int nlblk, double *__restrict__ part, long long part_stride,
+    int m_lo, int m_hi, int m_step)
 {
-    __shared__ double red[CL_WAVES][CL_T * CL_T][CL_LB];
-    // Work-groups are dispatched to the 8 XCDs round-robin: XCD x = blockIdx % 8 walks the l-blocks 8 k + x, and for each of them
-    // ALL tiles back to back -- the tiles of one l-block read the same rows of the same alms at about the same time, so a row comes
-    // from HBM once and from that XCD's L2 for the other tiles (tile-major order re-read every alm ncomp / 6 times from HBM:
-    // 50 GB for the 9 GB of the bench).  Heavy (high-l) blocks first.
-    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-    const int lblk = nlblk - 1 - ((seq / ntiles) * 8 + xcd);
-    if (lblk < 0) return;
-    const ClTile tile = tiles[seq % ntiles];
+    // heavy (high-l) blocks first; consecutive work-groups = the shares of one (l-block, tile group)
+    const int ms = blockIdx.x % nmsplit, g = (blockIdx.x / nmsplit) % ngroups, lblk = nlblk - 1 - (int)(blockIdx.x / (nmsplit * ngroups));
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ti = g * CL_TW + w;
+    const bool have = ti < ntiles;
+    const ClTile tile = tiles[have ? ti : 0];
     const int l = lblk * CL_LB + lane;
     const int lhi = min(lblk * CL_LB + CL_LB - 1, lmax_out);
-
-    // A tile may hold components whose own band limit is below lmax_out (mixed-lmax alms: only the
-    // components of REQUESTED pairs are checked against lmax_out by the host).  Their loads are
-    // predicated on (m, l) lying inside their own triangle -- the index would otherwise leave the buffer.
+    // A tile may hold components whose own band limit is below lmax_out (mixed-lmax alms: only the components of REQUESTED pairs
+    // are checked against lmax_out by the host).  Their loads are predicated on (m, l) lying inside their own triangle.
     const double2 *pa[CL_T], *pb[CL_T];
     long long La[CL_T], Lb[CL_T];
 #pragma unroll
@@ -53,10 +56,11 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_alm2cl_tiles(
     double acc[CL_T * CL_T];
 #pragma unroll
     for (int t = 0; t < CL_T * CL_T; ++t) acc[t] = 0.0;
-
-    // the orders summed: m_lo, m_lo + m_step, ... < m_hi (everything for hx_alm2cl_pairs; one rank's share on the m-sharded route)
-    for (int m = m_lo + w * m_step; m <= min(lhi, m_hi - 1); m += CL_WAVES * m_step) {
-        if (m <= l && l <= lmax_out) {
+    // the orders of this share: m_lo + (k nmsplit + ms) m_step, k = 0, 1, ...  (< m_hi, <= the largest l of the block)
+    const int mend = min(lhi, m_hi - 1);
+    int k = 0;
+    for (int m = m_lo + ms * m_step; m <= mend; m += nmsplit * m_step, ++k) {
+        if (have && m <= l && l <= lmax_out) {
             double2 a[CL_T], b[CL_T];
 #pragma unroll
             for (int t = 0; t < CL_T; ++t) {
@@ -73,21 +77,26 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_alm2cl_tiles(
                     acc[s * CL_T + t] = fma(wgt, p, acc[s * CL_T + t]);
                 }
         }
+        if ((k & (CL_SYNC - 1)) == CL_SYNC - 1) __syncthreads();  // (the trip count is the same for every wave of the group)
     }
+    if (have && l <= lmax_out) {
 #pragma unroll
-    for (int t = 0; t < CL_T * CL_T; ++t) red[w][t][lane] = acc[t];
-    __syncthreads();
-    // fixed-order combine; thread (w, lane) finishes pairs t = w, w + CL_WAVES, ...
-    if (l <= lmax_out) {
-        for (int t = w; t < CL_T * CL_T; t += CL_WAVES) {
-            int o = tile.out[t];
-            if (o < 0) continue;
-            double s = 0.0;
-#pragma unroll
-            for (int ww = 0; ww < CL_WAVES; ++ww) s += red[ww][t][lane];
-            cls[(long long)o * (lmax_out + 1) + l] = s / (2.0 * l + 1.0);
+        for (int t = 0; t < CL_T * CL_T; ++t) {
+            const int o = tile.out[t];
+            if (o >= 0) part[(long long)ms * part_stride + (long long)o * (lmax_out + 1) + l] = acc[t];
         }
     }
+}
+
+// cls[pair][l] = (sum over the shares, in order) / (2 l + 1)
+__global__ __launch_bounds__(256) void k_alm2cl_finish(const double *__restrict__ part, long long part_stride, int nmsplit, long long n, int lmax_out,
+                                                        double *__restrict__ cls)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int q = 0; q < nmsplit; ++q) s += part[(long long)q * part_stride + i];
+    cls[i] = s / (2.0 * (double)(i % (lmax_out + 1)) + 1.0);
 }
 
 }  // namespace hx
@@ -161,6 +170,8 @@ extern "C" int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double 
             t.out[slot] = p;
     }
     (void)nb;
+    // tiles of one work-group share components when they are neighbours in (i0, j0) order
+    std::stable_sort(tiles.begin(), tiles.end(), [](const ClTile &x, const ClTile &y) { return x.i0 != y.i0 ? x.i0 < y.i0 : x.j0 < y.j0; });
     DevBuf d_ptrs, d_lmax, d_tiles;
     HX_TRY(d_ptrs.alloc(sizeof(void *) * ncomp));
     HX_TRY(d_lmax.alloc(sizeof(int) * ncomp));
@@ -172,12 +183,21 @@ extern "C" int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double 
     HX_TRY(out.bind(cls, sizeof(double) * (size_t)npairs * (lmax_out + 1)));
 
     const int nlblk = (lmax_out + CL_LB) / CL_LB;
+    const int ngroups = ((int)tiles.size() + CL_TW - 1) / CL_TW;
+    // shares of the orders per (l-block, tile group): enough work-groups for ~2.5 rounds of the CUs (one work-group fills a CU)
+    int nmsplit = (int)((2.5 * rt().cus) / ((double)nlblk * ngroups) + 0.5);
+    nmsplit = std::max(1, std::min(nmsplit, 8));
+    const long long nout = (long long)npairs * (lmax_out + 1);
+    DevBuf d_part;
+    HX_TRY(d_part.alloc(sizeof(double) * (size_t)nout * nmsplit));
+    HX_HIP(hipMemsetAsync(d_part.p, 0, sizeof(double) * (size_t)nout * nmsplit, st));  // (shares without orders write nothing)
     {
         ProfScope ps("alm2cl");
-        const unsigned nlb8 = (unsigned)((nlblk + 7) / 8);  // l-blocks per XCD
-        hipLaunchKernelGGL(k_alm2cl_tiles, dim3(nlb8 * 8u * (unsigned)tiles.size()), dim3(CL_WAVES * 64), 0, st,
-                           d_ptrs.as<const double2 *>(), d_lmax.as<int>(), ncomp, d_tiles.as<ClTile>(), (int)tiles.size(),
-                           lmax_out, nlblk, out.as<double>(), m0, m1, mstep);
+        hipLaunchKernelGGL(k_alm2cl_rows, dim3((unsigned)(nlblk * ngroups * nmsplit)), dim3(CL_TW * 64), 0, st,
+                           d_ptrs.as<const double2 *>(), d_lmax.as<int>(), ncomp, d_tiles.as<ClTile>(), (int)tiles.size(), ngroups, nmsplit,
+                           lmax_out, nlblk, d_part.as<double>(), nout, m0, m1, mstep);
+        hipLaunchKernelGGL(k_alm2cl_finish, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, d_part.as<double>(), nout, nmsplit, nout,
+                           lmax_out, out.as<double>());
     }
     HX_HIP(hipGetLastError());
     HX_TRY(out.finish());
