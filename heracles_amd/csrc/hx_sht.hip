@@ -345,6 +345,105 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
 }
 
 // =====================================================================================
+// 1a. rings of 4 x 2^k pixels (the equatorial belt, and the cap rings with n = 2^k): plain FFTs, no Bluestein convolution.  The
+//     four work items of a (ring pair, component) of the kernel above each read ALL of the pair's pixels (and pixel weights): 3 of
+//     the 4 reads come from L2, but the belt is 5120 of the 8192 ring pairs at nside 4096 and its items spend 60 % (without weights)
+//     to 80 % (with) of their cycles waiting for those reads (tools/fft_ablate.sh 32: load + fill 102k of 173k / 275k of 337k
+//     cycles per ring pair and component) -- 515 GB through the L2s per step of the bench.  Here a work item is TWO sub-DFTs,
+//     r and r + 2: they are the sum and the difference of the same two combinations of the four segments
+//         t_r = e0 + e1,  t_{r+2} = e0 - e1,   e0 = z0 +- z2,  e1 = z1 +- z3 (x -i for odd r),
+//     so one read of the pixels fills two LDS buffers, and the two halves of the work-group (M / 16 threads each) run one
+//     transform each: half the reads.  Two 4096-point buffers are 139 KiB: one group of 512 threads per CU.
+// =====================================================================================
+template <int MODE>
+__global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const int *__restrict__ rp_list, int nrings, int nb, int M,
+                                                             const double *__restrict__ maps, const double *__restrict__ pixw,
+                                                             const double2 *__restrict__ zin, double2 *__restrict__ Y)
+{
+    extern __shared__ double2 buf[];  // two padded buffers of M points, then the phase tables (4 M / 64 + 1 and 64 entries)
+    __shared__ double2 tw_hi[TW_HI_MAX], tw_lo[64];
+    const int MP = lds_fft_slots(M), n = M, p = ilog2(M);
+    double2 *ph_hi = buf + 2 * MP, *ph_lo = ph_hi + ring_ph_hi(M);
+    const int nt = blockDim.x, nh = nt >> 1;  // threads of the group / of one transform
+    // HX_PAIR_ROUNDS 1: two work items per (ring pair, component), on one XCD side by side; 2: one work item runs both rounds from ONE
+    // read, its pixels (128 registers) kept across the transforms -- 46 registers spilled: 18.9 vs 19.4 ms per 8 components with
+    // pixel weights, 15.1 vs 14.3 without, same device: not the default
+#ifndef HX_PAIR_ROUNDS
+#define HX_PAIR_ROUNDS 1
+#endif
+    const int nitems = HX_PAIR_ROUNDS == 2 ? nrings * nb : ((nrings + 7) >> 3) * nb * 16;
+    const TwFactored twf = load_tw_factored(tw_hi, tw_lo, P.tw, P.twN);
+    const double inv4n = 0.25 / (double)n;
+    int tid = threadIdx.x;
+    // the phase tables depend on n = M only: built once per group
+    for (int a = tid; a <= (4 * n) >> 6; a += nt) ph_hi[a] = expipi(-(double)(a << 6) / (2.0 * n));
+    if (tid < 64) ph_lo[tid] = expipi(-(double)tid / (2.0 * n));
+    __syncthreads();
+    auto phase = [&](unsigned q) __attribute__((always_inline)) { return cmul(ph_hi[q >> 6], ph_lo[q & 63]); };  // exp(-i pi q / 2n), q < 4n
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        // one round per item: item = 8 (2 s + rpair) + x -- the two items of set s = (ring set s / nb, component s % nb) on XCD x
+        const int rfirst = HX_PAIR_ROUNDS == 2 ? 0 : (item >> 3) & 1, set = item >> 4;
+        const int ring = HX_PAIR_ROUNDS == 2 ? item / nb : (set / nb) * 8 + (item & 7), c = HX_PAIR_ROUNDS == 2 ? item % nb : set % nb;
+        if (ring >= nrings) continue;
+        const int rp = rp_list[ring];
+        const long long sN = P.startN[rp], sS = P.startS[rp];
+        asm volatile("; item" : "+v"(tid));
+        const bool haveS = sS >= 0, pw = MODE == 0 && pixw != nullptr;
+        const double *mpN = maps + (long long)c * P.npix + sN, *mpS = maps + (long long)c * P.npix + (haveS ? sS : sN);
+        const double *pwN = pixw + sN, *pwS = pixw + (haveS ? sS : sN);
+        const double2 *zp = zin + (long long)c * P.ny + sN;
+        struct __attribute__((aligned(8))) Pair { double x, y; };
+        // pairs of neighbouring j: 2 (tid + k nt), k < 4 (n / 2 pairs over nt = n / 8 threads, or 128 threads for n <= 1024)
+        double2 z[RING_FB][4];
+#pragma unroll
+        for (int u = 0; u < RING_FB; u += 2) {
+            const int j = 2 * (tid + (u >> 1) * nt), jj = j + 1 < n ? j : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = jj + q * n;
+                if (MODE == 0) {
+                    Pair fn = *reinterpret_cast<const Pair *>(mpN + i), fs = *reinterpret_cast<const Pair *>(mpS + i);
+                    if (pw) {
+                        const Pair wn = *reinterpret_cast<const Pair *>(pwN + i), ws = *reinterpret_cast<const Pair *>(pwS + i);
+                        fn.x *= wn.x; fn.y *= wn.y; fs.x *= ws.x; fs.y *= ws.y;
+                    }
+                    z[u][q] = make_double2(fn.x, haveS ? fs.x : 0.0);
+                    z[u + 1][q] = make_double2(fn.y, haveS ? fs.y : 0.0);
+                } else {
+                    z[u][q] = zp[i];
+                    z[u + 1][q] = zp[i + 1];
+                }
+            }
+        }
+        // round 0 = sub-DFTs 0 and 2, round 1 = sub-DFTs 1 and 3 (one round per work item by default: HX_PAIR_ROUNDS)
+#pragma unroll 1
+        for (int rpair = rfirst; rpair < rfirst + HX_PAIR_ROUNDS; ++rpair) {
+        // (the previous round's read-out has to be over before the buffers are filled again)
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int u = 0; u < RING_FB; ++u) {
+            const int j = 2 * (tid + (u >> 1) * nt) + (u & 1);
+            if (j >= n) continue;
+            const double2 e0 = rpair ? csub(z[u][0], z[u][2]) : cadd(z[u][0], z[u][2]);
+            const double2 e1 = rpair ? mul_mi(csub(z[u][1], z[u][3])) : cadd(z[u][1], z[u][3]);
+            // load phases exp(-i pi j r / 2n) of r = rpair and r + 2
+            const unsigned q0 = mod_by_inv((unsigned)j * (unsigned)rpair, 4u * (unsigned)n, inv4n);
+            const unsigned q1 = mod_by_inv((unsigned)j * (unsigned)(rpair + 2), 4u * (unsigned)n, inv4n);
+            buf[lds_slot(j)] = cmul(cadd(e0, e1), phase(q0));
+            buf[MP + lds_slot(j)] = cmul(csub(e0, e1), phase(q1));
+        }
+        __syncthreads();
+        const int half = tid >= nh ? 1 : 0, gt = tid - half * nh;
+        double2 *bh = buf + half * MP;
+        lds_fft_dif(bh, M, twf, P.twN, gt, nh);
+        double2 *out = Y + (long long)c * P.ny + sN + (long long)(rpair + 2 * half) * n;
+        for (int k = gt; k < n; k += nh) out[k] = bh[lds_slot(bitrev(k, p))];
+        }  // rounds
+    }
+}
+
+// =====================================================================================
 // 1b. rings whose Bluestein convolution does not fit LDS (nside 8192: cap rings with 4096 < n < 8192 need M = 16384 points
 //     = 256 KiB): the length-M cyclic convolution as an EVEN and an ODD half of C = M / 2 points each
 //         X[2k]   = FFT_C( x[j] + x[j + C] )[k],      X[2k+1] = FFT_C( (x[j] - x[j + C]) W_M^j )[k]         (forward, DIF)
@@ -623,6 +722,8 @@ static int plan_tables(hx_plan *pl)
     // 3 KiB of the 160 KiB are the static twiddle tables of k_ring_subdft
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_pairfft<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_pairfft<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_bhat_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft_split<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft_split<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
@@ -677,8 +778,13 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
     {
         // FFT-size classes: ring pairs grouped by in-LDS FFT length, longest rings first; rings beyond the limit form
         // the split class (M = 2 x cap)
+        // (second key: 0 regular kernel; -1 plain 2^k rings whose two buffers fit LDS: the pair kernel)
         std::map<std::pair<int, int>, std::vector<int>> byM;
-        for (int rp = pl->nrp - 1; rp >= 0; --rp) byM[{fft_size_for(nsub[rp]), 0}].push_back(rp);
+        for (int rp = pl->nrp - 1; rp >= 0; --rp) {
+            const int M = fft_size_for(nsub[rp]);
+            const bool pair = M == nsub[rp] && M >= 16 && M <= cap && (2 * (size_t)lds_fft_slots(M) + ring_ph_hi(M) + 64) * sizeof(double2) + 4096 <= 160 * 1024;
+            byM[{M, pair ? -1 : 0}].push_back(rp);
+        }
         std::vector<int> list;
         for (auto it = byM.rbegin(); it != byM.rend(); ++it) {
             hx_plan::FftClass c;
@@ -809,6 +915,16 @@ template <int MODE>
 static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, const double2 *zin, double2 *Y)
 {
     for (const auto &c : pl->fft_classes) {
+        if (c.big < 0) {  // plain 2^k rings: two sub-DFTs per work item (k_ring_pairfft)
+            const int threads = 2 * std::max(64, c.M / 16);
+            const size_t lds = (size_t)(2 * lds_fft_slots(c.M) + ring_ph_hi(c.M) + 64) * sizeof(double2);
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(512 / threads, (160 * 1024) / (lds + 3 * 1024 + 256)));
+            const long long items = HX_PAIR_ROUNDS == 2 ? (long long)c.count * nb : ((long long)c.count + 7) / 8 * nb * 16;
+            const unsigned groups = (unsigned)std::min<long long>(items, (long long)rt().cus * per_cu);
+            hipLaunchKernelGGL(k_ring_pairfft<MODE>, dim3(groups), dim3(threads), lds, rt().stream,
+                               pl->dev(), pl->fft_rp_list.as<int>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+            continue;
+        }
         if (c.M > pl->fft_cap || c.big) {  // Bluestein convolution of 2 x cap points in two halves / plain FFT of > 4096 points
             const int C = std::min(c.M, pl->fft_cap), threads = std::min(512, std::max(64, C / SPLIT_JMAX));
             hipLaunchKernelGGL(k_ring_subdft_split<MODE>, dim3(1, c.count, nb), dim3(threads), (size_t)lds_fft_slots(C) * sizeof(double2), rt().stream,
