@@ -1287,12 +1287,21 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
 // The ring Fourier stage runs once for the whole batch.
 static bool valu_batch(int spin, int nb) { return sweep_shape(spin, nb).valu != 0; }
 
-static int analysis_batch_valu(hx_plan *pl, int spin, int nb, const double *d_maps, double2 *d_alms, const double *d_rw,
-                               const double *d_pw, const double *d_fl, int add)
+int valu_tasks(hx_plan *pl, int spin, hx_plan::TaskSet **out)
 {
     if (spin) HX_TRY(ensure_rec2(pl));
     hx_plan::TaskSet &ts = spin ? pl->ts[4] : pl->ts[5];
     HX_TRY(build_task_set(pl, spin, valu_task_blocks(spin), ts));
+    *out = &ts;
+    return HX_OK;
+}
+
+static int analysis_batch_valu(hx_plan *pl, int spin, int nb, const double *d_maps, double2 *d_alms, const double *d_rw,
+                               const double *d_pw, const double *d_fl, int add)
+{
+    hx_plan::TaskSet *tsp = nullptr;
+    HX_TRY(valu_tasks(pl, spin, &tsp));
+    hx_plan::TaskSet &ts = *tsp;
     if (pl->hsrc == nullptr && pl->nssrc == nullptr) {
         HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
         HX_TRY(launch_ring_subdft_maps(pl, nb, d_maps, d_pw, pl->Y.as<double2>()));

@@ -426,6 +426,302 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_valu(ValuParams 
 }
 
 // =====================================================================================
+// synthesis (alm -> ring modes) of one map / field on the vector unit: the mirror image of k_legendre_valu
+// =====================================================================================
+// healpy's map2alm runs Jacobi iterations by default (iter = 3: SURVEY 8a-2): three of the seven transforms of every
+// Mapper.transform the reference issues (heracles/healpy.py:183-189) are SYNTHESES of a single map, and so is every hp.alm2map.
+// In this direction the sum runs over l, inside one lane: with lane = ring pair there is no cross-lane reduction at all --
+//   per (ring pair, l): 2 FMAs of the normalised recursion + 2 (spin 0) / 8 (spin 2) FMAs  acc += lambda_l(theta) x (alpha_l a_lm),
+//   alpha_l a_lm wave-uniform (a broadcast read from the chunk tables in LDS, 32 l at a time, as in the analysis kernel);
+//   spin 0: the even and the odd chain have an accumulator pair each:  F_N = E + O, F_S = E - O;
+//   spin 2: P+_N = sum lambda+ a+,  P-_S = sum (-1)^(l+m) lambda+ a-,  P-_N = sum lambda- a-,  P+_S = sum (-1)^(l+m) lambda- a+,
+//           a+- = -(E +- iB);  Q = (P+ + P-) / 2,  U = (P+ - P-) / 2i.
+// Every accumulator belongs to ONE chain.  A scaled chain (exponent < 0) is not masked inside the loop: what it adds between two
+// checks is dropped at the next check (its accumulators are zeroed as long as it is not live: it has never contributed before),
+// and at the end.  Output Fv[m][ring pair][NV]: (N_re, N_im, S_re, S_im) per component -- spin 2: Q then U.
+template <int SPIN>
+struct SynValuCfg {
+    static constexpr int R = ValuCfg<SPIN>::R;     // the task sets of the analysis kernel (2 R ring blocks per task)
+    static constexpr int LB = SPIN == 0 ? 8 : 4;   // l per unrolled block (even; spin 2 with 8: 58 registers beyond the 256 a lane can address)
+    static constexpr int NAV = SPIN == 0 ? 2 : 4;  // doubles of alpha_l a_lm per l
+    static constexpr int NV = SPIN == 0 ? 4 : 8;   // output doubles per (m, ring pair)
+};
+int synth_valu_doubles(int spin) { return spin == 0 ? SynValuCfg<0>::NV : SynValuCfg<2>::NV; }
+
+struct SynValuParams {
+    PlanDev P;
+    const LegTask *__restrict__ tasks;
+    const double2 *__restrict__ alm;  // spin 0: the map's alm; spin 2: E, then B at + alm_stride
+    long long alm_stride;
+    double *__restrict__ Fv;          // [m][rp][NV]
+};
+
+template <int SPIN>
+__global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_synth_valu(SynValuParams A, const double2 *__restrict__ coefn, const double *__restrict__ alphan)
+{
+    using C = SynValuCfg<SPIN>;
+    constexpr int R = C::R, LB = C::LB, NAV = C::NAV, NV = C::NV, NCH = 2;
+    constexpr int CH = 32, NSB = CH / LB;
+    __shared__ double2 cfs[2][CH];
+    __shared__ double avs[2][CH][NAV];
+    const PlanDev &P = A.P;
+    const LegTask task = A.tasks[blockIdx.x];
+    const int m = task.m, lmax = P.lmax, lane = threadIdx.x;
+    const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
+    const int off = (l0 + m) & 1;        // parity of l + m at the first l (spin 2, m = 1 only)
+    const long long cb = almidx(lmax, 0, m);
+    const int coff = SPIN == 0 ? 0 : 1;  // spin-2 coefficients are indexed by the target l
+
+    double xx[R], vc[R][NCH], vp[R][NCH], acc[R][NV];
+    int sc[R][NCH];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = r * 64 + lane, rp = task.rb0 * RBLK + k;
+        const bool valid = k < task.nrb * RBLK && rp < P.nrp;
+        vmask |= valid ? (1u << r) : 0u;
+        const double x = valid ? P.z[rp] : 0.0;
+        xx[r] = SPIN == 0 ? x * x : x;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) acc[r][q] = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { vc[r][c] = 0.0; vp[r][c] = 0.0; sc[r][c] = -100; }
+        if (valid) {
+            if (SPIN == 0) {
+                SVal a = spow(P.sth[rp], m);
+                a.v *= P.mfac[m];
+                SVal b = a;
+                b.v *= sqrt(2.0 * m + 3.0) * x;
+                snorm_small(a);
+                snorm_small(b);
+                vc[r][0] = a.v; sc[r][0] = a.e;
+                vc[r][1] = b.v; sc[r][1] = b.e;
+            } else {
+                SVal sp, sm;
+                spin2_seeds(m, P.sth[rp], P.omz[rp], P.kfac2[m], sp, sm);
+                vc[r][0] = sp.v; sc[r][0] = sp.e;
+                vc[r][1] = sm.v; sc[r][1] = sm.e;
+            }
+        }
+    }
+    auto promote = [&](int r, int c) __attribute__((always_inline)) {
+        const int hc = __double2hiint(vc[r][c]), hp = __double2hiint(vp[r][c]);
+        const bool up = sc[r][c] < 0 && (hc & 0x7ff00000) >= 0x3ff00000;
+        const int sub = up ? (300 << 20) : 0;
+        const bool pz = up && (hp & 0x7ff00000) <= (300 << 20);
+        vc[r][c] = __hiloint2double(hc - sub, __double2loint(vc[r][c]));
+        vp[r][c] = pz ? 0.0 : __hiloint2double(hp - sub, __double2loint(vp[r][c]));
+        sc[r][c] += up ? 1 : 0;
+    };
+    // accumulators of chain c of slot r: spin 0: (2 c, 2 c + 1); spin 2: lambda+ (c = 0) 0..3, lambda- (c = 1) 4..7
+    auto drop = [&](int r, int c) __attribute__((always_inline)) {
+        const bool z = sc[r][c] != 0;
+        constexpr int NQ = NV / 2;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[r][c * NQ + q] = z ? 0.0 : acc[r][c * NQ + q];
+    };
+    // one l step of slot r (the registers of a chain swap roles from step to step, as in k_legendre_valu); av = alpha_l a_lm
+    auto step = [&](auto ACCC, int r, int s, const double2 c, const double (&av)[NAV]) __attribute__((always_inline)) {
+        constexpr bool ACC = decltype(ACCC)::value;
+        if (SPIN == 0) {
+            const int ch = s & 1, odd = (s >> 1) & 1;
+            double &va = odd ? vp[r][ch] : vc[r][ch], &vb = odd ? vc[r][ch] : vp[r][ch];
+            const double t = fma(c.x, xx[r], c.y);
+            if (ACC) {
+                acc[r][2 * ch + 0] = fma(va, av[0], acc[r][2 * ch + 0]);
+                acc[r][2 * ch + 1] = fma(va, av[1], acc[r][2 * ch + 1]);
+            }
+            vb = fma(t, va, -vb);
+        } else {
+            const int odd = s & 1;
+            double &a0 = odd ? vp[r][0] : vc[r][0], &b0 = odd ? vc[r][0] : vp[r][0];
+            double &a1 = odd ? vp[r][1] : vc[r][1], &b1 = odd ? vc[r][1] : vp[r][1];
+            const double t0 = fma(c.x, xx[r], c.y), t1 = fma(c.x, xx[r], -c.y);
+            if (ACC) {
+                // av = (a+_re, a+_im, a-_re, a-_im); the southern sums alternate in sign with l (the overall sign (-1)^off at the end)
+                acc[r][0] = fma(a0, av[0], acc[r][0]);
+                acc[r][1] = fma(a0, av[1], acc[r][1]);
+                acc[r][2] = fma(odd ? -a0 : a0, av[2 % NAV], acc[r][2]);
+                acc[r][3] = fma(odd ? -a0 : a0, av[3 % NAV], acc[r][3]);
+                acc[r][4 % NV] = fma(a1, av[2 % NAV], acc[r][4 % NV]);
+                acc[r][5 % NV] = fma(a1, av[3 % NAV], acc[r][5 % NV]);
+                acc[r][6 % NV] = fma(odd ? -a1 : a1, av[0], acc[r][6 % NV]);
+                acc[r][7 % NV] = fma(odd ? -a1 : a1, av[1], acc[r][7 % NV]);
+            }
+            b0 = fma(t0, a0, -b0);
+            b1 = fma(t1, a1, -b1);
+        }
+    };
+    using BT = std::integral_constant<bool, true>;
+    using BF = std::integral_constant<bool, false>;
+
+    // chunk tables: lane < CH carries l = (first l of the chunk) + lane: coefficients of the step and alpha_l a_lm (0 beyond lmax)
+    double2 cpre = make_double2(0.0, 0.0);
+    double apre[NAV];
+    auto fetch = [&](int lc) __attribute__((always_inline)) {
+        if (lane < CH) {
+            const int l = lc + lane;
+            cpre = coefn[cb + l + coff];
+            const bool in = l <= lmax;
+            const double al = alphan[cb + l];
+            if (SPIN == 0) {
+                const double2 a = in ? A.alm[cb + l] : make_double2(0.0, 0.0);
+                apre[0] = al * a.x; apre[1] = al * a.y;
+            } else {
+                const double2 E = in ? A.alm[cb + l] : make_double2(0.0, 0.0);
+                const double2 B = in ? A.alm[A.alm_stride + cb + l] : make_double2(0.0, 0.0);
+                apre[0] = al * (-E.x + B.y); apre[1] = al * (-E.y - B.x);                  // a+ = -(E + iB)
+                apre[2 % NAV] = al * (-E.x - B.y); apre[3 % NAV] = al * (-E.y + B.x);      // a- = -(E - iB)
+            }
+        }
+    };
+    auto stash = [&](int b) __attribute__((always_inline)) {
+        if (lane < CH) {
+            cfs[b][lane] = cpre;
+#pragma unroll
+            for (int q = 0; q < NAV; ++q) avs[b][lane][q] = apre[q];
+        }
+    };
+    fetch(l0);
+    stash(0);
+    __syncthreads();
+    int buf = 0, lb = l0, sb = 0;
+    auto stage_begin = [&]() __attribute__((always_inline)) {
+        if (sb == 0) fetch(lb + CH);
+    };
+    auto stage_end = [&]() __attribute__((always_inline)) {
+        if (++sb == NSB) {
+            sb = 0;
+            stash(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    };
+    constexpr int CHK = HX_VALU_CHK / LB > 0 ? HX_VALU_CHK / LB : 1;
+    int bk = 0, n_dead = 0, n_acc = 0;
+    // ---- phase 0: every chain of the wave still scaled: recursions only ----
+    const double zero_av[NAV] = {};
+    for (; lb <= lmax; lb += LB, ++bk) {
+        if (bk % CHK == 0) {
+            bool dead = true;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                promote(r, 0);
+                promote(r, 1);
+                dead = dead && (sc[r][0] < 0 && sc[r][1] < 0);
+            }
+            if (HX_VALU_NODEAD || !__all(dead)) break;
+        }
+        stage_begin();
+        const double2 *cf = cfs[buf] + sb * LB;
+#pragma unroll
+        for (int s = 0; s < LB; ++s) {
+            const double2 c = cf[s];
+#pragma unroll
+            for (int r = 0; r < R; ++r) step(BF{}, r, s, c, zero_av);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage_end();
+        ++n_dead;
+    }
+    // ---- phase 1: accumulation.  Until every chain of the wave is live, a check every CHK l promotes the scaled chains and
+    // drops what the chains that are not live have added since the last check ----
+    bool steady = false;
+    bk = 0;  // (the block that left phase 0 has been promoted; nothing has been accumulated yet)
+    for (; lb <= lmax; lb += LB, ++bk) {
+        stage_begin();
+        if (!steady && bk % CHK == 0) {
+            bool live = true;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                drop(r, 0);
+                drop(r, 1);
+                promote(r, 0);
+                promote(r, 1);
+                const bool val = (vmask >> r) & 1;  // (lanes without a ring carry zeros and exponent -100 for ever)
+                live = live && (!val || (sc[r][0] == 0 && sc[r][1] == 0));
+            }
+            steady = __all(live);
+        }
+        const double2 *cf = cfs[buf] + sb * LB;
+        const double (*av)[NAV] = avs[buf] + sb * LB;
+        double2 cn = cf[0];
+        double an[NAV];
+#pragma unroll
+        for (int q = 0; q < NAV; ++q) an[q] = av[0][q];
+#pragma unroll
+        for (int s = 0; s < LB; ++s) {
+            const double2 c = cn;
+            double a[NAV];
+#pragma unroll
+            for (int q = 0; q < NAV; ++q) a[q] = an[q];
+            if (s + 1 < LB) {  // the next l's values land while this l runs
+                cn = cf[s + 1];
+#pragma unroll
+                for (int q = 0; q < NAV; ++q) an[q] = av[s + 1][q];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) step(BT{}, r, s, c, a);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage_end();
+        ++n_acc;
+    }
+    // ---- ring modes of this m ----
+    double *fm = A.Fv + (long long)m * P.nrp_pad * NV;
+    const double ssgn = (SPIN == 2 && off) ? -1.0 : 1.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        drop(r, 0);  // chains that never became live
+        drop(r, 1);
+        const int k = r * 64 + lane, rp = task.rb0 * RBLK + k;
+        if (k >= task.nrb * RBLK || rp >= P.nrp_pad) continue;
+        double o[NV];
+        if (SPIN == 0) {
+            o[0] = acc[r][0] + acc[r][2]; o[1] = acc[r][1] + acc[r][3];
+            o[2] = acc[r][0] - acc[r][2]; o[3] = acc[r][1] - acc[r][3];
+        } else {
+            const double ppn_r = acc[r][0], ppn_i = acc[r][1], pms_r = ssgn * acc[r][2], pms_i = ssgn * acc[r][3];
+            const double pmn_r = acc[r][4 % NV], pmn_i = acc[r][5 % NV], pps_r = ssgn * acc[r][6 % NV], pps_i = ssgn * acc[r][7 % NV];
+            // Q = (P+ + P-) / 2;  U = (P+ - P-) / 2i: U_re = (Im P+ - Im P-) / 2, U_im = -(Re P+ - Re P-) / 2
+            o[0] = 0.5 * (ppn_r + pmn_r); o[1] = 0.5 * (ppn_i + pmn_i);
+            o[2] = 0.5 * (pps_r + pms_r); o[3] = 0.5 * (pps_i + pms_i);
+            o[4 % NV] = 0.5 * (ppn_i - pmn_i); o[5 % NV] = -0.5 * (ppn_r - pmn_r);
+            o[6 % NV] = 0.5 * (pps_i - pms_i); o[7 % NV] = -0.5 * (pps_r - pms_r);
+        }
+        double *row = fm + (long long)rp * NV;
+#pragma unroll
+        for (int q = 0; q < NV; q += 2) *reinterpret_cast<double2 *>(row + q) = make_double2(o[q], o[q + 1]);
+    }
+    if (lane == 0) {
+        constexpr unsigned long long REC = SPIN == 0 ? 2 : 4, ACC = SPIN == 0 ? 2 : 8;
+        atomicAdd(&g_valu_flops, (unsigned long long)(n_dead * REC + n_acc * (REC + ACC)) * (64ull * R * LB * 2ull));
+    }
+}
+
+// Fv of component c0 (spin 2: the field (c0, c0 + 1)) of d_alms; rings outside the task list (pruned) stay zero
+template <int SPIN>
+static int launch_synth_valu_t(hx_plan *pl, hx_plan::TaskSet &ts, const double2 *d_alm, double *d_Fv)
+{
+    hipStream_t st = rt().stream;
+    constexpr int NV = SynValuCfg<SPIN>::NV;
+    HX_HIP(hipMemsetAsync(d_Fv, 0, sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * NV, st));
+    SynValuParams A;
+    A.P = pl->dev(); A.tasks = ts.d_tasks.as<LegTask>(); A.alm = d_alm; A.alm_stride = pl->nlm; A.Fv = d_Fv;
+    const double2 *cn = SPIN == 0 ? pl->cn0.as<double2>() : pl->cn2.as<double2>();
+    const double *al = SPIN == 0 ? pl->al0.as<double>() : pl->al2.as<double>();
+    ProfScope ps("legendre_synthesis");
+    ProfScope ps2("legendre_synth_valu");
+    hipLaunchKernelGGL(k_legendre_synth_valu<SPIN>, dim3((unsigned)ts.tasks.size()), dim3(64), 0, st, A, cn, al);
+    HX_HIP(hipGetLastError());
+    return HX_OK;
+}
+int launch_synth_valu(hx_plan *pl, int spin, hx_plan::TaskSet &ts, const double2 *d_alm, double *d_Fv)
+{
+    return spin == 0 ? launch_synth_valu_t<0>(pl, ts, d_alm, d_Fv) : launch_synth_valu_t<2>(pl, ts, d_alm, d_Fv);
+}
+
+// =====================================================================================
 // host: one m-chunk of one map / field
 // =====================================================================================
 template <int SPIN>

@@ -611,6 +611,41 @@ __global__ __launch_bounds__(256) void k_synth_spectrum(PlanDev P, const double 
     }
 }
 
+// The same from the output of the vector-unit synthesis (hx_legendre_valu.hip): Fv[m][rp][4 nc] of ONE map (nc = 1) or (Q, U)
+// field (nc = 2), component c = (N_re, N_im, S_re, S_im) at 4 c.  The values of four consecutive ring pairs at one m share a
+// 128-byte line: a group takes four ring pairs (thread = (ring pair, component, k)).
+__global__ __launch_bounds__(256) void k_synth_spectrum_v(PlanDev P, const double *__restrict__ Fv, int nc, int lmax,
+                                                          double2 *__restrict__ Zc)
+{
+    const int rp = blockIdx.x * 4 + (threadIdx.x & 3), rest = threadIdx.x >> 2;
+    if (rp >= P.nrp) return;
+    const int c = rest % nc, kk = rest / nc, kstep = (int)(blockDim.x >> 2) / nc;
+    const int n = P.nsub[rp], nphi = 4 * n;
+    const bool shifted = P.shifted[rp] != 0;
+    const long long mstride = (long long)P.nrp_pad * 4 * nc;
+    const double *row = Fv + (long long)rp * 4 * nc + 4 * c;
+    for (int k = kk; k < nphi; k += kstep) {
+        double2 xn = make_double2(0.0, 0.0), xs = xn;
+        for (int m = k; m <= lmax; m += nphi) {  // m == k (mod nphi)
+            const double2 *b = reinterpret_cast<const double2 *>(row + m * mstride);
+            double2 ph = make_double2(1.0, 0.0);
+            if (shifted) ph = expipi((double)(m % (2 * nphi)) / (double)nphi);
+            const double sc = m == 0 ? 0.5 : 1.0;  // c_m / 2
+            xn = cadd(xn, cscale(cmul(b[0], ph), sc));
+            xs = cadd(xs, cscale(cmul(b[1], ph), sc));
+        }
+        for (int m = (nphi - k) % nphi; m <= lmax; m += nphi) {  // m == -k (mod nphi)
+            const double2 *b = reinterpret_cast<const double2 *>(row + m * mstride);
+            double2 ph = make_double2(1.0, 0.0);
+            if (shifted) ph = expipi((double)(m % (2 * nphi)) / (double)nphi);
+            const double sc = m == 0 ? 0.5 : 1.0;
+            xn = cadd(xn, cscale(cconj(cmul(b[0], ph)), sc));
+            xs = cadd(xs, cscale(cconj(cmul(b[1], ph)), sc));
+        }
+        Zc[(long long)c * P.ny + P.startN[rp] + k] = cconj(cadd(xn, mul_pi(xs)));
+    }
+}
+
 // Y_r[k] = DFT(conj Z)[4k+r] = conj(z[4k+r]) -> f_N = Re, f_S = -Im.  One thread per k gathers its four
 // sub-spectra values (coalesced along k) and writes four consecutive pixels of each ring (32 B per lane).
 __global__ __launch_bounds__(256) void k_synth_scatter(PlanDev P, const double2 *__restrict__ Y,
@@ -965,10 +1000,41 @@ int launch_ring_subdft_maps(hx_plan *pl, int nb, const double *d_maps, const dou
 
 // ---- one synthesis pass over a batch (device pointers).  If d_ref != NULL the output is
 // the residual ref - synth (Jacobi iteration). -------------------------------------------
+// HX_SYNTH_MFMA=1: the round-1 matrix kernel (k_legendre_synthesis, 8 components per sweep) instead of one vector-unit sweep per
+// map / field -- an A/B switch; the vector-unit kernel is faster for every batch size measured (tools/time_synth_iter.py)
+static bool synth_mfma()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("HX_SYNTH_MFMA");
+        v = (e && atoi(e) == 1) ? 1 : 0;
+    }
+    return v == 1;
+}
+
 static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms, double *d_maps,
                            const double *d_ref)
 {
     hipStream_t st = rt().stream;
+    if (!synth_mfma()) {
+        hx_plan::TaskSet *ts = nullptr;
+        HX_TRY(valu_tasks(pl, spin, &ts));
+        const int unit = spin ? 2 : 1;
+        HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * unit));
+        HX_TRY(pl->resid.alloc(sizeof(double2) * (size_t)pl->ny * unit));  // conj(Z) spectra
+        HX_TRY(pl->Fsyn.alloc(sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * synth_valu_doubles(spin)));
+        PlanDev P = pl->dev();
+        for (int c0 = 0; c0 < nb; c0 += unit) {
+            HX_TRY(launch_synth_valu(pl, spin, *ts, d_alms + (size_t)c0 * pl->nlm, pl->Fsyn.as<double>()));
+            ProfScope ps("ring_fft");
+            hipLaunchKernelGGL(k_synth_spectrum_v, dim3((pl->nrp + 3) / 4), dim3(256), 0, st, P, pl->Fsyn.as<double>(), unit, pl->lmax, pl->resid.as<double2>());
+            HX_TRY(launch_subdft_classes<1>(pl, unit, nullptr, nullptr, pl->resid.as<double2>(), pl->Y.as<double2>()));
+            hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, unit), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps + (size_t)c0 * pl->npix, d_ref ? 1 : 0,
+                               d_ref ? d_ref + (size_t)c0 * pl->npix : nullptr);
+        }
+        HX_HIP(hipGetLastError());
+        return HX_OK;
+    }
     HX_TRY(build_tasks(pl, spin));
     if (spin) HX_TRY(ensure_rec2(pl));
     HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * 8));

@@ -336,5 +336,8 @@ int launch_valu_chunk(hx_plan *pl, int spin, hx_plan::TaskSet &ts, int m0, int m
 int valu_task_blocks(int spin);      // 32-ring-pair blocks per task
 int valu_partial_cols(int spin);     // doubles per row of the partial buffer
 int valu_operand_doubles(int spin);  // doubles per (m, ring pair) of the operand array
-int valu_exec_flops(unsigned long long *v, bool reset);  // FP64 vector flops executed by the vector-unit kernels since the last reset
+int valu_exec_flops(unsigned long long *v, bool reset);
+int valu_tasks(hx_plan *pl, int spin, hx_plan::TaskSet **ts);  // (hx_analysis.hip) the task set of the vector-unit kernels, built on first use
+int synth_valu_doubles(int spin);    // doubles per (m, ring pair) of the synthesis output Fv[m][rp][.]
+int launch_synth_valu(hx_plan *pl, int spin, hx_plan::TaskSet &ts, const double2 *d_alm, double *d_Fv);  // one map / field: alm -> Fv  // FP64 vector flops executed by the vector-unit kernels since the last reset
 }  // namespace hx

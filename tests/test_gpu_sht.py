@@ -93,6 +93,20 @@ def test_alm2map(oracle, nside, lmax, spin):
     close(out, oracle.alm2map(alm, nside, lmax, spin=spin), 1e-11)
 
 
+@pytest.mark.parametrize("nside,lmax", [(128, 200), (256, 300)])
+@pytest.mark.parametrize("spin", [0, 2])
+def test_alm2map_medium_scaled_chains(oracle, nside, lmax, spin):
+    """Synthesis at sizes where most recursion chains start far below 2^-300 (every phase of the vector-unit synthesis kernel:
+    scaled-only blocks, blocks whose late chains are dropped at the next check, steady blocks), three maps / two fields, against
+    the oracle's direct sums."""
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(7 * nside + spin)
+    alm = random_alm(rng, lmax, spin, (3,) if spin == 0 else (4,))
+    out = hx.get_plan(nside, lmax).alm2map(alm, spin)
+    close(out, oracle.alm2map(alm, nside, lmax, spin=spin), 1e-11)
+
+
 @pytest.mark.parametrize("spin", [0, 2])
 def test_roundtrip_medium(oracle, spin):
     """nside=256, lmax=384: alm -> map (GPU) -> alm (GPU, niter=3) returns the input."""

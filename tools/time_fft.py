@@ -3,11 +3,14 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, heracles_amd as hx
 hx.init(0)
+if os.environ.get("FFT_CAP"):  # rings whose Bluestein convolution is longer run as two half-length passes (k_ring_subdft_split)
+    hx._lib.check(hx._lib.load().hx_set_max_lds_fft(int(os.environ["FFT_CAP"])))
 nside, lmax = int(os.environ.get("NSIDE", 4096)), int(os.environ.get("LMAX", 6144))
 plan = hx.Plan(nside, lmax)
-m = torch.randn((8, 12 * nside * nside), dtype=torch.float64, device="cuda")
+nc = int(os.environ.get("NCOMP", 8))
+m = torch.randn((nc, 12 * nside * nside), dtype=torch.float64, device="cuda")
 pw = torch.ones(12 * nside * nside, dtype=torch.float64, device="cuda") if os.environ.get("PW", "1") == "1" else None  # PW=0: without pixel weights
 plan.map2alm(m, 0, pix_weights=pw)
 hx._lib.profile_enable(True); hx._lib.profile_reset()
 plan.map2alm(m, 0, pix_weights=pw)
-print(os.environ.get("HX_LIBRARY", "default").split("/")[-1], "ring_fft ms (8 comps%s):" % (", pixel weights" if pw is not None else ""), round(hx._lib.profile_get("ring_fft")[1], 2))
+print(os.environ.get("HX_LIBRARY", "default").split("/")[-1], "ring_fft ms (%d comps%s):" % (nc, ", pixel weights" if pw is not None else ""), round(hx._lib.profile_get("ring_fft")[1], 2))
