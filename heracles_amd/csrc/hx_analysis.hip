@@ -804,269 +804,6 @@ __global__ __launch_bounds__(256) void k_alm_reduce(PlanDev P, const LegTask *__
 }
 
 // =====================================================================================
-// Legendre synthesis on FP64 MFMA:  F_m(r)[col] = sum_l lambda_lm(theta_r) a_lm[col]
-// =====================================================================================
-// The GEMM is out[ring][col] = Lambda^T[ring][l] x a[l][col] with K = l.  Lanes, recursion,
-// coefficient hand-over and LDS tiles are those of the analysis kernel; the A operand is read
-// from the tile as [16 rings x 4 l-rows], the B operand (alpha_l a_lm of this block, 32 l x 16
-// columns, staged once per block in LDS for all waves) as [4 l-rows x 16 columns], and the D
-// tiles stay in registers over the whole l sweep -- each wave owns its rings, so there is no
-// cross-wave reduction.  Even and odd (l+m) are accumulated separately: north = even + odd,
-// south = even - odd (spin 2: the (+2)/(-2) functions swap roles between the hemispheres).
-struct SynParams {
-    PlanDev P;
-    const LegTask *__restrict__ tasks;
-    const double2 *__restrict__ alm;   // [comp][nlm]
-    long long alm_stride;
-    int ncomp;
-    double *__restrict__ Fsyn;         // [rp][m][north/south][16]: all m of a ring pair contiguous for the ring FFT stage
-};
-
-// column `col` of the B operand of function `op` at (l, m): alpha_l times
-//   spin 0: Re/Im a_lm of component col/2
-//   spin 2: op 0 (lambda+): [-(E+iB), -(E-iB)],  op 1 (lambda-): [-(E-iB), -(E+iB)]  of field col/4
-template <int SPIN>
-__device__ inline double synth_b_value(const SynParams &A, long long idx, int col, int op)
-{
-    if (SPIN == 0) {
-        const int c = col >> 1;
-        if (c >= A.ncomp) return 0.0;
-        const double2 a = A.alm[(long long)c * A.alm_stride + idx];
-        return (col & 1) ? a.y : a.x;
-    } else {
-        const int f = col >> 2, sub = col & 3;
-        if (2 * f + 1 >= A.ncomp) return 0.0;
-        const double2 E = A.alm[(long long)(2 * f) * A.alm_stride + idx];
-        const double2 B = A.alm[(long long)(2 * f + 1) * A.alm_stride + idx];
-        const bool plus = ((sub >> 1) ^ op) == 0;  // -(E + iB) if plus else -(E - iB)
-        if (plus) return (sub & 1) ? (-E.y - B.x) : (-E.x + B.y);
-        return (sub & 1) ? (-E.y + B.x) : (-E.x - B.y);
-    }
-}
-
-template <int SPIN>
-__global__ __launch_bounds__(LegCfg<SPIN>::NW * 64) void k_legendre_synthesis(SynParams A,
-                                                                            const double2 *__restrict__ coefn,
-                                                                            const double *__restrict__ alphan)
-{
-    using C = LegCfg<SPIN>;
-    constexpr int NW = C::NW, NT = C::NT, NOP = C::NOP;
-    __shared__ double tiles[NW][NT][16][64];
-    __shared__ double2 coefs[2][LBLK];
-    constexpr int BLD = NCOL + 8;             // row stride 24: rows two apart fall into different bank halves
-    __shared__ double bs[2][NOP][LBLK][BLD];  // alpha_l a_lm of this / the next block
-    const PlanDev &P = A.P;
-    const LegTask task = A.tasks[blockIdx.x];
-    const int m = task.m, lmax = P.lmax;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int h = lane >> 5, r32 = lane & 31;
-    const bool wave_on = w < task.nrb;
-    const int rb = task.rb0 + (wave_on ? w : 0);
-    const int rp = rb * RBLK + r32;
-    const bool valid = wave_on && rp < P.nrp;
-    const double x = valid ? P.z[rp] : 0.0;
-    const double xx = SPIN == 0 ? x * x : x;
-    const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
-    const int off = (l0 + m) & 1;
-    const long long cb = almidx(lmax, 0, m);
-    const long long cbs = __builtin_amdgcn_readfirstlane((int)cb);
-    const int ai = lane & 15, ak = lane >> 4;
-
-    double vc = 0.0, vp = 0.0;
-    int sc = -100;
-    if (valid) {
-        if (SPIN == 0) {
-            SVal s = spow(P.sth[rp], m);
-            s.v *= P.mfac[m];
-            if (h) s.v *= sqrt(2.0 * m + 3.0) * x;
-            snorm_small(s);
-            vc = s.v; sc = s.e;
-        } else {
-            SVal sp, sm;
-            spin2_seeds(m, P.sth[rp], P.omz[rp], P.kfac2[m], sp, sm);
-            vc = h ? sm.v : sp.v;
-            sc = h ? sm.e : sp.e;
-        }
-    }
-    const double sgn = (SPIN == 2 && h) ? -1.0 : 1.0;
-    double *mytile = &tiles[w][0][0][0];
-    // synthesis reads A[ring i][l-row k]: rows k, k+1 of one instruction must fall into different
-    // halves of the banks -> swizzle the column by (row & 1) << 4
-    auto swz = [](int r) { return (r & 1) << 4; };
-
-    // D tiles: [parity][function][ring group of 16], row = ring (lane>>4 + 4 reg), col = lane&15
-    double4_t acc[2][NOP][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < NOP; ++b)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[a][b][c] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-    auto lds_barrier = []() {
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_s_barrier();
-    };
-    // staging by all threads: coefficients (threads < 64) and the B block (NOP*512 values)
-    const int coff = SPIN == 0 ? 0 : 1;
-    constexpr int NBV = NOP * LBLK * NCOL;              // B values per block
-    constexpr int BPT = (NBV + NW * 64 - 1) / (NW * 64); // per thread
-    double cpre = 0.0, bpre[BPT];
-    auto fetch = [&](int lb_) {
-        if (threadIdx.x < 2 * LBLK) cpre = reinterpret_cast<const double *>(coefn + cb + lb_ + coff)[threadIdx.x];
-#pragma unroll
-        for (int u = 0; u < BPT; ++u) {
-            const int t = threadIdx.x + u * NW * 64;
-            bpre[u] = 0.0;
-            if (t < NBV) {
-                const int op = t / (LBLK * NCOL), ll = (t / NCOL) % LBLK, col = t % NCOL;
-                const int l = lb_ + ll;
-                if (l <= lmax) bpre[u] = alphan[cb + l] * synth_b_value<SPIN>(A, cb + l, col, op);
-            }
-        }
-    };
-    auto stash = [&](int buf) {
-        if (threadIdx.x < 2 * LBLK) (&coefs[buf][0].x)[threadIdx.x] = cpre;
-#pragma unroll
-        for (int u = 0; u < BPT; ++u) {
-            const int t = threadIdx.x + u * NW * 64;
-            if (t < NBV) bs[buf][t / (LBLK * NCOL)][(t / NCOL) % LBLK][t % NCOL] = bpre[u];
-        }
-    };
-    fetch(l0);
-    stash(0);
-    __syncthreads();
-    int cbuf = 0;
-    for (int lb = l0; lb <= lmax; lb += LBLK, cbuf ^= 1) {
-        fetch(lb + LBLK);
-        const double2 *cf = coefs[cbuf];
-        if (wave_on) {
-            // live / dead chains: see k_legendre_analysis
-            const bool all_live = __all(sc == 0 || !valid);
-            const bool all_dead = __all(sc < 0 || !valid);
-            auto advance = [&](int e) {
-                const double2 c = SPIN == 2 ? coefn[cbs + lb + coff + e] : cf[e];  // see k_legendre_analysis
-                const double vn = fma(fma(c.x, xx, sgn * c.y), vc, -vp);
-                vp = vc;
-                vc = vn;
-            };
-            auto promote = [&]() {
-                const bool up = sc < 0 && fabs(vc) > 1.0;
-                if (__any(up)) {
-                    if (up) {
-                        vc *= SC_SMALL; vp *= SC_SMALL;
-                        sc += 1;
-                    }
-                }
-            };
-            constexpr int NSTEP = SPIN == 0 ? LBLK / 2 : LBLK;
-            if (all_dead) {
-#pragma unroll 4
-                for (int s = 0; s < NSTEP; ++s) {
-                    advance(SPIN == 0 ? 2 * s + h : s);
-                    if ((s & 3) == 3) promote();
-                }
-            } else {
-                if (all_live) {
-#pragma unroll
-                    for (int s = 0; s < NSTEP; ++s) {
-                        const int t = SPIN == 0 ? 0 : ((s + off) & 1), r = SPIN == 0 ? s : (s >> 1);
-                        mytile[(t * 16 + r) * 64 + (lane ^ swz(r))] = vc;
-                        advance(SPIN == 0 ? 2 * s + h : s);
-                    }
-                } else {
-#pragma unroll
-                    for (int s = 0; s < NSTEP; ++s) {
-                        const int t = SPIN == 0 ? 0 : ((s + off) & 1), r = SPIN == 0 ? s : (s >> 1);
-                        mytile[(t * 16 + r) * 64 + (lane ^ swz(r))] = sc == 0 ? vc : 0.0;
-                        advance(SPIN == 0 ? 2 * s + h : s);
-                        if ((s & 3) == 3) promote();
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // A[i][k] = tile row 4 kg + k (an l of parity par), ring 16 rg + i of half hh
-                // B[k][j] = bs[op][l - lb][j],  l - lb = 2 (4 kg + k) + (par ^ off)
-#pragma unroll
-                for (int par = 0; par < 2; ++par)
-#pragma unroll
-                    for (int op = 0; op < NOP; ++op)
-#pragma unroll
-                        for (int kg = 0; kg < 4; ++kg) {
-                            const int row = 4 * kg + ak;
-                            const double b = bs[cbuf][op][2 * row + (par ^ off)][ai];
-                            const int t = SPIN == 0 ? 0 : par, hh = SPIN == 0 ? par : op;
-#pragma unroll
-                            for (int rg = 0; rg < 2; ++rg) {
-                                const double a = mytile[(t * 16 + row) * 64 + ((hh * 32 + 16 * rg + ai) ^ swz(row))];
-                                acc[par][op][rg] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[par][op][rg], 0, 0, 0);
-                            }
-                        }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        stash(cbuf ^ 1);
-        lds_barrier();
-    }
-    // ---- epilogue: north = even + odd, south = even - odd ---------------------------------
-    if (!wave_on) return;
-#pragma unroll
-    for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const int ring = rb * RBLK + 16 * rg + ak + 4 * r4;
-            if (ring >= P.nrp_pad) continue;
-            double *base = A.Fsyn + (((long long)ring * (lmax + 1) + m) * 2) * NCOL;
-            if (SPIN == 0) {
-                const double e = acc[0][0][rg][r4], o = acc[1][0][rg][r4];
-                base[ai] = e + o;
-                base[NCOL + ai] = e - o;
-            } else {
-                // this lane's column j = 4f + sub.  function 0 (lambda+): sub 0,1 -> P+_N, sub 2,3 -> P-_S
-                //                                  function 1 (lambda-): sub 0,1 -> P-_N, sub 2,3 -> P+_S
-                const int sub = ai & 3, f4 = ai & ~3;
-                const double e0 = acc[0][0][rg][r4], o0 = acc[1][0][rg][r4];
-                const double e1 = acc[0][NOP - 1][rg][r4], o1 = acc[1][NOP - 1][rg][r4];
-                if (sub < 2) {
-                    const double pp = e0 + o0, pm = e1 + o1;   // P+_N, P-_N (re if sub==0 else im)
-                    // Q = (P+ + P-)/2,  U = (P+ - P-)/(2i):  U_re = (Im P+ - Im P-)/2, U_im = -(Re P+ - Re P-)/2
-                    base[f4 + sub] = 0.5 * (pp + pm);
-                    if (sub == 0) base[f4 + 3] = -0.5 * (pp - pm);
-                    else          base[f4 + 2] = 0.5 * (pp - pm);
-                } else {
-                    const double pm = e0 - o0, pp = e1 - o1;   // P-_S, P+_S
-                    base[NCOL + f4 + (sub - 2)] = 0.5 * (pp + pm);
-                    if (sub == 2) base[NCOL + f4 + 3] = -0.5 * (pp - pm);
-                    else          base[NCOL + f4 + 2] = 0.5 * (pp - pm);
-                }
-            }
-        }
-}
-
-int legendre_synthesis(hx_plan *pl, int spin, int nb, const double2 *d_alms, double *d_Fsyn)
-{
-    hipStream_t st = rt().stream;
-    HX_TRY(build_tasks(pl, spin));
-    if (spin) HX_TRY(ensure_rec2(pl));
-    hx_plan::TaskSet &ts = pl->ts[spin ? 1 : 0];
-    // rings outside the task list (pruned) contribute nothing
-    HX_HIP(hipMemsetAsync(d_Fsyn, 0, sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * 2 * NCOL, st));
-    SynParams A;
-    A.P = pl->dev(); A.tasks = ts.d_tasks.as<LegTask>(); A.alm = d_alms; A.alm_stride = pl->nlm; A.ncomp = nb; A.Fsyn = d_Fsyn;
-    ProfScope ps("legendre_synthesis");
-    if (spin == 0)
-        hipLaunchKernelGGL(k_legendre_synthesis<0>, dim3((unsigned)ts.tasks.size()), dim3(LegCfg<0>::NW * 64), 0, st, A,
-                           (const double2 *)pl->cn0.as<double2>(), (const double *)pl->al0.as<double>());
-    else
-        hipLaunchKernelGGL(k_legendre_synthesis<2>, dim3((unsigned)ts.tasks.size()), dim3(LegCfg<2>::NW * 64), 0, st, A,
-                           (const double2 *)pl->cn2.as<double2>(), (const double *)pl->al2.as<double>());
-    HX_HIP(hipGetLastError());
-    return HX_OK;
-}
-
-// =====================================================================================
 // host side: task list, m-chunking, launch sequence
 // =====================================================================================
 // libsharp's published heuristic for the largest m that contributes on a ring

@@ -569,51 +569,13 @@ __global__ __launch_bounds__(512) void k_ring_subdft_split(PlanDev P, const int 
 }
 
 // =====================================================================================
-// synthesis: Fsyn -> ring spectra -> pixels (the Legendre part lives in hx_analysis.hip)
+// synthesis: Fv -> ring spectra -> pixels (the Legendre part lives in hx_legendre_valu.hip)
 // =====================================================================================
-// Fsyn[rp][m][N/S][16] -> conj(Z) spectra of the packed ring pair z = f_N + i f_S.
-// X[k] = sum_{m == k mod nphi} (c_m/2) Ft_m + sum_{m == -k} (c_m/2) conj(Ft_m), Ft = F e^{i m phi0}
-// grid: x = ring pair; lanes = (k, component): the 8 components of a (ring pair, m) row are 128
-// contiguous bytes, and consecutive k are consecutive rows.  Output Zc[c][startN + k] = conj(X_N + i X_S)
-__global__ __launch_bounds__(256) void k_synth_spectrum(PlanDev P, const double *__restrict__ Fsyn, int ncomp,
-                                                        int lmax, double2 *__restrict__ Zc)
-{
-    const int rp = blockIdx.x, c = threadIdx.x & 7;
-    const int n = P.nsub[rp], nphi = 4 * n;
-    const bool shifted = P.shifted[rp] != 0;
-    if (c >= ncomp) return;
-    const double *row = Fsyn + ((long long)rp * (lmax + 1)) * 2 * NCOL + 2 * c;
-    for (int k = threadIdx.x >> 3; k < nphi; k += blockDim.x >> 3) {
-        double2 xn = make_double2(0.0, 0.0), xs = xn;
-        // m == k (mod nphi)
-        for (int m = k; m <= lmax; m += nphi) {
-            const double2 *b = reinterpret_cast<const double2 *>(row + (long long)m * 2 * NCOL);
-            double2 ph = make_double2(1.0, 0.0);
-            if (shifted) ph = expipi((double)(m % (2 * nphi)) / (double)nphi);
-            const double2 fn = cmul(b[0], ph), fs = cmul(b[NCOL / 2], ph);
-            const double sc = m == 0 ? 0.5 : 1.0;  // c_m / 2
-            xn = cadd(xn, cscale(fn, sc));
-            xs = cadd(xs, cscale(fs, sc));
-        }
-        // m == -k (mod nphi)
-        for (int m = (nphi - k) % nphi; m <= lmax; m += nphi) {
-            const double2 *b = reinterpret_cast<const double2 *>(row + (long long)m * 2 * NCOL);
-            double2 ph = make_double2(1.0, 0.0);
-            if (shifted) ph = expipi((double)(m % (2 * nphi)) / (double)nphi);
-            const double2 fn = cconj(cmul(b[0], ph)), fs = cconj(cmul(b[NCOL / 2], ph));
-            const double sc = m == 0 ? 0.5 : 1.0;
-            xn = cadd(xn, cscale(fn, sc));
-            xs = cadd(xs, cscale(fs, sc));
-        }
-        // Z = X_N + i X_S ; store conj(Z)
-        const double2 zz = cadd(xn, mul_pi(xs));
-        Zc[(long long)c * P.ny + P.startN[rp] + k] = cconj(zz);
-    }
-}
-
-// The same from the output of the vector-unit synthesis (hx_legendre_valu.hip): Fv[m][rp][4 nc] of ONE map (nc = 1) or (Q, U)
-// field (nc = 2), component c = (N_re, N_im, S_re, S_im) at 4 c.  The values of four consecutive ring pairs at one m share a
-// 128-byte line: a group takes four ring pairs (thread = (ring pair, component, k)).
+// Fv[m][rp][4 nc] -> conj(Z) spectra of the packed ring pair z = f_N + i f_S.  Fv is the output of the vector-unit synthesis
+// (hx_legendre_valu.hip) for ONE map (nc = 1) or (Q, U) field (nc = 2), component c = (N_re, N_im, S_re, S_im) at 4 c.
+// X[k] = sum_{m == k mod nphi} (c_m/2) Ft_m + sum_{m == -k} (c_m/2) conj(Ft_m), Ft = F e^{i m phi0};  output
+// Zc[c][startN + k] = conj(X_N + i X_S).  The values of four consecutive ring pairs at one m share a 128-byte line: a group
+// takes four ring pairs (thread = (ring pair, component, k)).
 __global__ __launch_bounds__(256) void k_synth_spectrum_v(PlanDev P, const double *__restrict__ Fv, int nc, int lmax,
                                                           double2 *__restrict__ Zc)
 {
@@ -998,55 +960,27 @@ int launch_ring_subdft_maps(hx_plan *pl, int nb, const double *d_maps, const dou
 }
 }  // namespace hx
 
-// ---- one synthesis pass over a batch (device pointers).  If d_ref != NULL the output is
-// the residual ref - synth (Jacobi iteration). -------------------------------------------
-// HX_SYNTH_MFMA=1: the round-1 matrix kernel (k_legendre_synthesis, 8 components per sweep) instead of one vector-unit sweep per
-// map / field -- an A/B switch; the vector-unit kernel is faster for every batch size measured (tools/time_synth_iter.py)
-static bool synth_mfma()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("HX_SYNTH_MFMA");
-        v = (e && atoi(e) == 1) ? 1 : 0;
-    }
-    return v == 1;
-}
-
+// ---- one synthesis pass over a batch (device pointers): one sweep of the vector-unit kernel per map / field (the round-1 matrix
+// kernel it replaces took 100 / 217 ms for one spin-0 map / spin-2 field at nside 4096 against 19 / 57, and 201 / 653 ms for ten
+// against 187 / 570).  If d_ref != NULL the output is the residual ref - synth (Jacobi iteration). ----
 static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms, double *d_maps,
                            const double *d_ref)
 {
     hipStream_t st = rt().stream;
-    if (!synth_mfma()) {
-        hx_plan::TaskSet *ts = nullptr;
-        HX_TRY(valu_tasks(pl, spin, &ts));
-        const int unit = spin ? 2 : 1;
-        HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * unit));
-        HX_TRY(pl->resid.alloc(sizeof(double2) * (size_t)pl->ny * unit));  // conj(Z) spectra
-        HX_TRY(pl->Fsyn.alloc(sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * synth_valu_doubles(spin)));
-        PlanDev P = pl->dev();
-        for (int c0 = 0; c0 < nb; c0 += unit) {
-            HX_TRY(launch_synth_valu(pl, spin, *ts, d_alms + (size_t)c0 * pl->nlm, pl->Fsyn.as<double>()));
-            ProfScope ps("ring_fft");
-            hipLaunchKernelGGL(k_synth_spectrum_v, dim3((pl->nrp + 3) / 4), dim3(256), 0, st, P, pl->Fsyn.as<double>(), unit, pl->lmax, pl->resid.as<double2>());
-            HX_TRY(launch_subdft_classes<1>(pl, unit, nullptr, nullptr, pl->resid.as<double2>(), pl->Y.as<double2>()));
-            hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, unit), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps + (size_t)c0 * pl->npix, d_ref ? 1 : 0,
-                               d_ref ? d_ref + (size_t)c0 * pl->npix : nullptr);
-        }
-        HX_HIP(hipGetLastError());
-        return HX_OK;
-    }
-    HX_TRY(build_tasks(pl, spin));
-    if (spin) HX_TRY(ensure_rec2(pl));
-    HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * 8));
-    HX_TRY(pl->resid.alloc(sizeof(double2) * (size_t)pl->ny * 8));  // conj(Z) spectra
-    HX_TRY(pl->Fsyn.alloc(sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * 2 * NCOL));
+    hx_plan::TaskSet *ts = nullptr;
+    HX_TRY(valu_tasks(pl, spin, &ts));
+    const int unit = spin ? 2 : 1;
+    HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * unit));
+    HX_TRY(pl->resid.alloc(sizeof(double2) * (size_t)pl->ny * unit));  // conj(Z) spectra
+    HX_TRY(pl->Fsyn.alloc(sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * synth_valu_doubles(spin)));
     PlanDev P = pl->dev();
-    HX_TRY(legendre_synthesis(pl, spin, nb, d_alms, pl->Fsyn.as<double>()));
-    {
+    for (int c0 = 0; c0 < nb; c0 += unit) {
+        HX_TRY(launch_synth_valu(pl, spin, *ts, d_alms + (size_t)c0 * pl->nlm, pl->Fsyn.as<double>()));
         ProfScope ps("ring_fft");
-        hipLaunchKernelGGL(k_synth_spectrum, dim3(pl->nrp), dim3(256), 0, st, P, pl->Fsyn.as<double>(), nb, pl->lmax, pl->resid.as<double2>());
-        HX_TRY(launch_subdft_classes<1>(pl, nb, nullptr, nullptr, pl->resid.as<double2>(), pl->Y.as<double2>()));
-        hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, nb), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps, d_ref ? 1 : 0, d_ref);
+        hipLaunchKernelGGL(k_synth_spectrum_v, dim3((pl->nrp + 3) / 4), dim3(256), 0, st, P, pl->Fsyn.as<double>(), unit, pl->lmax, pl->resid.as<double2>());
+        HX_TRY(launch_subdft_classes<1>(pl, unit, nullptr, nullptr, pl->resid.as<double2>(), pl->Y.as<double2>()));
+        hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, unit), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps + (size_t)c0 * pl->npix, d_ref ? 1 : 0,
+                           d_ref ? d_ref + (size_t)c0 * pl->npix : nullptr);
     }
     HX_HIP(hipGetLastError());
     return HX_OK;
@@ -1099,9 +1033,9 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
     HX_TRY(valms.bind(alms, sizeof(double2) * (size_t)ncomp * pl->nlm));
     // residual maps of the Jacobi iterations: plan-owned scratch (no per-call hipMalloc)
     DevBuf &resid = pl->resid_maps;
-    if (niter > 0) HX_TRY(resid.alloc(sizeof(double) * (size_t)8 * pl->npix));
-    // without iterations the sweeps are sized by analysis_next_batch(); the synthesis of the
-    // Jacobi iterations works on 8 components at a time
+    // the sweeps are sized by analysis_next_batch() (the first is the largest); the synthesis of the Jacobi iterations takes the
+    // maps / fields of a sweep one at a time
+    if (niter > 0) HX_TRY(resid.alloc(sizeof(double) * (size_t)analysis_next_batch(spin, ncomp) * pl->npix));
     if (piped) {
         const size_t sweep_bytes = sizeof(double) * (size_t)analysis_next_batch(spin, ncomp, true) * pl->npix;
         for (int i = 0; i < 2; ++i) {
@@ -1127,7 +1061,7 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
         }
     }
     for (int c0 = 0, nb = 0; !piped && c0 < ncomp; c0 += nb) {
-        nb = niter > 0 ? std::min(8, ncomp - c0) : analysis_next_batch(spin, ncomp - c0);
+        nb = analysis_next_batch(spin, ncomp - c0);
         const double *dm = vmaps.as<double>() + (size_t)c0 * pl->npix;
         double2 *da = valms.as<double2>() + (size_t)c0 * pl->nlm;
         // the filter fl is applied once, after the last iteration
@@ -1273,11 +1207,7 @@ extern "C" int hx_alm2map(hx_plan *pl, int spin, int ncomp, const double *alms, 
     OutView vmaps;
     HX_TRY(valms.bind(alms, sizeof(double2) * (size_t)ncomp * pl->nlm));
     HX_TRY(vmaps.bind(maps, sizeof(double) * (size_t)ncomp * pl->npix));
-    for (int c0 = 0; c0 < ncomp; c0 += 8) {
-        const int nb = std::min(8, ncomp - c0);
-        HX_TRY(synthesis_batch(pl, spin, nb, valms.as<double2>() + (size_t)c0 * pl->nlm,
-                               vmaps.as<double>() + (size_t)c0 * pl->npix, nullptr));
-    }
+    HX_TRY(synthesis_batch(pl, spin, ncomp, valms.as<double2>(), vmaps.as<double>(), nullptr));
     HX_TRY(vmaps.finish());
     if (valms.tmp.p || vmaps.tmp.p) {
         HX_HIP(hipStreamSynchronize(rt().stream));
