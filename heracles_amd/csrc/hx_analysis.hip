@@ -1024,11 +1024,13 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
 // The ring Fourier stage runs once for the whole batch.
 static bool valu_batch(int spin, int nb) { return sweep_shape(spin, nb).valu != 0; }
 
-int valu_tasks(hx_plan *pl, int spin, hx_plan::TaskSet **out)
+int valu_tasks(hx_plan *pl, int spin, hx_plan::TaskSet **out, int blocks)
 {
     if (spin) HX_TRY(ensure_rec2(pl));
-    hx_plan::TaskSet &ts = spin ? pl->ts[4] : pl->ts[5];
-    HX_TRY(build_task_set(pl, spin, valu_task_blocks(spin), ts));
+    if (blocks <= 0) blocks = valu_task_blocks(spin);
+    if (blocks != valu_task_blocks(spin) && blocks != 8) return fail(HX_ERR_ARG, "valu_tasks: %d ring blocks per task", blocks);
+    hx_plan::TaskSet &ts = blocks == 8 && blocks != valu_task_blocks(spin) ? (spin ? pl->ts[6] : pl->ts[7]) : (spin ? pl->ts[4] : pl->ts[5]);
+    HX_TRY(build_task_set(pl, spin, blocks, ts));
     *out = &ts;
     return HX_OK;
 }

@@ -439,28 +439,36 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_valu(ValuParams 
 // Every accumulator belongs to ONE chain.  A scaled chain (exponent < 0) is not masked inside the loop: what it adds between two
 // checks is dropped at the next check (its accumulators are zeroed as long as it is not live: it has never contributed before),
 // and at the end.  Output Fv[m][ring pair][NV]: (N_re, N_im, S_re, S_im) per component -- spin 2: Q then U.
-template <int SPIN>
+// NB maps (spin 0) / fields (spin 2) per sweep share the recursion: 2 + 2 NB (spin 0) / 4 + 8 NB (spin 2) FMAs per (ring pair, l)
+// instead of NB (2 + 2) / NB (4 + 8).  Their accumulators take the registers of half the ring slots: R = 4 (tasks of 8 ring blocks).
+template <int SPIN, int NB>
 struct SynValuCfg {
-    static constexpr int R = ValuCfg<SPIN>::R;     // the task sets of the analysis kernel (2 R ring blocks per task)
-    static constexpr int LB = SPIN == 0 ? 8 : 4;   // l per unrolled block (even; spin 2 with 8: 58 registers beyond the 256 a lane can address)
-    static constexpr int NAV = SPIN == 0 ? 2 : 4;  // doubles of alpha_l a_lm per l
-    static constexpr int NV = SPIN == 0 ? 4 : 8;   // output doubles per (m, ring pair)
+    static constexpr int R = NB == 1 ? ValuCfg<SPIN>::R : 4;  // NB = 1: the task sets of the analysis kernel (2 R ring blocks per task)
+    // l per unrolled block (even): hipcc requests the table values of a whole block up front -- LB (2 + NAV) doubles; spin 2 with
+    // 8-l blocks took 58 registers beyond the 256 a lane can address
+    static constexpr int LB = SPIN == 0 ? (NB <= 2 ? 8 : 4) : (NB == 1 ? 4 : 2);
+    static constexpr int NA1 = SPIN == 0 ? 2 : 4;  // doubles of alpha_l a_lm per l and map / field
+    static constexpr int NV1 = SPIN == 0 ? 4 : 8;  // output doubles per (m, ring pair) and map / field
+    static constexpr int NAV = NA1 * NB, NV = NV1 * NB;
 };
-int synth_valu_doubles(int spin) { return spin == 0 ? SynValuCfg<0>::NV : SynValuCfg<2>::NV; }
+int synth_valu_max_units(int spin) { return spin == 0 ? 4 : 2; }
+int synth_valu_task_blocks(int spin, int units) { return units == 1 ? valu_task_blocks(spin) : 2 * 4; }
 
 struct SynValuParams {
     PlanDev P;
     const LegTask *__restrict__ tasks;
-    const double2 *__restrict__ alm;  // spin 0: the map's alm; spin 2: E, then B at + alm_stride
+    const double2 *__restrict__ alm;  // component c at + c alm_stride: spin 0: the maps' alms; spin 2: (E, B) per field
     long long alm_stride;
-    double *__restrict__ Fv;          // [m][rp][NV]
+    double *__restrict__ Fv;          // [m][rp][NV]: component c = (N_re, N_im, S_re, S_im) at 4 c (spin 2: Q, U of field b at 8 b)
 };
 
-template <int SPIN>
-__global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_synth_valu(SynValuParams A, const double2 *__restrict__ coefn, const double *__restrict__ alphan)
+// (four spin-0 maps: 294 registers if the compiler may -- copies in AGPRs around the checks and hand-overs; held to 256, i.e. two
+// waves per SIMD like the other shapes, the copies become a few scratch accesses outside the steady loop)
+template <int SPIN, int NB>
+__global__ __launch_bounds__(64, (SPIN == 0 && NB == 4) ? 2 : HX_VALU_WAVES) void k_legendre_synth_valu(SynValuParams A, const double2 *__restrict__ coefn, const double *__restrict__ alphan)
 {
-    using C = SynValuCfg<SPIN>;
-    constexpr int R = C::R, LB = C::LB, NAV = C::NAV, NV = C::NV, NCH = 2;
+    using C = SynValuCfg<SPIN, NB>;
+    constexpr int R = C::R, LB = C::LB, NAV = C::NAV, NV = C::NV, NA1 = C::NA1, NV1 = C::NV1, NCH = 2;
     constexpr int CH = 32, NSB = CH / LB;
     __shared__ double2 cfs[2][CH];
     __shared__ double avs[2][CH][NAV];
@@ -513,12 +521,14 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_synth_valu(SynVa
         vp[r][c] = pz ? 0.0 : __hiloint2double(hp - sub, __double2loint(vp[r][c]));
         sc[r][c] += up ? 1 : 0;
     };
-    // accumulators of chain c of slot r: spin 0: (2 c, 2 c + 1); spin 2: lambda+ (c = 0) 0..3, lambda- (c = 1) 4..7
+    // accumulators of chain c of slot r, map / field b: spin 0: NV1 b + (2 c, 2 c + 1); spin 2: lambda+ (c = 0) NV1 b + 0..3, lambda- (c = 1) + 4..7
     auto drop = [&](int r, int c) __attribute__((always_inline)) {
         const bool z = sc[r][c] != 0;
-        constexpr int NQ = NV / 2;
+        constexpr int NQ = NV1 / 2;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[r][c * NQ + q] = z ? 0.0 : acc[r][c * NQ + q];
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[r][b * NV1 + c * NQ + q] = z ? 0.0 : acc[r][b * NV1 + c * NQ + q];
     };
     // one l step of slot r (the registers of a chain swap roles from step to step, as in k_legendre_valu); av = alpha_l a_lm
     auto step = [&](auto ACCC, int r, int s, const double2 c, const double (&av)[NAV]) __attribute__((always_inline)) {
@@ -528,8 +538,11 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_synth_valu(SynVa
             double &va = odd ? vp[r][ch] : vc[r][ch], &vb = odd ? vc[r][ch] : vp[r][ch];
             const double t = fma(c.x, xx[r], c.y);
             if (ACC) {
-                acc[r][2 * ch + 0] = fma(va, av[0], acc[r][2 * ch + 0]);
-                acc[r][2 * ch + 1] = fma(va, av[1], acc[r][2 * ch + 1]);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    acc[r][b * NV1 + 2 * ch + 0] = fma(va, av[b * NA1 + 0], acc[r][b * NV1 + 2 * ch + 0]);
+                    acc[r][b * NV1 + 2 * ch + 1] = fma(va, av[b * NA1 + 1], acc[r][b * NV1 + 2 * ch + 1]);
+                }
             }
             vb = fma(t, va, -vb);
         } else {
@@ -538,15 +551,19 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_synth_valu(SynVa
             double &a1 = odd ? vp[r][1] : vc[r][1], &b1 = odd ? vc[r][1] : vp[r][1];
             const double t0 = fma(c.x, xx[r], c.y), t1 = fma(c.x, xx[r], -c.y);
             if (ACC) {
-                // av = (a+_re, a+_im, a-_re, a-_im); the southern sums alternate in sign with l (the overall sign (-1)^off at the end)
-                acc[r][0] = fma(a0, av[0], acc[r][0]);
-                acc[r][1] = fma(a0, av[1], acc[r][1]);
-                acc[r][2] = fma(odd ? -a0 : a0, av[2 % NAV], acc[r][2]);
-                acc[r][3] = fma(odd ? -a0 : a0, av[3 % NAV], acc[r][3]);
-                acc[r][4 % NV] = fma(a1, av[2 % NAV], acc[r][4 % NV]);
-                acc[r][5 % NV] = fma(a1, av[3 % NAV], acc[r][5 % NV]);
-                acc[r][6 % NV] = fma(odd ? -a1 : a1, av[0], acc[r][6 % NV]);
-                acc[r][7 % NV] = fma(odd ? -a1 : a1, av[1], acc[r][7 % NV]);
+                // av = (a+_re, a+_im, a-_re, a-_im) per field; the southern sums alternate in sign with l (the overall sign (-1)^off at the end)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const int o = b * NV1, v = b * NA1;
+                    acc[r][o + 0] = fma(a0, av[v + 0], acc[r][o + 0]);
+                    acc[r][o + 1] = fma(a0, av[v + 1], acc[r][o + 1]);
+                    acc[r][o + 2] = fma(odd ? -a0 : a0, av[v + 2 % NA1], acc[r][o + 2]);
+                    acc[r][o + 3] = fma(odd ? -a0 : a0, av[v + 3 % NA1], acc[r][o + 3]);
+                    acc[r][o + 4 % NV1] = fma(a1, av[v + 2 % NA1], acc[r][o + 4 % NV1]);
+                    acc[r][o + 5 % NV1] = fma(a1, av[v + 3 % NA1], acc[r][o + 5 % NV1]);
+                    acc[r][o + 6 % NV1] = fma(odd ? -a1 : a1, av[v + 0], acc[r][o + 6 % NV1]);
+                    acc[r][o + 7 % NV1] = fma(odd ? -a1 : a1, av[v + 1], acc[r][o + 7 % NV1]);
+                }
             }
             b0 = fma(t0, a0, -b0);
             b1 = fma(t1, a1, -b1);
@@ -564,14 +581,17 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_synth_valu(SynVa
             cpre = coefn[cb + l + coff];
             const bool in = l <= lmax;
             const double al = alphan[cb + l];
-            if (SPIN == 0) {
-                const double2 a = in ? A.alm[cb + l] : make_double2(0.0, 0.0);
-                apre[0] = al * a.x; apre[1] = al * a.y;
-            } else {
-                const double2 E = in ? A.alm[cb + l] : make_double2(0.0, 0.0);
-                const double2 B = in ? A.alm[A.alm_stride + cb + l] : make_double2(0.0, 0.0);
-                apre[0] = al * (-E.x + B.y); apre[1] = al * (-E.y - B.x);                  // a+ = -(E + iB)
-                apre[2 % NAV] = al * (-E.x - B.y); apre[3 % NAV] = al * (-E.y + B.x);      // a- = -(E - iB)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (SPIN == 0) {
+                    const double2 a = in ? A.alm[b * A.alm_stride + cb + l] : make_double2(0.0, 0.0);
+                    apre[b * NA1 + 0] = al * a.x; apre[b * NA1 + 1] = al * a.y;
+                } else {
+                    const double2 E = in ? A.alm[2 * b * A.alm_stride + cb + l] : make_double2(0.0, 0.0);
+                    const double2 B = in ? A.alm[(2 * b + 1) * A.alm_stride + cb + l] : make_double2(0.0, 0.0);
+                    apre[b * NA1 + 0] = al * (-E.x + B.y); apre[b * NA1 + 1] = al * (-E.y - B.x);              // a+ = -(E + iB)
+                    apre[b * NA1 + 2 % NA1] = al * (-E.x - B.y); apre[b * NA1 + 3 % NA1] = al * (-E.y + B.x);  // a- = -(E - iB)
+                }
             }
         }
     };
@@ -645,8 +665,12 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_synth_valu(SynVa
         }
         const double2 *cf = cfs[buf] + sb * LB;
         const double (*av)[NAV] = avs[buf] + sb * LB;
+        // wide sweeps (8 table doubles per l): hipcc otherwise requests the values of the WHOLE block in the block before it -- 80
+        // registers beside 64 accumulators, 294 in all, one wave per SIMD; the empty asm statements pin the look-ahead to one l
+        constexpr bool PIN = NAV > 4;
         double2 cn = cf[0];
         double an[NAV];
+        if (PIN) asm volatile("" ::: "memory");
 #pragma unroll
         for (int q = 0; q < NAV; ++q) an[q] = av[0][q];
 #pragma unroll
@@ -655,6 +679,7 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_synth_valu(SynVa
             double a[NAV];
 #pragma unroll
             for (int q = 0; q < NAV; ++q) a[q] = an[q];
+            if (PIN) asm volatile("" ::: "memory");
             if (s + 1 < LB) {  // the next l's values land while this l runs
                 cn = cf[s + 1];
 #pragma unroll
@@ -677,34 +702,40 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_synth_valu(SynVa
         const int k = r * 64 + lane, rp = task.rb0 * RBLK + k;
         if (k >= task.nrb * RBLK || rp >= P.nrp_pad) continue;
         double o[NV];
-        if (SPIN == 0) {
-            o[0] = acc[r][0] + acc[r][2]; o[1] = acc[r][1] + acc[r][3];
-            o[2] = acc[r][0] - acc[r][2]; o[3] = acc[r][1] - acc[r][3];
-        } else {
-            const double ppn_r = acc[r][0], ppn_i = acc[r][1], pms_r = ssgn * acc[r][2], pms_i = ssgn * acc[r][3];
-            const double pmn_r = acc[r][4 % NV], pmn_i = acc[r][5 % NV], pps_r = ssgn * acc[r][6 % NV], pps_i = ssgn * acc[r][7 % NV];
-            // Q = (P+ + P-) / 2;  U = (P+ - P-) / 2i: U_re = (Im P+ - Im P-) / 2, U_im = -(Re P+ - Re P-) / 2
-            o[0] = 0.5 * (ppn_r + pmn_r); o[1] = 0.5 * (ppn_i + pmn_i);
-            o[2] = 0.5 * (pps_r + pms_r); o[3] = 0.5 * (pps_i + pms_i);
-            o[4 % NV] = 0.5 * (ppn_i - pmn_i); o[5 % NV] = -0.5 * (ppn_r - pmn_r);
-            o[6 % NV] = 0.5 * (pps_i - pms_i); o[7 % NV] = -0.5 * (pps_r - pms_r);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const double *ac = acc[r] + b * NV1;
+            double *ob = o + b * NV1;
+            if (SPIN == 0) {
+                ob[0] = ac[0] + ac[2]; ob[1] = ac[1] + ac[3];
+                ob[2] = ac[0] - ac[2]; ob[3] = ac[1] - ac[3];
+            } else {
+                const double ppn_r = ac[0], ppn_i = ac[1], pms_r = ssgn * ac[2], pms_i = ssgn * ac[3];
+                const double pmn_r = ac[4 % NV1], pmn_i = ac[5 % NV1], pps_r = ssgn * ac[6 % NV1], pps_i = ssgn * ac[7 % NV1];
+                // Q = (P+ + P-) / 2;  U = (P+ - P-) / 2i: U_re = (Im P+ - Im P-) / 2, U_im = -(Re P+ - Re P-) / 2
+                ob[0] = 0.5 * (ppn_r + pmn_r); ob[1] = 0.5 * (ppn_i + pmn_i);
+                ob[2] = 0.5 * (pps_r + pms_r); ob[3] = 0.5 * (pps_i + pms_i);
+                ob[4 % NV1] = 0.5 * (ppn_i - pmn_i); ob[5 % NV1] = -0.5 * (ppn_r - pmn_r);
+                ob[6 % NV1] = 0.5 * (pps_i - pms_i); ob[7 % NV1] = -0.5 * (pps_r - pms_r);
+            }
         }
         double *row = fm + (long long)rp * NV;
 #pragma unroll
         for (int q = 0; q < NV; q += 2) *reinterpret_cast<double2 *>(row + q) = make_double2(o[q], o[q + 1]);
     }
     if (lane == 0) {
-        constexpr unsigned long long REC = SPIN == 0 ? 2 : 4, ACC = SPIN == 0 ? 2 : 8;
+        constexpr unsigned long long REC = SPIN == 0 ? 2 : 4, ACC = (SPIN == 0 ? 2 : 8) * NB;
         atomicAdd(&g_valu_flops, (unsigned long long)(n_dead * REC + n_acc * (REC + ACC)) * (64ull * R * LB * 2ull));
     }
 }
 
-// Fv of component c0 (spin 2: the field (c0, c0 + 1)) of d_alms; rings outside the task list (pruned) stay zero
-template <int SPIN>
+// Fv of `units` maps (spin 0: 1, 2 or 4) / fields (spin 2: 1 or 2) whose alms start at d_alm; ts = the task set of
+// synth_valu_task_blocks(spin, units) ring blocks per task; rings outside the task list (pruned) stay zero
+template <int SPIN, int NB>
 static int launch_synth_valu_t(hx_plan *pl, hx_plan::TaskSet &ts, const double2 *d_alm, double *d_Fv)
 {
     hipStream_t st = rt().stream;
-    constexpr int NV = SynValuCfg<SPIN>::NV;
+    constexpr int NV = SynValuCfg<SPIN, NB>::NV;
     HX_HIP(hipMemsetAsync(d_Fv, 0, sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * NV, st));
     SynValuParams A;
     A.P = pl->dev(); A.tasks = ts.d_tasks.as<LegTask>(); A.alm = d_alm; A.alm_stride = pl->nlm; A.Fv = d_Fv;
@@ -712,13 +743,18 @@ static int launch_synth_valu_t(hx_plan *pl, hx_plan::TaskSet &ts, const double2 
     const double *al = SPIN == 0 ? pl->al0.as<double>() : pl->al2.as<double>();
     ProfScope ps("legendre_synthesis");
     ProfScope ps2("legendre_synth_valu");
-    hipLaunchKernelGGL(k_legendre_synth_valu<SPIN>, dim3((unsigned)ts.tasks.size()), dim3(64), 0, st, A, cn, al);
+    hipLaunchKernelGGL((k_legendre_synth_valu<SPIN, NB>), dim3((unsigned)ts.tasks.size()), dim3(64), 0, st, A, cn, al);
     HX_HIP(hipGetLastError());
     return HX_OK;
 }
-int launch_synth_valu(hx_plan *pl, int spin, hx_plan::TaskSet &ts, const double2 *d_alm, double *d_Fv)
+int launch_synth_valu(hx_plan *pl, int spin, int units, hx_plan::TaskSet &ts, const double2 *d_alm, double *d_Fv)
 {
-    return spin == 0 ? launch_synth_valu_t<0>(pl, ts, d_alm, d_Fv) : launch_synth_valu_t<2>(pl, ts, d_alm, d_Fv);
+    if (spin == 0 && units == 1) return launch_synth_valu_t<0, 1>(pl, ts, d_alm, d_Fv);
+    if (spin == 0 && units == 2) return launch_synth_valu_t<0, 2>(pl, ts, d_alm, d_Fv);
+    if (spin == 0 && units == 4) return launch_synth_valu_t<0, 4>(pl, ts, d_alm, d_Fv);
+    if (spin == 2 && units == 1) return launch_synth_valu_t<2, 1>(pl, ts, d_alm, d_Fv);
+    if (spin == 2 && units == 2) return launch_synth_valu_t<2, 2>(pl, ts, d_alm, d_Fv);
+    return fail(HX_ERR_ARG, "launch_synth_valu: %d units of spin %d", units, spin);
 }
 
 // =====================================================================================

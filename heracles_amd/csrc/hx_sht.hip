@@ -967,20 +967,25 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
                            const double *d_ref)
 {
     hipStream_t st = rt().stream;
-    hx_plan::TaskSet *ts = nullptr;
-    HX_TRY(valu_tasks(pl, spin, &ts));
-    const int unit = spin ? 2 : 1;
-    HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * unit));
-    HX_TRY(pl->resid.alloc(sizeof(double2) * (size_t)pl->ny * unit));  // conj(Z) spectra
-    HX_TRY(pl->Fsyn.alloc(sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * synth_valu_doubles(spin)));
+    // maps (spin 0) / fields (spin 2) per sweep: as many as the kernel takes (4 / 2: they share the recursion), then the rest
+    const int cpu = spin ? 2 : 1, umax = synth_valu_max_units(spin);
+    HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * cpu * umax));
+    HX_TRY(pl->resid.alloc(sizeof(double2) * (size_t)pl->ny * cpu * umax));  // conj(Z) spectra
+    HX_TRY(pl->Fsyn.alloc(sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * 4 * cpu * umax));
     PlanDev P = pl->dev();
-    for (int c0 = 0; c0 < nb; c0 += unit) {
-        HX_TRY(launch_synth_valu(pl, spin, *ts, d_alms + (size_t)c0 * pl->nlm, pl->Fsyn.as<double>()));
+    for (int c0 = 0; c0 < nb;) {
+        int units = umax;
+        while (units * cpu > nb - c0) units >>= 1;
+        const int nc = units * cpu;
+        hx_plan::TaskSet *ts = nullptr;
+        HX_TRY(valu_tasks(pl, spin, &ts, synth_valu_task_blocks(spin, units)));
+        HX_TRY(launch_synth_valu(pl, spin, units, *ts, d_alms + (size_t)c0 * pl->nlm, pl->Fsyn.as<double>()));
         ProfScope ps("ring_fft");
-        hipLaunchKernelGGL(k_synth_spectrum_v, dim3((pl->nrp + 3) / 4), dim3(256), 0, st, P, pl->Fsyn.as<double>(), unit, pl->lmax, pl->resid.as<double2>());
-        HX_TRY(launch_subdft_classes<1>(pl, unit, nullptr, nullptr, pl->resid.as<double2>(), pl->Y.as<double2>()));
-        hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, unit), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps + (size_t)c0 * pl->npix, d_ref ? 1 : 0,
+        hipLaunchKernelGGL(k_synth_spectrum_v, dim3((pl->nrp + 3) / 4), dim3(256), 0, st, P, pl->Fsyn.as<double>(), nc, pl->lmax, pl->resid.as<double2>());
+        HX_TRY(launch_subdft_classes<1>(pl, nc, nullptr, nullptr, pl->resid.as<double2>(), pl->Y.as<double2>()));
+        hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, nc), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps + (size_t)c0 * pl->npix, d_ref ? 1 : 0,
                            d_ref ? d_ref + (size_t)c0 * pl->npix : nullptr);
+        c0 += nc;
     }
     HX_HIP(hipGetLastError());
     return HX_OK;

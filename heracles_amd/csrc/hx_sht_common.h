@@ -307,8 +307,9 @@ struct hx_plan {
         std::vector<long long> rows_before_m; // partial rows of all tasks with smaller m (size lmax+2)
         std::vector<long long> arow;          // the same with ONE span of rows per m (pipelined kernel: ring groups summed in place)
         hx::DevBuf d_tasks, d_of_m, d_arow;
-    } ts[6];  // spin 0, spin 2, spin 0 with half-size work-groups, spin 2 with one ring set per wave (4 ring blocks per task),
-       // spin 2 / spin 0 on the vector unit (hx_legendre_valu.hip: 2 R ring blocks per task)
+    } ts[8];  // spin 0, spin 2, spin 0 with half-size work-groups, spin 2 with one ring set per wave (4 ring blocks per task),
+       // spin 2 / spin 0 on the vector unit (hx_legendre_valu.hip: 2 R ring blocks per task), spin 2 / spin 0 synthesis of several
+       // maps per sweep (8 ring blocks per task)
     struct FftClass { int M, first, count, big; };
     std::vector<FftClass> fft_classes;   // ring pairs grouped by in-LDS FFT length
     hx::DevBuf fft_rp_list;
@@ -336,7 +337,8 @@ int valu_task_blocks(int spin);      // 32-ring-pair blocks per task
 int valu_partial_cols(int spin);     // doubles per row of the partial buffer
 int valu_operand_doubles(int spin);  // doubles per (m, ring pair) of the operand array
 int valu_exec_flops(unsigned long long *v, bool reset);
-int valu_tasks(hx_plan *pl, int spin, hx_plan::TaskSet **ts);  // (hx_analysis.hip) the task set of the vector-unit kernels, built on first use
-int synth_valu_doubles(int spin);    // doubles per (m, ring pair) of the synthesis output Fv[m][rp][.]
-int launch_synth_valu(hx_plan *pl, int spin, hx_plan::TaskSet &ts, const double2 *d_alm, double *d_Fv);  // one map / field: alm -> Fv  // FP64 vector flops executed by the vector-unit kernels since the last reset
+int valu_tasks(hx_plan *pl, int spin, hx_plan::TaskSet **ts, int blocks = 0);  // (hx_analysis.hip) task set of the vector-unit kernels (blocks: 32-ring-pair blocks per task, 0 = valu_task_blocks), built on first use
+int synth_valu_max_units(int spin);                // maps (spin 0) / fields (spin 2) per sweep of the synthesis kernel: 1, 2, .. a power of two
+int synth_valu_task_blocks(int spin, int units);   // ring blocks per task of that sweep
+int launch_synth_valu(hx_plan *pl, int spin, int units, hx_plan::TaskSet &ts, const double2 *d_alm, double *d_Fv);  // alm -> Fv[m][rp][4 per component]  // FP64 vector flops executed by the vector-unit kernels since the last reset
 }  // namespace hx
