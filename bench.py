@@ -55,6 +55,7 @@ def parse():
     p.add_argument("--no-mixmat", action="store_true")
     p.add_argument("--no-host-leg", action="store_true", help="skip the host -> host (PCIe-inclusive) measurement")
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--no-single", action="store_true", help="skip the single-map transform timings")
     return p.parse_args()
 
 
@@ -388,6 +389,27 @@ def main():
             oa0, oa2, tim, stride = osample
             cpu = cpu_baseline(nside, lmax, per_set.count(0), per_set.count(2), oa0, oa2, tim, stride)
 
+        # ---- the reference's own call shape: ONE map / ONE field per transform (heracles/mapping.py:171), resident inputs; with
+        # niter = 0 (weights supplied) and with healpy's default three Jacobi iterations; one alm2map.  Informational: not `value`.
+        single = None
+        if world == 1 and not args.no_single:
+            single = {}
+            for spin, src in ((0, maps0[:1]), (2, maps2[0])):
+                a1 = torch.empty((src.shape[0], nlm), dtype=torch.complex128, device=dev)
+                back = torch.empty_like(src)
+                for name, fn in (("map2alm_niter0_ms", lambda: plan.map2alm(src, spin, out=a1, pix_weights=pw)),
+                                 ("map2alm_niter3_ms", lambda: plan.map2alm(src, spin, out=a1, niter=3)),
+                                 ("alm2map_ms", lambda: plan.alm2map(a1, spin, out=back))):
+                    fn()
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    fn()
+                    torch.cuda.synchronize(dev)
+                    single[f"spin{spin}_{name}"] = (time.perf_counter() - t1) * 1e3
+                del a1, back
+            single["what"] = ("one spin-0 map / one spin-2 (Q, U) field per call, device-resident: the vector-unit kernels "
+                              "(k_legendre_valu, k_legendre_synth_valu)")
+
         mix = None
         if not args.no_mixmat:
             L = args.mixmat_lmax or lmax
@@ -426,6 +448,7 @@ def main():
             "strong_scaling": strong,
             "value_host_to_host": host_leg["value"] if host_leg else None,
             "host_to_host": host_leg,
+            "single_map_transforms": single,
             "mixmat_build_sec": mix["seconds"] if mix else None,
             "mixmat": mix,
             "roofline": roofline,
