@@ -49,8 +49,7 @@ struct LegParams {
     int ng;                            // active column groups (<= NG, + 1 if there are extra 4-column blocks)
     int ncol;                          // doubles per F / partial row: 16 per full group + 4 per extra block
     int pcol;                          // pipelined kernel: doubles per accumulation row = ncol rounded up to whole 128-byte lines
-    int ablate;                        // diagnostic only (HX_ABLATE): 1 skip MFMA, 2 skip recursion, 8 count paths
-    unsigned long long *counters;
+    unsigned long long *counters;      // diagnostic builds only (HX_PIPE_ABL & 8: cycle accounting per stage kind)
     // pipelined kernel only: a work-group owns one m and walks its ring groups in order (tasks and of_m are then the whole
     // lists, indexed by m), adding into ONE span of rows per m: arow[m] - arow0
     const MTasks *__restrict__ of_m;
@@ -967,7 +966,6 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         LegParams A;
         A.P = P; A.tasks = ts.d_tasks.as<LegTask>() + t0; A.F = pl->F.as<double>(); A.partial = pl->partial.as<double>();
         A.m0 = m0; A.ms = ms; A.row0 = ts.rows_before_m[m0]; A.ng = ng; A.ncol = ncol; A.pcol = pcol;
-        A.ablate = 0;
         A.counters = nullptr;
         A.of_m = ts.d_of_m.as<MTasks>(); A.arow = ts.d_arow.as<long long>(); A.arow0 = ts.arow[m0];
         A.tasks = ts.d_tasks.as<LegTask>();  // the pipelined kernel indexes the whole list through of_m
