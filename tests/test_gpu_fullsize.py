@@ -65,6 +65,24 @@ def test_analysis_is_the_adjoint_of_synthesis(plan, spin):
 
 
 @pytest.mark.parametrize("spin", [0, 2])
+def test_synthesis_sweeps_of_several_maps_full_size(plan, spin):
+    """The multi-map shapes of the synthesis kernel at nside 4096 (four spin-0 maps / two spin-2 fields share one recursion):
+    bitwise equal to the single-map sweeps, which the adjointness test above ties to the analysis."""
+    import torch
+
+    nc = 5 if spin == 0 else 6  # sweeps of 4 + 1 maps / 2 + 1 fields
+    a = _random_alm(torch, nc, 31 + spin, lmin=spin)
+    y = torch.empty((nc, NPIX), dtype=torch.float64, device="cuda")
+    plan.alm2map(a, spin, out=y)
+    unit = 1 if spin == 0 else 2
+    one = torch.empty((unit, NPIX), dtype=torch.float64, device="cuda")
+    for c in (0, nc - unit):
+        plan.alm2map(a[c : c + unit], spin, out=one)
+        assert torch.equal(one, y[c : c + unit])
+    assert bool(torch.isfinite(y).all())
+
+
+@pytest.mark.parametrize("spin", [0, 2])
 def test_linearity_full_size(plan, spin):
     import torch
 

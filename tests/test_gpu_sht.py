@@ -108,6 +108,22 @@ def test_alm2map_medium_scaled_chains(oracle, nside, lmax, spin):
 
 
 @pytest.mark.parametrize("spin", [0, 2])
+def test_alm2map_sweeps_of_several_maps_match_single_sweeps(spin):
+    """Four spin-0 maps / two spin-2 fields per synthesis sweep share the recursion (other ring slots per lane, other block
+    lengths): every lane still adds the same terms in the same order, so a batch is bitwise what its maps give one by one."""
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(91 + spin)
+    nside, lmax = 128, 200
+    alm = random_alm(rng, lmax, spin, (7,) if spin == 0 else (6,))  # sweeps of 4 + 2 + 1 maps / 2 + 1 fields
+    plan = hx.get_plan(nside, lmax)
+    batch = plan.alm2map(alm, spin)
+    unit = 1 if spin == 0 else 2
+    for c in range(0, alm.shape[0], unit):
+        np.testing.assert_array_equal(batch[c : c + unit], plan.alm2map(alm[c : c + unit], spin))
+
+
+@pytest.mark.parametrize("spin", [0, 2])
 def test_roundtrip_medium(oracle, spin):
     """nside=256, lmax=384: alm -> map (GPU) -> alm (GPU, niter=3) returns the input."""
     import heracles_amd as hx
