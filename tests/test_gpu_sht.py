@@ -82,6 +82,24 @@ def _apply_fl(alm, fl, lmax):
     return out
 
 
+@pytest.mark.parametrize("spin,ncomp", [(0, 11), (2, 10)])
+def test_iterations_on_batches(oracle, spin, ncomp):
+    """Jacobi iterations of a batch: the analysis passes take the batch in the sweeps of the plain transform (one matrix sweep of
+    11 maps / 5 fields), the syntheses in sweeps of 4 maps / 2 fields that share the recursion, residual maps in plan scratch
+    sized for the whole sweep -- against the oracle's iterations map by map."""
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(29 + spin)
+    nside, lmax = 32, 64
+    maps = rng.standard_normal((ncomp, 12 * nside**2))
+    plan = hx.get_plan(nside, lmax)
+    got = plan.map2alm(maps, spin, niter=2)
+    unit = 1 if spin == 0 else 2
+    for c in (0, ncomp - unit):
+        close(got[c : c + unit], oracle.map2alm(maps[c : c + unit], nside, lmax, spin=spin, niter=2), 1e-10)
+    close(got, np.concatenate([plan.map2alm(maps[c : c + unit], spin, niter=2) for c in range(0, ncomp, unit)]), 1e-11)
+
+
 @pytest.mark.parametrize("nside,lmax", [(4, 8), (8, 20), (12, 20), (32, 48)])
 @pytest.mark.parametrize("spin", [0, 2])
 def test_alm2map(oracle, nside, lmax, spin):
