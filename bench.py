@@ -56,6 +56,7 @@ def parse():
     p.add_argument("--no-host-leg", action="store_true", help="skip the host -> host (PCIe-inclusive) measurement")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--no-single", action="store_true", help="skip the single-map transform timings")
+    p.add_argument("--generic-weights", action="store_true", help="pixel weights without the symmetry of healpy's files (generic path of the ring kernels)")
     return p.parse_args()
 
 
@@ -174,9 +175,17 @@ def main():
     maps2 = torch.randn((n2, 2, npix), dtype=torch.float64, device=dev, generator=gen)
     alm0, alm2 = work.local_alm_views(dev)
     # Pixel weights in the timed path: the reference always transforms with use_pixel_weights=True (heracles/healpy.py:186).
-    # healpy's weight files are not available offline; a synthetic full-sky array of the same kind (1 + small, smooth, 8-fold
-    # symmetric is not required by the kernels) stands in: the kernels do the same work whatever the values.
-    pw = 1.0 + 1e-3 * torch.cos(torch.arange(npix, dtype=torch.float64, device=dev) * (2.0 * np.pi / 1024.0))
+    # healpy's weight files are not available offline; a synthetic file of the same FORMAT stands in: random values (1e-3) in
+    # healpy's compressed layout, expanded by the library exactly as a real file would be (heracles_amd.weights) -- so the full-sky
+    # array has the symmetry real weights have (it repeats over the four quadrants of a ring and from north to south), which the
+    # ring kernels detect per call and use (one weight per pixel pair instead of eight; an array without it takes the generic
+    # path: --generic-weights).
+    from heracles_amd import weights as hxw
+
+    if args.generic_weights:
+        pw = 1.0 + 1e-3 * torch.cos(torch.arange(npix, dtype=torch.float64, device=dev) * (2.0 * np.pi / 1024.0))
+    else:
+        pw = hxw.expand_pixel_weights(nside, 1e-3 * np.random.default_rng(7).standard_normal(hxw.compressed_size(nside)), device=dev)
 
     def step():
         if n2:
@@ -441,10 +450,10 @@ def main():
             "config": {"workload": f"{nbins} bins x ({'2 spin-0 + 1 spin-2' if args.workload == 'euclid' else 'spin-0, spin-2'}) maps "
                                    f"{'per GPU' if args.scaling == 'weak' else 'in all'} = "
                                    f"{nmaps_total} maps / {sum(2 if s else 1 for s in spins)} components over {world} GPU(s), nside={nside}, lmax={lmax}, "
-                                   f"niter=0, ring weights 1, pix_weights: synthetic full-sky array (healpy's files are not available offline); "
+                                   f"niter=0, ring weights 1, pix_weights: synthetic file in healpy's format (its files are not available offline); "
                                    f"{npairs} auto+cross map pairs; inputs resident in HBM",
                        "nside": nside, "lmax": lmax, "maps_total": nmaps_total, "maps_this_rank": len(mine), "pairs": npairs,
-                       "pix_weights": "synthetic full-sky array, applied in the timed path",
+                       "pix_weights": ("synthetic array without symmetry (generic path)" if args.generic_weights else "synthetic weights in healpy's compressed format, expanded to the full sky (symmetric like healpy's)") + ", applied in the timed path",
                        "parallelism": (f"maps dealt to {world} GPUs by cost, RCCL all-gather of alms, tiled pair split"
                                        if world > 1 else "1 GPU")},
             "verified": (verify or {}).get("ok") if verify is not None else None,

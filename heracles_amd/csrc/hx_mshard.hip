@@ -79,6 +79,7 @@ extern "C" int hx_ring_modes(hx_plan *pl, int ncomp, const double *maps, const d
     HX_TRY(vmaps.bind(maps, sizeof(double) * (size_t)ncomp * pl->npix));
     HX_TRY(vrw.bind(ring_weights, sizeof(double) * pl->nrp));
     HX_TRY(vpw.bind(pix_weights, sizeof(double) * (size_t)pl->npix));
+    HX_TRY(classify_pixel_weights(pl, vpw.as<double>()));
     PlanDev P = pl->dev();
     P.nssrc = nullptr;
     P.hsrc = nullptr;

@@ -149,7 +149,13 @@ __host__ __device__ inline int ring_ph_hi(int M) { return (4 * M) / 64 + 1; }  /
 constexpr int RING_NTMAX = 512;  // threads per group: M / 16 (one radix-16 butterfly per thread and pass), 64 at least
 constexpr int RING_FB = 8;       // values of j per thread whose pixel loads are in flight together (64 loads)
 
-template <int MODE>
+// WSYM (MODE 0): the pixel-weight array has the symmetry of healpy's full weights -- it repeats over the four quadrants of a ring
+// and from the northern to the southern ring of a pair -- so ONE weight per pixel pair of the first quadrant is read instead of
+// eight.  Whether an array has that symmetry is found once per call of the C ABI (k_pixw_symmetry, one read of the array and a
+// 4-byte read-back before anything else of the call is queued).  A template parameter, because a second run-time branch inside
+// the batches of loads splits them (17.2 instead of 14.0 ms per 8 components even without weights); "weights or none" stays the
+// run-time test it was (as a compile-time constant the 64 loads of the generic path are issued together: 256 registers, 34 spilled).
+template <int MODE, bool WSYM = false>
 __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int *__restrict__ rp_list, int nrings, int nb, int Mclass,
                                                             const double *__restrict__ maps,
                                                             const double *__restrict__ pixw,
@@ -189,7 +195,8 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
         // to L2 / HBM per batch instead of one per j (out-of-range j read pixel 0 of the ring and write the spare slot of the
         // buffer; a missing southern ring (the equator) reads the northern one and selects 0).  The first batch is requested
         // before the phase tables are built, whose sincospi then cover part of its way ----
-        const bool haveS = sS >= 0, pw = MODE == 0 && pixw != nullptr, odd = r & 1;
+        const bool haveS = sS >= 0, odd = r & 1, pw = MODE == 0 && !WSYM && pixw != nullptr;
+        constexpr bool wsym = MODE == 0 && WSYM;
         const double sg = (r & 2) ? -1.0 : 1.0;
         const double *mpN = maps + (long long)c * P.npix + sN, *mpS = maps + (long long)c * P.npix + (haveS ? sS : sN);
         const double *pwN = pixw + sN, *pwS = pixw + (haveS ? sS : sN);
@@ -207,6 +214,8 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
                 const int j = 2 * (tid + ((u0 + u) >> 1) * nt);      // first j of the pair; the batch covers j < (u0 + RING_FB) nt
                 const bool tail = j == n - 1 && n >= 2;              // (n = 1: the scalar path below)
                 const int jj = tail ? n - 2 : (j + 1 < n ? j : 0);
+                Pair wq = {1.0, 1.0};
+                if (MODE == 0 && wsym && n >= 2) wq = *reinterpret_cast<const Pair *>(pwN + jj);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int i = jj + q * n;
@@ -218,13 +227,15 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
                         if (n >= 2) {
                             fn = *reinterpret_cast<const Pair *>(mpN + i);
                             fs = *reinterpret_cast<const Pair *>(mpS + i);
-                            if (pw) {
+                            if (wsym) {
+                                fn.x *= wq.x; fn.y *= wq.y; fs.x *= wq.x; fs.y *= wq.y;
+                            } else if (pw) {
                                 const Pair wn = *reinterpret_cast<const Pair *>(pwN + i), ws = *reinterpret_cast<const Pair *>(pwS + i);
                                 fn.x *= wn.x; fn.y *= wn.y; fs.x *= ws.x; fs.y *= ws.y;
                             }
                         } else {
                             fn.x = fn.y = mpN[q]; fs.x = fs.y = mpS[q];
-                            if (pw) { fn.x *= pwN[q]; fs.x *= pwS[q]; fn.y = fn.x; fs.y = fs.x; }
+                            if (pw || wsym) { fn.x *= pwN[q]; fs.x *= pwS[q]; fn.y = fn.x; fs.y = fs.x; }
                         }
                         z[u][q] = make_double2(tail ? fn.y : fn.x, haveS ? (tail ? fs.y : fs.x) : 0.0);
                         z[u + 1][q] = make_double2(fn.y, haveS ? fs.y : 0.0);
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
 //     so one read of the pixels fills two LDS buffers, and the two halves of the work-group (M / 16 threads each) run one
 //     transform each: half the reads.  Two 4096-point buffers are 139 KiB: one group of 512 threads per CU.
 // =====================================================================================
-template <int MODE>
+template <int MODE, bool WSYM = false>
 __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const int *__restrict__ rp_list, int nrings, int nb, int M,
                                                              const double *__restrict__ maps, const double *__restrict__ pixw,
                                                              const double2 *__restrict__ zin, double2 *__restrict__ Y)
@@ -380,6 +391,9 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const in
     if (tid < 64) ph_lo[tid] = expipi(-(double)tid / (2.0 * n));
     __syncthreads();
     auto phase = [&](unsigned q) __attribute__((always_inline)) { return cmul(ph_hi[q >> 6], ph_lo[q & 63]); };  // exp(-i pi q / 2n), q < 4n
+#if HX_FFT_ABL & 32
+    unsigned long long fcyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flast = __builtin_amdgcn_s_memtime();
+#endif
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         // one round per item: item = 8 (2 s + rpair) + x -- the two items of set s = (ring set s / nb, component s % nb) on XCD x
         const int rfirst = HX_PAIR_ROUNDS == 2 ? 0 : (item >> 3) & 1, set = item >> 4;
@@ -388,7 +402,8 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const in
         const int rp = rp_list[ring];
         const long long sN = P.startN[rp], sS = P.startS[rp];
         asm volatile("; item" : "+v"(tid));
-        const bool haveS = sS >= 0, pw = MODE == 0 && pixw != nullptr;
+        const bool haveS = sS >= 0, pw = MODE == 0 && !WSYM && pixw != nullptr;
+        constexpr bool wsym = MODE == 0 && WSYM;
         const double *mpN = maps + (long long)c * P.npix + sN, *mpS = maps + (long long)c * P.npix + (haveS ? sS : sN);
         const double *pwN = pixw + sN, *pwS = pixw + (haveS ? sS : sN);
         const double2 *zp = zin + (long long)c * P.ny + sN;
@@ -398,12 +413,16 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const in
 #pragma unroll
         for (int u = 0; u < RING_FB; u += 2) {
             const int j = 2 * (tid + (u >> 1) * nt), jj = j + 1 < n ? j : 0;
+            Pair wq = {1.0, 1.0};
+            if (MODE == 0 && wsym) wq = *reinterpret_cast<const Pair *>(pwN + jj);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = jj + q * n;
                 if (MODE == 0) {
                     Pair fn = *reinterpret_cast<const Pair *>(mpN + i), fs = *reinterpret_cast<const Pair *>(mpS + i);
-                    if (pw) {
+                    if (wsym) {
+                        fn.x *= wq.x; fn.y *= wq.y; fs.x *= wq.x; fs.y *= wq.y;
+                    } else if (pw) {
                         const Pair wn = *reinterpret_cast<const Pair *>(pwN + i), ws = *reinterpret_cast<const Pair *>(pwS + i);
                         fn.x *= wn.x; fn.y *= wn.y; fs.x *= ws.x; fs.y *= ws.y;
                     }
@@ -421,6 +440,11 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const in
         // (the previous round's read-out has to be over before the buffers are filled again)
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
+        HX_FSTAMP(0);
+#if HX_FFT_ABL & 32
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the pixels have landed
+        HX_FSTAMP(1);
+#endif
 #pragma unroll
         for (int u = 0; u < RING_FB; ++u) {
             const int j = 2 * (tid + (u >> 1) * nt) + (u & 1);
@@ -434,13 +458,20 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const in
             buf[MP + lds_slot(j)] = cmul(csub(e0, e1), phase(q1));
         }
         __syncthreads();
+        HX_FSTAMP(2);
         const int half = tid >= nh ? 1 : 0, gt = tid - half * nh;
         double2 *bh = buf + half * MP;
         lds_fft_dif(bh, M, twf, P.twN, gt, nh);
+        HX_FSTAMP(3);
         double2 *out = Y + (long long)c * P.ny + sN + (long long)(rpair + 2 * half) * n;
         for (int k = gt; k < n; k += nh) out[k] = bh[lds_slot(bitrev(k, p))];
+        HX_FSTAMP(4);
         }  // rounds
     }
+#if HX_FFT_ABL & 32
+    if (tid == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_fft_cyc[i], fcyc[i]);
+#endif
 }
 
 // =====================================================================================
@@ -717,10 +748,12 @@ static int plan_tables(hx_plan *pl)
     hipLaunchKernelGGL(k_init_norm0, dim3((2 * (lmax + 1) + 63) / 64), dim3(64), 0, st, lmax, pl->cn0.as<double2>(), pl->al0.as<double>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_bhat), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // 3 KiB of the 160 KiB are the static twiddle tables of k_ring_subdft
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_pairfft<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_pairfft<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_pairfft<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_pairfft<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_pairfft<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_bhat_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft_split<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_subdft_split<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
@@ -918,8 +951,24 @@ static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, cons
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(512 / threads, (160 * 1024) / (lds + 3 * 1024 + 256)));
             const long long items = HX_PAIR_ROUNDS == 2 ? (long long)c.count * nb : ((long long)c.count + 7) / 8 * nb * 16;
             const unsigned groups = (unsigned)std::min<long long>(items, (long long)rt().cus * per_cu);
-            hipLaunchKernelGGL(k_ring_pairfft<MODE>, dim3(groups), dim3(threads), lds, rt().stream,
-                               pl->dev(), pl->fft_rp_list.as<int>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+            if (MODE == 0 && d_pw && pl->pw_mode == 2) {
+                hipLaunchKernelGGL((k_ring_pairfft<MODE, MODE == 0>), dim3(groups), dim3(threads), lds, rt().stream,
+                                   pl->dev(), pl->fft_rp_list.as<int>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+            } else {
+                hipLaunchKernelGGL((k_ring_pairfft<MODE, false>), dim3(groups), dim3(threads), lds, rt().stream,
+                                   pl->dev(), pl->fft_rp_list.as<int>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+            }
+#if HX_FFT_ABL & 32
+            {
+                unsigned long long hc[8], z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                (void)hipStreamSynchronize(rt().stream);
+                (void)hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_fft_cyc), sizeof(hc));
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fft_cyc), z8, sizeof(z8));
+                const double units = (double)c.count * nb;
+                fprintf(stderr, "[hx] pair fft class M %5d rings %5d: shader cycles per (ring pair, component) = two items: issue+barrier %.0f  wait for pixels %.0f  fill %.0f  transforms %.0f  read-out %.0f\n",
+                        c.M, c.count, hc[0] / units, hc[1] / units, hc[2] / units, hc[3] / units, hc[4] / units);
+            }
+#endif
             continue;
         }
         if (c.M > pl->fft_cap || c.big) {  // Bluestein convolution of 2 x cap points in two halves / plain FFT of > 4096 points
@@ -935,8 +984,13 @@ static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, cons
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(512 / threads, (160 * 1024) / (lds + 3 * 1024 + 256)));
         const long long items = ((long long)c.count + 7) / 8 * nb * 32;
         const unsigned groups = (unsigned)std::min<long long>(items, (long long)rt().cus * per_cu);
-        hipLaunchKernelGGL(k_ring_subdft<MODE>, dim3(groups), dim3(threads), lds, rt().stream,
-                           pl->dev(), pl->fft_rp_list.as<int>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+        if (MODE == 0 && d_pw && pl->pw_mode == 2) {
+            hipLaunchKernelGGL((k_ring_subdft<MODE, MODE == 0>), dim3(groups), dim3(threads), lds, rt().stream,
+                               pl->dev(), pl->fft_rp_list.as<int>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+        } else {
+            hipLaunchKernelGGL((k_ring_subdft<MODE, false>), dim3(groups), dim3(threads), lds, rt().stream,
+                               pl->dev(), pl->fft_rp_list.as<int>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+        }
 #if HX_FFT_ABL & 32
         {
             unsigned long long hc[8], z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -953,10 +1007,47 @@ static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, cons
     return HX_OK;
 }
 
+// flag stays != 0 if the weights of every ring pair repeat over its four quadrants and from its northern to its southern ring
+// (bitwise): one read of the array, 0.4 ms at nside 4096 per call, against 8 weight loads per pixel pair in every ring kernel
+__global__ __launch_bounds__(256) void k_pixw_symmetry(PlanDev P, const double *__restrict__ pixw, int *__restrict__ flag)
+{
+    const int rp = blockIdx.x, n = P.nsub[rp];
+    const long long sN = P.startN[rp], sS = P.startS[rp];
+    bool ok = true;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const double w = pixw[sN + j];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) ok = ok && pixw[sN + j + (long long)q * n] == w;
+        if (sS >= 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ok = ok && pixw[sS + j + (long long)q * n] == w;
+        }
+    }
+    if (!ok) *flag = 0;
+}
+
 int launch_ring_subdft_maps(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, double2 *Y)
 {
     ProfScope ps("ring_fft");
+    if (d_pw && pl->pw_checked != d_pw) HX_TRY(classify_pixel_weights(pl, d_pw));  // (entry points that did not do it themselves)
     return launch_subdft_classes<0>(pl, nb, d_maps, d_pw, nullptr, Y);
+}
+
+// Called by the entry points of the C ABI right after they have bound their pixel-weight array, before they queue anything else:
+// the host waits for a 4-byte verdict (pl->pw_mode: 1 generic, 2 symmetric), which holds for this array until the next entry.
+int classify_pixel_weights(hx_plan *pl, const double *d_pw)
+{
+    pl->pw_checked = d_pw;
+    pl->pw_mode = 0;
+    if (!d_pw || pl->nside < 1) return HX_OK;
+    HX_TRY(pl->pw_sym.alloc(sizeof(int)));
+    HX_HIP(hipMemsetAsync(pl->pw_sym.p, 1, sizeof(int), rt().stream));
+    hipLaunchKernelGGL(k_pixw_symmetry, dim3(pl->nrp), dim3(256), 0, rt().stream, pl->dev(), d_pw, pl->pw_sym.as<int>());
+    int flag = 0;
+    HX_HIP(hipMemcpyAsync(&flag, pl->pw_sym.p, sizeof(int), hipMemcpyDeviceToHost, rt().stream));
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    pl->pw_mode = flag != 0 ? 2 : 1;
+    return HX_OK;
 }
 }  // namespace hx
 
@@ -1034,6 +1125,7 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
     if (!piped) HX_TRY(vmaps.bind(maps, sizeof(double) * (size_t)ncomp * pl->npix));
     HX_TRY(vrw.bind(ring_weights, sizeof(double) * pl->nrp));
     HX_TRY(vpw.bind(pix_weights, sizeof(double) * (size_t)pl->npix));
+    HX_TRY(classify_pixel_weights(pl, vpw.as<double>()));
     HX_TRY(vfl.bind(fl, sizeof(double) * (pl->lmax + 1)));
     HX_TRY(valms.bind(alms, sizeof(double2) * (size_t)ncomp * pl->nlm));
     // residual maps of the Jacobi iterations: plan-owned scratch (no per-call hipMalloc)
@@ -1103,6 +1195,7 @@ extern "C" int hx_map2alm_multi(hx_plan *pl, int njobs, const int *spins, const 
     InView vrw, vpw;
     HX_TRY(vrw.bind(ring_weights, sizeof(double) * pl->nrp));
     HX_TRY(vpw.bind(pix_weights, sizeof(double) * (size_t)pl->npix));
+    HX_TRY(classify_pixel_weights(pl, vpw.as<double>()));
     std::vector<InView> vfl(njobs);
     std::vector<OutView> valm(njobs);
     struct Sweep { int job, c0, nb; };

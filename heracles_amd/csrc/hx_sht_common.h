@@ -313,7 +313,9 @@ struct hx_plan {
     struct FftClass { int M, first, count, big; };
     std::vector<FftClass> fft_classes;   // ring pairs grouped by in-LDS FFT length
     hx::DevBuf fft_rp_list;
-    hx::DevBuf Y, F, partial, d_dbg, resid, resid_maps, Fsyn;
+    hx::DevBuf Y, F, partial, d_dbg, resid, resid_maps, Fsyn, pw_sym;
+    const double *pw_checked = nullptr;       // the pixel-weight array of the current call that pw_mode describes
+    int pw_mode = 0;                          // 1: one weight per pixel; 2: the array repeats over the quadrants of every ring and from north to south (healpy's weights)
     static constexpr int NSTAGE = 3;          // (hx_map2alm uses two of them, hx_map2alm_multi all three)
     hx::DevBuf stage[NSTAGE];                 // maps of one sweep each: host input uploaded sweep by sweep
     hipEvent_t stage_up[NSTAGE] = {nullptr, nullptr, nullptr}, stage_done[NSTAGE] = {nullptr, nullptr, nullptr};
@@ -325,6 +327,7 @@ namespace hx {
 hx_plan *plan_create_equiangular(int N, int lmax);
 int ensure_rec2(hx_plan *pl);
 int launch_ring_subdft_maps(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, double2 *Y);
+int classify_pixel_weights(hx_plan *pl, const double *d_pw);
 // hx_analysis.hip
 int build_tasks(hx_plan *pl, int spin);
 int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 *d_alms, const double *d_rw,

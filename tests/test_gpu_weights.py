@@ -8,7 +8,14 @@ import warnings
 import numpy as np
 import pytest
 
+
 pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol):
+    scale = max(np.abs(b).max(), 1e-300)
+    err = np.abs(np.asarray(a) - np.asarray(b)).max()
+    assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
 
 
 @pytest.mark.parametrize("nside", [1, 2, 4, 16, 64, 6])
@@ -67,3 +74,25 @@ def test_mapper_reads_weights_from_datapath(oracle, tmp_path):
     finally:
         hx.HipHealpixMapper.DATAPATH = None
     np.testing.assert_array_equal(alm2, alm)
+
+
+@pytest.mark.parametrize("nside,lmax,spin,ncomp", [(32, 64, 0, 3), (64, 100, 2, 4), (128, 160, 0, 10), (24, 40, 2, 10)])
+def test_symmetric_weights_take_the_short_path_and_agree(oracle, nside, lmax, spin, ncomp):
+    """healpy's full weights repeat over the four quadrants of a ring and from north to south; the ring kernels then read one weight
+    per pixel pair instead of eight (flag set per call by k_pixw_symmetry).  The same transform with an array that is symmetric,
+    and with one whose symmetry a single pixel breaks (generic path), against the oracle."""
+    import heracles_amd as hx
+    from heracles_amd import weights as hw
+
+    rng = np.random.default_rng(5 * nside + spin)
+    comp = 1e-2 * rng.standard_normal(hw.compressed_size(nside))
+    w = np.asarray(hw.expand_pixel_weights(nside, comp))
+    maps = rng.standard_normal((ncomp, 12 * nside**2))
+    plan = hx.get_plan(nside, lmax)
+    close(plan.map2alm(maps, spin, pix_weights=w), oracle.map2alm(maps, nside, lmax, spin=spin, pix_weights=w), 1e-11)
+    w2 = w.copy()
+    w2[12 * nside**2 - 3] *= 1.5  # a southern pixel: only the north -> south comparison sees it
+    close(plan.map2alm(maps, spin, pix_weights=w2), oracle.map2alm(maps, nside, lmax, spin=spin, pix_weights=w2), 1e-11)
+    w3 = w.copy()
+    w3[5] = np.nan  # NaN never compares equal: generic path, and the NaN reaches the output as it would in healpy
+    assert not np.isfinite(plan.map2alm(maps[:1] if spin == 0 else maps[:2], spin, pix_weights=w3)).all()

@@ -9,7 +9,8 @@ nside, lmax = int(os.environ.get("NSIDE", 4096)), int(os.environ.get("LMAX", 614
 plan = hx.Plan(nside, lmax)
 nc = int(os.environ.get("NCOMP", 8))
 m = torch.randn((nc, 12 * nside * nside), dtype=torch.float64, device="cuda")
-pw = torch.ones(12 * nside * nside, dtype=torch.float64, device="cuda") if os.environ.get("PW", "1") == "1" else None  # PW=0: without pixel weights
+pwm = os.environ.get("PW", "1")  # 0: no pixel weights; 1: an array with the symmetry of healpy's weights (short path); 2: random weights (generic path)
+pw = None if pwm == "0" else (torch.ones(12 * nside * nside, dtype=torch.float64, device="cuda") if pwm == "1" else 1.0 + 0.01 * torch.rand(12 * nside * nside, dtype=torch.float64, device="cuda"))
 plan.map2alm(m, 0, pix_weights=pw)
 hx._lib.profile_enable(True); hx._lib.profile_reset()
 plan.map2alm(m, 0, pix_weights=pw)
