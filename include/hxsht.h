@@ -94,7 +94,9 @@ int hx_executed_flops(double *out2, int reset);
 /* maps  : [ncomp][npix] double; spin 2: components come in (Q,U) pairs, ncomp even
  * alms  : [ncomp][nlm] complex; spin 2: (E,B) pairs
  * ring_weights : NULL or [2*nside] quadrature weights of ring pairs (north ring 1..2nside)
- * pix_weights  : NULL or [npix] per-pixel weights (healpy use_pixel_weights=True data)
+ * pix_weights  : NULL or [npix] per-pixel weights (healpy use_pixel_weights=True data).  An array that repeats over the four
+ *                quadrants of every ring and from north to south -- healpy's weights do -- is recognised per call and read
+ *                once per pixel pair instead of eight times; any other array is used as it is
  * fl    : NULL or [lmax+1] filter applied to the output, alm[l,m] *= fl[l]
  *         (pixel-window deconvolution, heracles/healpy.py:172-196)
  * niter : Jacobi refinement iterations (healpy's `iter`)                              */
