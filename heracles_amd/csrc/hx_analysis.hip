@@ -32,12 +32,25 @@
 namespace hx {
 using namespace hxfft;
 
+// HX_HALF_F: spin-2 operand rows of the odd parity are not stored.  With x = B+(P+_N), y = B-(P-_S) (operand of lambda+; lambda-
+// alike) the two rows are x + y and x - y, and x - y is x + y with the four columns of a field reversed and the signs (-, +, +, -)
+// under lambda+, (+, -, -, +) under lambda-.  The Legendre kernel loads the even row a second time at column j ^ 3 (plain loads:
+// anything else in its prologue -- a DPP move, a sign flip -- moves its 256 registers of operands around and costs the stages 140
+// register copies each: 496 instead of 400 ms); the signs go where they are free: the lambda- chains run with alternating
+// sign (-p', +q' in their coefficient table, the seed negated for m = 1), which leaves (-, +, +, -) on the odd-parity rows under
+// BOTH functions, and k_alm_reduce<2> flips those when it changes the layout.  Half the F rows: half of what k_fourier_combine<2>
+// writes and the Legendre prologue fetches from HBM.
+#ifndef HX_HALF_F
+#define HX_HALF_F 1
+#endif
 template <int SPIN>
 struct LegCfg {
     static constexpr int NW = SPIN == 0 ? 16 : 8;   // waves per workgroup
     static constexpr int NT = SPIN == 0 ? 1 : 2;    // 16x64 tiles per wave
     static constexpr int NOP = SPIN == 0 ? 1 : 2;   // A-operand functions per ring
+    static constexpr int NPAR = (SPIN == 2 && HX_HALF_F) ? 1 : 2;  // parity rows of F per (m, ring pair)
 };
+int analysis_f_rows(int spin) { return spin == 0 ? LegCfg<0>::NPAR * LegCfg<0>::NOP : LegCfg<2>::NPAR * LegCfg<2>::NOP; }
 
 struct LegParams {
     PlanDev P;
@@ -81,7 +94,8 @@ __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double
     const int slot = threadIdx.x & 7;
     const bool live = rp < P.nrp;
     const RingAtM ram = ring_at_m[threadIdx.x >> 3];
-    double *row = F + (((long long)blockIdx.x * P.nrp_pad + rp) * 2) * NOP * ncol;
+    constexpr int NPAR = LegCfg<SPIN>::NPAR;
+    double *row = F + (((long long)blockIdx.x * P.nrp_pad + rp) * NPAR) * NOP * ncol;
     for (int g = 0; g < ng; ++g) {
         if (SPIN == 0) {
             const int c = g * 8 + slot;
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double
             }
             const int col = g * NCOL + 4 * (slot >> 1);
             *reinterpret_cast<double4 *>(row + (0 * NOP + op) * ncol + col) = o0;
-            *reinterpret_cast<double4 *>(row + (1 * NOP + op) * ncol + col) = o1;
+            if (NPAR == 2) *reinterpret_cast<double4 *>(row + (1 * NOP + op) * ncol + col) = o1;
         }
     }
 }
@@ -295,13 +309,27 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
             const int rbi = SPIN == 0 ? 2 * (s * NW + w) + (q >> 3) : s * NW + w;
             const bool on = rbi < task.nrb;
             const long long row = (long long)blockIdx.x * P.nrp_pad + (task.rb0 + rbi) * RBLK + pipe_rho(q & 7, ak);
+            if (SPIN == 2 && HX_HALF_F) {
+                // only the even-parity row x + y is stored; the position of the odd parity (p ^ off = 1; off: m = 1 only) loads the SAME
+                // row at column j ^ 3 -- two loads per operand as before, one row of F (signs: see HX_HALF_F)
+                const double *f = A.F + (row * NOP + op) * A.ncol;
 #pragma unroll
-            for (int pos = 0; pos < 2; ++pos) {
-                const double *f = A.F + ((row * 2 + (pos ^ off)) * NOP + op) * A.ncol;
+                for (int pos = 0; pos < 2; ++pos) {
+                    const int cx = (pos ^ off) ? 3 : 0;
 #pragma unroll
-                for (int g = 0; g < NGA; ++g) fr[s][sp][pos][g] = (NG > 0 && on) ? f[g * NCOL + ai] : 0.0;
+                    for (int g = 0; g < NGA; ++g) fr[s][sp][pos][g] = (NG > 0 && on) ? f[g * NCOL + (ai ^ cx)] : 0.0;
 #pragma unroll
-                for (int g = 0; g < NXA; ++g) frx[s][sp][pos][g] = (NBX > 0 && on) ? f[NG * NCOL + 4 * g + (lane & 3)] : 0.0;
+                    for (int g = 0; g < NXA; ++g) frx[s][sp][pos][g] = (NBX > 0 && on) ? f[NG * NCOL + 4 * g + ((lane & 3) ^ cx)] : 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int pos = 0; pos < 2; ++pos) {
+                    const double *f = A.F + ((row * 2 + (pos ^ off)) * NOP + op) * A.ncol;
+#pragma unroll
+                    for (int g = 0; g < NGA; ++g) fr[s][sp][pos][g] = (NG > 0 && on) ? f[g * NCOL + ai] : 0.0;
+#pragma unroll
+                    for (int g = 0; g < NXA; ++g) frx[s][sp][pos][g] = (NBX > 0 && on) ? f[NG * NCOL + 4 * g + (lane & 3)] : 0.0;
+                }
             }
         }
 
@@ -325,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
             } else {
                 SVal sp, sm;
                 spin2_seeds(m, P.sth[rpl[s]], P.omz[rpl[s]], P.kfac2[m], sp, sm);
-                vc[s][0] = (lane >> 5) ? sm.v : sp.v;
+                vc[s][0] = (lane >> 5) ? ((HX_HALF_F && off) ? -sm.v : sm.v) : sp.v;  // (HX_HALF_F: the lambda- chain alternates in sign, + at even l + m)
                 sc[s][0] = (lane >> 5) ? sm.e : sp.e;
             }
         }
@@ -337,7 +365,8 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
         __builtin_amdgcn_s_barrier();
     };
     // coefficient hand-over: thread t < 128 carries double (t & 63) of a block's 32 (p', q') pairs into table t >> 6
-    const double csign = (SPIN == 2 && (tid & 1) && (tid >> 6) == 1) ? -1.0 : 1.0;
+    // table 1 (lambda-): (p', -q'); with HX_HALF_F the chain carries (-1)^(l + m) lambda-, whose recursion has (-p', +q')
+    const double csign = (SPIN == 2 && (tid >> 6) == 1 && ((tid & 1) != 0) != (HX_HALF_F != 0)) ? -1.0 : 1.0;
     if (tid < 128) {
 #pragma unroll
         for (int bb = 0; bb <= NSUB; ++bb)
@@ -774,6 +803,10 @@ __global__ __launch_bounds__(256) void k_alm_reduce(PlanDev P, const LegTask *__
             double2 v = make_double2(0.0, 0.0);
             if (l >= l0 && mt.count > 0) {
                 v = *reinterpret_cast<const double2 *>(partial + (r0 + (l - l0)) * ncol + (c >> 3) * NCOL + 2 * (c & 7));
+                if (SPIN == 2 && HX_HALF_F && ((l + m) & 1)) {  // odd-parity rows carry the signs (-, +, +, -) on (E_re, E_im, B_re, B_im)
+                    if (c & 1) v.y = -v.y;
+                    else v.x = -v.x;
+                }
                 if (fl) { v.x *= fl[l]; v.y *= fl[l]; }
             }
             double2 *dst = alm + (long long)c * alm_stride + almidx(lmax, l, m);
@@ -1097,7 +1130,7 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
                    const double *d_pw, const double *d_fl, int add)
 {
     if (valu_batch(spin, nb)) return analysis_batch_valu(pl, spin, nb, d_maps, d_alms, d_rw, d_pw, d_fl, add);
-    const int sidx = spin ? 1 : 0, nop = spin ? 2 : 1;
+    const int sidx = spin ? 1 : 0;
     HX_TRY(build_tasks(pl, spin));
     if (spin) HX_TRY(ensure_rec2(pl));
     // doubles per F / partial row: only the columns in use are stored -- 4-column granularity on the
@@ -1121,7 +1154,7 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
             budget = std::min(budget, 0.5 * (double)(fr + pl->F.bytes + pl->partial.bytes));
         budget = std::max(budget, 2e9);
     }
-    const double f_per_m = (double)pl->nrp_pad * 2 * nop * ncol * sizeof(double);
+    const double f_per_m = (double)pl->nrp_pad * analysis_f_rows(spin) * ncol * sizeof(double);
     const int lmax = pl->lmax;
     // rows of the partial buffer: one span per m (the pipelined kernel adds its ring groups in place)
     const std::vector<long long> &prow = ts.arow;
