@@ -125,6 +125,24 @@ def test_alm2map_medium_scaled_chains(oracle, nside, lmax, spin):
     close(out, oracle.alm2map(alm, nside, lmax, spin=spin), 1e-11)
 
 
+@pytest.mark.parametrize("nside,lmax", [(16, 24), (64, 100), (128, 200)])
+@pytest.mark.parametrize("spin,ncomp", [(0, 5), (0, 8), (0, 10), (2, 6), (2, 16), (2, 20), (0, 13), (2, 26)])
+def test_alm2map_batches(oracle, nside, lmax, spin, ncomp):
+    """Batches of 5 .. 13 maps / 3 .. 13 fields (sweeps of four maps / two fields that share the recursion, then the rest) against the
+    oracle's direct sums."""
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(11 * nside + ncomp + spin)
+    alm = random_alm(rng, lmax, spin, (ncomp,))
+    out = hx.get_plan(nside, lmax).alm2map(alm, spin)
+    if nside <= 64 or ncomp in (5, 6, 10, 20):
+        close(out, oracle.alm2map(alm, nside, lmax, spin=spin), 1e-11)
+    else:  # (the oracle takes a minute per ten maps at this size: first and last unit)
+        unit = 1 if spin == 0 else 2
+        for c in (0, ncomp - unit):
+            close(out[c : c + unit], oracle.alm2map(alm[c : c + unit], nside, lmax, spin=spin), 1e-11)
+
+
 @pytest.mark.parametrize("spin", [0, 2])
 def test_alm2map_sweeps_of_several_maps_match_single_sweeps(spin):
     """Four spin-0 maps / two spin-2 fields per synthesis sweep share the recursion (other ring slots per lane, other block
