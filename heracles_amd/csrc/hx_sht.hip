@@ -1130,9 +1130,9 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
     HX_TRY(valms.bind(alms, sizeof(double2) * (size_t)ncomp * pl->nlm));
     // residual maps of the Jacobi iterations: plan-owned scratch (no per-call hipMalloc)
     DevBuf &resid = pl->resid_maps;
-    // the sweeps are sized by analysis_next_batch() (the first is the largest); the synthesis of the Jacobi iterations takes the
-    // maps / fields of a sweep one at a time
-    if (niter > 0) HX_TRY(resid.alloc(sizeof(double) * (size_t)analysis_next_batch(spin, ncomp) * pl->npix));
+    // the sweeps are sized by analysis_next_batch(); the synthesis of the Jacobi iterations takes the maps / fields of a sweep in its
+    // own sweeps of four maps / two fields
+    if (niter > 0) HX_TRY(resid.alloc(sizeof(double) * (size_t)analysis_max_batch(spin, ncomp) * pl->npix));
     if (piped) {
         const size_t sweep_bytes = sizeof(double) * (size_t)analysis_next_batch(spin, ncomp, true) * pl->npix;
         for (int i = 0; i < 2; ++i) {

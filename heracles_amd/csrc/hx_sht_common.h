@@ -334,6 +334,7 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
                    const double *d_pw, const double *d_fl, int add);
 int analysis_max_comp(int spin);
 int analysis_next_batch(int spin, int remaining, bool from_host = false);
+int analysis_max_batch(int spin, int ncomp);
 // hx_legendre_valu.hip: one map (spin 0) / one field (spin 2) per sweep on the FP64 vector unit
 int launch_valu_chunk(hx_plan *pl, int spin, hx_plan::TaskSet &ts, int m0, int m1, int c0, const double *d_rw);
 int valu_task_blocks(int spin);      // 32-ring-pair blocks per task

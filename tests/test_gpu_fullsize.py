@@ -274,8 +274,8 @@ def test_nside_8192_against_oracle_on_sampled_m(oracle):
 def test_config5_euclid_job_on_one_gpu(oracle):
     """BASELINE configs[4] in its own shape on ONE GPU: 13 bins x (2 spin-0 + 1 spin-2) at nside 4096 / lmax 6144 = 39 maps / 52
     components / 780 map pairs (sizes: heracles/examples/heracles.cfg:28-62; ~100 GB of maps and alms, 288 GB on the device).
-    Its sweeps -- 26 spin-0 maps = 13 + 13 (two 16-column groups each, the second partly filled), 13 spin-2 fields = 7 + 6 -- are
-    not the bench's: components of different sweeps and column groups against the oracle on every 512th m, spectra of map pairs
+    Its sweeps -- 26 spin-0 maps = 16 + 10 (two full 16-column groups; one group + one 4-column block), 13 spin-2 fields = 8 + 5, the
+    split that costs least -- are not the bench's: components of different sweeps and column groups against the oracle on every 512th m, spectra of map pairs
     against a direct device-side sum, and the L = 6144 mixing matrices against the 3j oracle on a corner."""
     import torch
 
@@ -308,10 +308,10 @@ def test_config5_euclid_job_on_one_gpu(oracle):
             sl = slice(base + m, base + LMAX + 1)
             assert np.abs(got[:, sl] - ref[:, sl]).max() <= 1e-10 * scale, (tag, m)
 
-    # spin 0: map 9 (first sweep, second column group), map 20 (second sweep); spin 2: field 6 (first sweep, second group),
-    # field 12 (second sweep, last field)
+    # spin 0: map 9 (first sweep, second column group), map 25 (second sweep, its 4-column block); spin 2: field 6 (first sweep,
+    # second group), field 12 (second sweep, the field of its 4-column block)
     check(alm0[9:10], maps0[9:10], 0, "spin0 map 9")
-    check(alm0[20:21], maps0[20:21], 0, "spin0 map 20")
+    check(alm0[25:26], maps0[25:26], 0, "spin0 map 25")
     check(alm2[6], maps2[6], 2, "spin2 field 6")
     check(alm2[12], maps2[12], 2, "spin2 field 12")
     del maps0, maps2

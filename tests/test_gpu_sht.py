@@ -303,8 +303,8 @@ def test_one_ring_set_kernel_device_batches(oracle, nside, lmax, ncomp):
     """9 - 10 spin-2 fields that are ALREADY IN HBM go through the Legendre kernel with one ring set per wave in one sweep of
     36 / 40 columns (host arrays are uploaded and transformed as two overlapped sweeps of the two-set kernel instead, which is
     what the other tests of this file exercise): against the oracle, with odd and even numbers of l-blocks, tasks of fewer
-    than 4 ring blocks, 22 components = one sweep of 6 + one of 5 fields, and -- at nside 256 -- cut into m-chunks without
-    changing a bit."""
+    than 4 ring blocks, 22 components = one 40-column sweep + one field on the vector-unit kernel (the split that costs least), and
+    -- at nside 256 -- cut into m-chunks without changing a bit."""
     import torch
     import heracles_amd as hx
 
@@ -318,7 +318,8 @@ def test_one_ring_set_kernel_device_batches(oracle, nside, lmax, ncomp):
         hx._lib.set_scratch_budget(2.5e7)
         try:
             again = plan.map2alm(dev, 2)
-            assert plan.last_chunks >= 3, plan.last_chunks
+            if ncomp != 22:  # (the last sweep of 22 components is the single field: it needs less scratch)
+                assert plan.last_chunks >= 3, plan.last_chunks
         finally:
             hx._lib.set_scratch_budget(0)
         np.testing.assert_array_equal(again.cpu().numpy() if hasattr(again, "cpu") else np.asarray(again), got)
