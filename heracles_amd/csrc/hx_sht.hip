@@ -1186,12 +1186,17 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
 // of the upload is a small transform.  Callers put their large jobs first.  niter = 0 only (iterations need their maps resident).
 // (At the bench size -- 32 GB of spin-2 and 16 GB of spin-0 maps at 55 GB/s -- the sweeps are 5 + 5 fields and 8 + 2 maps: their
 // transforms, 240 + 240 + 100 + 50 ms, ride under the 880 ms of uploads except the last.)
-extern "C" int hx_map2alm_multi(hx_plan *pl, int njobs, const int *spins, const int *ncomps, const double *const *maps, double *const *alms,
-                                const double *ring_weights, const double *pix_weights, const double *const *fls)
+// comp_maps (hx_map2alm_list): job j's components are SEPARATE arrays comp_maps[j][c] (maps[j] = the first of them); they are
+// gathered into the staging buffer of their sweep -- host arrays through the pinned pipeline, device arrays by copies on the
+// upload stream; neighbours in memory go as one transfer.
+static int map2alm_multi_impl(hx_plan *pl, int njobs, const int *spins, const int *ncomps, const double *const *maps, const double *const *const *comp_maps,
+                              double *const *alms, const double *ring_weights, const double *pix_weights, const double *const *fls)
 {
     HX_TRY(ensure_ready());
     if (!pl || njobs < 1 || !spins || !ncomps || !maps || !alms) return fail(HX_ERR_ARG, "hx_map2alm_multi: bad arguments");
     for (int j = 0; j < njobs; ++j) HX_TRY(check_sht_args(pl, spins[j], ncomps[j], maps[j], alms[j]));
+    // a job goes through the staging buffers if its maps are on the host, or scattered over separate arrays
+    auto staged = [&](int j) { return !is_device_ptr(maps[j]) || (comp_maps && comp_maps[j]); };
     InView vrw, vpw;
     HX_TRY(vrw.bind(ring_weights, sizeof(double) * pl->nrp));
     HX_TRY(vpw.bind(pix_weights, sizeof(double) * (size_t)pl->npix));
@@ -1204,7 +1209,7 @@ extern "C" int hx_map2alm_multi(hx_plan *pl, int njobs, const int *spins, const 
     for (int j = 0; j < njobs; ++j) {
         HX_TRY(vfl[j].bind(fls ? fls[j] : nullptr, sizeof(double) * (pl->lmax + 1)));
         HX_TRY(valm[j].bind(alms[j], sizeof(double2) * (size_t)ncomps[j] * pl->nlm));
-        const bool host = !is_device_ptr(maps[j]);
+        const bool host = staged(j);
         any_host = any_host || host;
         const int unit = spins[j] ? 2 : 1, cap = spins[j] ? 10 : 8;  // 5 spin-2 fields / 8 spin-0 maps: one full column group each
         for (int c0 = 0; c0 < ncomps[j];) {
@@ -1216,7 +1221,7 @@ extern "C" int hx_map2alm_multi(hx_plan *pl, int njobs, const int *spins, const 
             c0 += nb;
         }
     }
-    if (any_host && !is_device_ptr(maps[sweeps.back().job])) {
+    if (any_host && staged(sweeps.back().job)) {
         for (;;) {  // halve the last sweep until it holds at most two units
             Sweep &l = sweeps.back();
             const int unit = spins[l.job] ? 2 : 1, units = l.nb / unit;
@@ -1231,7 +1236,7 @@ extern "C" int hx_map2alm_multi(hx_plan *pl, int njobs, const int *spins, const 
     constexpr int NST = hx_plan::NSTAGE;
     size_t stage_bytes = 0;
     for (const Sweep &w : sweeps)
-        if (!is_device_ptr(maps[w.job])) stage_bytes = std::max(stage_bytes, (size_t)(sizeof(double) * (size_t)w.nb * (size_t)pl->npix));
+        if (staged(w.job)) stage_bytes = std::max(stage_bytes, (size_t)(sizeof(double) * (size_t)w.nb * (size_t)pl->npix));
     if (any_host) {
         if (!cs) return fail(HX_ERR_HIP, "hx_map2alm_multi: no copy stream");
         for (int i = 0; i < NST; ++i) {
@@ -1246,12 +1251,25 @@ extern "C" int hx_map2alm_multi(hx_plan *pl, int njobs, const int *spins, const 
     std::vector<int> hidx(sweeps.size(), -1);
     int nh = 0;
     for (size_t k = 0; k < sweeps.size(); ++k)
-        if (!is_device_ptr(maps[sweeps[k].job])) hidx[k] = nh++;
+        if (staged(sweeps[k].job)) hidx[k] = nh++;
     auto upload = [&](size_t k) -> int {
         const Sweep &w = sweeps[k];
         const int b = hidx[k] % NST;
         if (hidx[k] >= NST) HX_HIP(hipEventSynchronize(pl->stage_done[b]));  // host sweep h - NST has read this buffer
-        HX_TRY(copy_h2d(pl->stage[b].p, maps[w.job] + (size_t)w.c0 * pl->npix, sizeof(double) * (size_t)w.nb * pl->npix, cs));
+        if (comp_maps && comp_maps[w.job]) {
+            const double *const *cm = comp_maps[w.job] + w.c0;
+            for (int c = 0; c < w.nb;) {  // runs of components that lie behind one another in memory: one transfer each
+                int e = c + 1;
+                while (e < w.nb && cm[e] == cm[e - 1] + pl->npix) ++e;
+                char *dst = (char *)pl->stage[b].p + sizeof(double) * (size_t)c * pl->npix;
+                const size_t bytes = sizeof(double) * (size_t)(e - c) * pl->npix;
+                if (is_device_ptr(cm[c])) HX_HIP(hipMemcpyAsync(dst, cm[c], bytes, hipMemcpyDeviceToDevice, cs));
+                else HX_TRY(copy_h2d(dst, cm[c], bytes, cs));
+                c = e;
+            }
+        } else {
+            HX_TRY(copy_h2d(pl->stage[b].p, maps[w.job] + (size_t)w.c0 * pl->npix, sizeof(double) * (size_t)w.nb * pl->npix, cs));
+        }
         HX_HIP(hipEventRecord(pl->stage_up[b], cs));
         return HX_OK;
     };
@@ -1294,6 +1312,59 @@ extern "C" int hx_map2alm_multi(hx_plan *pl, int njobs, const int *spins, const 
     if (trace) fprintf(stderr, "[hx] multi: everything queued at %.0f ms\n", now_ms());
     HX_HIP(hipStreamSynchronize(rt().stream));  // staging buffers of host arguments are released on return
     if (trace) fprintf(stderr, "[hx] multi: done at %.0f ms\n", now_ms());
+    return HX_OK;
+}
+
+extern "C" int hx_map2alm_multi(hx_plan *pl, int njobs, const int *spins, const int *ncomps, const double *const *maps, double *const *alms,
+                                const double *ring_weights, const double *pix_weights, const double *const *fls)
+{
+    return map2alm_multi_impl(pl, njobs, spins, ncomps, maps, nullptr, alms, ring_weights, pix_weights, fls);
+}
+
+// The loop of heracles/mapping.py:151-172 as ONE call over the arrays the reference holds: one array per map -- [npix] for spin 0,
+// [2][npix] (Q, U) for spin 2 -- and one output array per map ([nlm] / [2][nlm] complex).  The maps are gathered sweep by sweep
+// into the staging buffers of hx_map2alm_multi (no stacked copy on the host: np.stack of the bench's 48 GB costs several seconds),
+// spin-2 fields first; the alms are collected in HBM and handed out at the end.
+extern "C" int hx_map2alm_list(hx_plan *pl, int nmaps, const int *spins, const double *const *maps, double *const *alms,
+                               const double *ring_weights, const double *pix_weights, const double *fl0, const double *fl2)
+{
+    HX_TRY(ensure_ready());
+    if (!pl || nmaps < 1 || !spins || !maps || !alms) return fail(HX_ERR_ARG, "hx_map2alm_list: bad arguments");
+    std::vector<const double *> comps[2];  // [0]: spin 2, [1]: spin 0 (large jobs first)
+    std::vector<int> owner[2];
+    for (int i = 0; i < nmaps; ++i) {
+        if (spins[i] != 0 && spins[i] != 2) return fail(HX_ERR_UNSUPPORTED, "spin-%d maps not yet supported", spins[i]);
+        if (!maps[i] || !alms[i]) return fail(HX_ERR_ARG, "hx_map2alm_list: null map or alm %d", i);
+        const int g = spins[i] ? 0 : 1;
+        comps[g].push_back(maps[i]);
+        if (spins[i]) comps[g].push_back(maps[i] + pl->npix);
+        owner[g].push_back(i);
+    }
+    int jspin[2], jn[2], nj = 0;
+    const double *jmaps[2], *jfl[2];
+    const double *const *jcomp[2];
+    double *jalm[2];
+    DevBuf out[2];
+    for (int g = 0; g < 2; ++g) {
+        if (comps[g].empty()) continue;
+        HX_TRY(out[g].alloc(sizeof(double2) * comps[g].size() * (size_t)pl->nlm));
+        jspin[nj] = g == 0 ? 2 : 0; jn[nj] = (int)comps[g].size(); jmaps[nj] = comps[g][0]; jcomp[nj] = comps[g].data();
+        jalm[nj] = out[g].as<double>(); jfl[nj] = g == 0 ? fl2 : fl0;
+        ++nj;
+    }
+    HX_TRY(map2alm_multi_impl(pl, nj, jspin, jn, jmaps, jcomp, jalm, ring_weights, pix_weights, jfl));
+    // (the call above has synchronised) alms out: host arrays through the pinned pipeline, device arrays by device copies
+    for (int g = 0; g < 2; ++g) {
+        const int cpu = g == 0 ? 2 : 1;
+        for (size_t u = 0; u < owner[g].size(); ++u) {
+            const size_t bytes = sizeof(double2) * (size_t)cpu * pl->nlm;
+            const char *src = (const char *)out[g].p + u * bytes;
+            double *dst = alms[owner[g][u]];
+            if (is_device_ptr(dst)) HX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, rt().stream));
+            else HX_TRY(copy_d2h(dst, src, bytes));
+        }
+    }
+    HX_HIP(hipStreamSynchronize(rt().stream));
     return HX_OK;
 }
 

@@ -275,17 +275,31 @@ class HipHealpixMapper:
         return alm
 
     def transform_many(self, maps, spins):
-        """Batched transform of a list of maps (the loop of heracles/mapping.py:151-172 as
-        one call): spin-0 maps are stacked 8 to a launch, spin-2 maps 4 to a launch."""
+        """Batched transform of a list of maps (the loop of heracles/mapping.py:151-172 as one call).  Without iterations the
+        arrays go to ``hx_map2alm_list`` as they are -- no stacked copy on the host, one upload pipeline across spins --; with
+        ``niter > 0`` (the maps have to stay resident) the maps of a spin are stacked and transformed as one batch."""
+        for sp in spins:
+            if sp not in (0, 2):
+                raise NotImplementedError(f"spin-{sp} maps not yet supported")
+        plan = sht.get_plan(self.__nside, self.__lmax)
+        self._load_weights()
         out = [None] * len(maps)
+        if self.niter == 0:
+            want = [(12 * self.__nside**2,) if sp == 0 else (2, 12 * self.__nside**2) for sp in spins]
+            native = [np.ascontiguousarray(_native(m), dtype=np.float64).reshape(w) for m, w in zip(maps, want)]
+            alms = plan.map2alm_list(native, spins, ring_weights=self.ring_weights, pix_weights=self.pixel_weights,
+                                     fl0=self._fl(0), fl2=self._fl(2))
+            for i, a in enumerate(alms):
+                a = np.array(a) if not isinstance(a, np.ndarray) else a
+                update_metadata(a, **{**(maps[i].dtype.metadata or {}), "deconv": self.__deconv})
+                out[i] = a
+            return out
         for s in (0, 2):
             idx = [i for i, sp in enumerate(spins) if sp == s]
             if not idx:
                 continue
             stack = np.stack([np.ascontiguousarray(_native(maps[i]), dtype=np.float64) for i in idx])
             fl = self._fl(s)
-            plan = sht.get_plan(self.__nside, self.__lmax)
-            self._load_weights()
             alms = plan.map2alm(stack.reshape(-1, stack.shape[-1]), s, ring_weights=self.ring_weights,
                                 pix_weights=self.pixel_weights, fl=fl, niter=self.niter)
             alms = alms.reshape(*stack.shape[:-1], -1)
@@ -293,9 +307,6 @@ class HipHealpixMapper:
                 a = np.array(alms[k])
                 update_metadata(a, **{**(maps[i].dtype.metadata or {}), "deconv": self.__deconv})
                 out[i] = a
-        for i, sp in enumerate(spins):
-            if sp not in (0, 2):
-                raise NotImplementedError(f"spin-{sp} maps not yet supported")
         return out
 
     def resample(self, data):

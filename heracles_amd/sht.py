@@ -138,6 +138,37 @@ class Plan:
         _lib.check(_lib.load().hx_map2alm_multi(self._h, n, spins, ncomps, pm, pa, _lib.ptr(rw), _lib.ptr(pw), pf))
         return outs
 
+    def map2alm_list(self, maps, spins, *, outs=None, ring_weights=None, pix_weights=None, fl0=None, fl2=None):
+        """The transform loop of ``heracles.transform`` (heracles/mapping.py:151-172) as one call over SEPARATE arrays: ``maps[i]``
+        is ``(npix,)`` for spin 0 or ``(2, npix)`` (Q, U) for spin 2, numpy or device; returns one alm array per map (``(nlm,)`` /
+        ``(2, nlm)``).  The maps are gathered into the upload pipeline sweep by sweep (no stacked host copy), spin-2 fields first."""
+        import ctypes as C
+
+        n = len(maps)
+        keep, res = [], []
+        sp = (C.c_int * n)()
+        pm, pa = (C.c_void_p * n)(), (C.c_void_p * n)()
+        for i, (m, s) in enumerate(zip(maps, spins)):
+            m = self._prep(m, np.float64)
+            want = (self.npix,) if int(s) == 0 else (2, self.npix)
+            if int(s) not in (0, 2):
+                raise NotImplementedError(f"spin-{s} maps not yet supported")
+            if tuple(m.shape) != want:
+                raise ValueError(f"map {i} of spin {s} has shape {tuple(m.shape)}, expected {want}")
+            out = outs[i] if outs is not None else self._out_like(m, want[:-1] + (self.nlm,), True)
+            keep.append(m)
+            res.append(out)
+            sp[i] = int(s)
+            pm[i], pa[i] = _lib.ptr(m), _lib.ptr(out)
+        rw = self._prep(ring_weights, np.float64)
+        pw = self._prep(pix_weights, np.float64)
+        f0, f2 = self._prep(fl0, np.float64), self._prep(fl2, np.float64)
+        for f in (f0, f2):
+            if f is not None and f.shape[-1] != self.lmax + 1:
+                raise ValueError("fl must have lmax+1 entries")
+        _lib.check(_lib.load().hx_map2alm_list(self._h, n, sp, pm, pa, _lib.ptr(rw), _lib.ptr(pw), _lib.ptr(f0), _lib.ptr(f2)))
+        return res
+
     def alm2map(self, alms, spin=0, *, out=None):
         alms = self._prep(alms, np.complex128)
         lead = tuple(alms.shape[:-1])
