@@ -88,7 +88,7 @@ def load():
         L.hx_map2alm.argtypes = [vp, i, i, dp, dp, dp, dp, dp, i]
         L.hx_alm2map.argtypes = [vp, i, i, dp, dp]
         L.hx_map2alm_multi.argtypes = [vp, i, vp, vp, vp, vp, dp, dp, vp]
-        L.hx_map2alm_list.argtypes = [vp, i, vp, vp, vp, dp, dp, dp, dp]
+        L.hx_map2alm_list.argtypes = [vp, i, vp, vp, vp, dp, dp, dp, dp, i]
         L.hx_alm2cl_pairs.argtypes = [i, vp, vp, i, i, vp, vp, dp]
         L.hx_alm2cl_pairs_range.argtypes = [i, vp, vp, i, i, vp, vp, i, i, i, dp]
         L.hx_gauss_legendre.argtypes = [i, dp, dp]

@@ -1324,12 +1324,13 @@ extern "C" int hx_map2alm_multi(hx_plan *pl, int njobs, const int *spins, const 
 // The loop of heracles/mapping.py:151-172 as ONE call over the arrays the reference holds: one array per map -- [npix] for spin 0,
 // [2][npix] (Q, U) for spin 2 -- and one output array per map ([nlm] / [2][nlm] complex).  The maps are gathered sweep by sweep
 // into the staging buffers of hx_map2alm_multi (no stacked copy on the host: np.stack of the bench's 48 GB costs several seconds),
-// spin-2 fields first; the alms are collected in HBM and handed out at the end.
+// spin-2 fields first; the alms are collected in HBM and handed out at the end.  niter > 0 (Jacobi iterations need their maps
+// resident): the maps of a spin are gathered into one device array first, then transformed as a batch.
 extern "C" int hx_map2alm_list(hx_plan *pl, int nmaps, const int *spins, const double *const *maps, double *const *alms,
-                               const double *ring_weights, const double *pix_weights, const double *fl0, const double *fl2)
+                               const double *ring_weights, const double *pix_weights, const double *fl0, const double *fl2, int niter)
 {
     HX_TRY(ensure_ready());
-    if (!pl || nmaps < 1 || !spins || !maps || !alms) return fail(HX_ERR_ARG, "hx_map2alm_list: bad arguments");
+    if (!pl || nmaps < 1 || !spins || !maps || !alms || niter < 0) return fail(HX_ERR_ARG, "hx_map2alm_list: bad arguments");
     std::vector<const double *> comps[2];  // [0]: spin 2, [1]: spin 0 (large jobs first)
     std::vector<int> owner[2];
     for (int i = 0; i < nmaps; ++i) {
@@ -1352,7 +1353,28 @@ extern "C" int hx_map2alm_list(hx_plan *pl, int nmaps, const int *spins, const d
         jalm[nj] = out[g].as<double>(); jfl[nj] = g == 0 ? fl2 : fl0;
         ++nj;
     }
-    HX_TRY(map2alm_multi_impl(pl, nj, jspin, jn, jmaps, jcomp, jalm, ring_weights, pix_weights, jfl));
+    if (niter == 0) {
+        HX_TRY(map2alm_multi_impl(pl, nj, jspin, jn, jmaps, jcomp, jalm, ring_weights, pix_weights, jfl));
+    } else {
+        InView vrw, vpw;  // (bound once: a host weight array is not uploaded per spin)
+        HX_TRY(vrw.bind(ring_weights, sizeof(double) * pl->nrp));
+        HX_TRY(vpw.bind(pix_weights, sizeof(double) * (size_t)pl->npix));
+        for (int j = 0; j < nj; ++j) {
+            DevBuf in;
+            HX_TRY(in.alloc(sizeof(double) * (size_t)jn[j] * pl->npix));
+            for (int c = 0; c < jn[j];) {
+                int e = c + 1;
+                while (e < jn[j] && jcomp[j][e] == jcomp[j][e - 1] + pl->npix) ++e;
+                char *dst = (char *)in.p + sizeof(double) * (size_t)c * pl->npix;
+                const size_t bytes = sizeof(double) * (size_t)(e - c) * pl->npix;
+                if (is_device_ptr(jcomp[j][c])) HX_HIP(hipMemcpyAsync(dst, jcomp[j][c], bytes, hipMemcpyDeviceToDevice, rt().stream));
+                else HX_TRY(copy_h2d(dst, jcomp[j][c], bytes));
+                c = e;
+            }
+            HX_TRY(hx_map2alm(pl, jspin[j], jn[j], in.as<double>(), jalm[j], vrw.as<double>(), vpw.as<double>(), jfl[j], niter));
+            HX_HIP(hipStreamSynchronize(rt().stream));  // `in` is released here
+        }
+    }
     // (the call above has synchronised) alms out: host arrays through the pinned pipeline, device arrays by device copies
     for (int g = 0; g < 2; ++g) {
         const int cpu = g == 0 ? 2 : 1;

@@ -275,38 +275,23 @@ class HipHealpixMapper:
         return alm
 
     def transform_many(self, maps, spins):
-        """Batched transform of a list of maps (the loop of heracles/mapping.py:151-172 as one call).  Without iterations the
-        arrays go to ``hx_map2alm_list`` as they are -- no stacked copy on the host, one upload pipeline across spins --; with
-        ``niter > 0`` (the maps have to stay resident) the maps of a spin are stacked and transformed as one batch."""
+        """Batched transform of a list of maps (the loop of heracles/mapping.py:151-172 as one call): the arrays go to
+        ``hx_map2alm_list`` as they are -- no stacked copy on the host, one upload pipeline across spins (``niter = 0``) or one
+        resident batch per spin (``niter > 0``)."""
         for sp in spins:
             if sp not in (0, 2):
                 raise NotImplementedError(f"spin-{sp} maps not yet supported")
         plan = sht.get_plan(self.__nside, self.__lmax)
         self._load_weights()
-        out = [None] * len(maps)
-        if self.niter == 0:
-            want = [(12 * self.__nside**2,) if sp == 0 else (2, 12 * self.__nside**2) for sp in spins]
-            native = [np.ascontiguousarray(_native(m), dtype=np.float64).reshape(w) for m, w in zip(maps, want)]
-            alms = plan.map2alm_list(native, spins, ring_weights=self.ring_weights, pix_weights=self.pixel_weights,
-                                     fl0=self._fl(0), fl2=self._fl(2))
-            for i, a in enumerate(alms):
-                a = np.array(a) if not isinstance(a, np.ndarray) else a
-                update_metadata(a, **{**(maps[i].dtype.metadata or {}), "deconv": self.__deconv})
-                out[i] = a
-            return out
-        for s in (0, 2):
-            idx = [i for i, sp in enumerate(spins) if sp == s]
-            if not idx:
-                continue
-            stack = np.stack([np.ascontiguousarray(_native(maps[i]), dtype=np.float64) for i in idx])
-            fl = self._fl(s)
-            alms = plan.map2alm(stack.reshape(-1, stack.shape[-1]), s, ring_weights=self.ring_weights,
-                                pix_weights=self.pixel_weights, fl=fl, niter=self.niter)
-            alms = alms.reshape(*stack.shape[:-1], -1)
-            for k, i in enumerate(idx):
-                a = np.array(alms[k])
-                update_metadata(a, **{**(maps[i].dtype.metadata or {}), "deconv": self.__deconv})
-                out[i] = a
+        npix = 12 * self.__nside**2
+        native = [np.ascontiguousarray(_native(m), dtype=np.float64).reshape((npix,) if sp == 0 else (2, npix)) for m, sp in zip(maps, spins)]
+        alms = plan.map2alm_list(native, spins, ring_weights=self.ring_weights, pix_weights=self.pixel_weights,
+                                 fl0=self._fl(0), fl2=self._fl(2), niter=self.niter)
+        out = []
+        for m, a in zip(maps, alms):
+            a = a if isinstance(a, np.ndarray) else np.array(a)
+            update_metadata(a, **{**(m.dtype.metadata or {}), "deconv": self.__deconv})
+            out.append(a)
         return out
 
     def resample(self, data):

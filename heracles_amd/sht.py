@@ -138,10 +138,11 @@ class Plan:
         _lib.check(_lib.load().hx_map2alm_multi(self._h, n, spins, ncomps, pm, pa, _lib.ptr(rw), _lib.ptr(pw), pf))
         return outs
 
-    def map2alm_list(self, maps, spins, *, outs=None, ring_weights=None, pix_weights=None, fl0=None, fl2=None):
+    def map2alm_list(self, maps, spins, *, outs=None, ring_weights=None, pix_weights=None, fl0=None, fl2=None, niter=0):
         """The transform loop of ``heracles.transform`` (heracles/mapping.py:151-172) as one call over SEPARATE arrays: ``maps[i]``
         is ``(npix,)`` for spin 0 or ``(2, npix)`` (Q, U) for spin 2, numpy or device; returns one alm array per map (``(nlm,)`` /
-        ``(2, nlm)``).  The maps are gathered into the upload pipeline sweep by sweep (no stacked host copy), spin-2 fields first."""
+        ``(2, nlm)``).  The maps are gathered into the upload pipeline sweep by sweep (no stacked host copy), spin-2 fields first;
+        with ``niter > 0`` the maps of a spin are gathered into one device array and iterated as a batch."""
         import ctypes as C
 
         n = len(maps)
@@ -166,7 +167,7 @@ class Plan:
         for f in (f0, f2):
             if f is not None and f.shape[-1] != self.lmax + 1:
                 raise ValueError("fl must have lmax+1 entries")
-        _lib.check(_lib.load().hx_map2alm_list(self._h, n, sp, pm, pa, _lib.ptr(rw), _lib.ptr(pw), _lib.ptr(f0), _lib.ptr(f2)))
+        _lib.check(_lib.load().hx_map2alm_list(self._h, n, sp, pm, pa, _lib.ptr(rw), _lib.ptr(pw), _lib.ptr(f0), _lib.ptr(f2), int(niter)))
         return res
 
     def alm2map(self, alms, spin=0, *, out=None):

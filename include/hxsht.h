@@ -113,9 +113,10 @@ int hx_map2alm_multi(hx_plan *plan, int njobs, const int *spins, const int *ncom
 /* The same for SEPARATE arrays, as heracles holds them (heracles/mapping.py:151-172: one array per (field, bin)): map i is
  * maps[i] -- [npix] for spin 0, [2][npix] (Q, U) for spin 2 --, its alm goes to alms[i] ([nlm] / [2][nlm] complex); host or
  * device pointers.  The maps are gathered sweep by sweep into the upload pipeline of hx_map2alm_multi (no stacked host copy),
- * spin-2 fields first; fl0 / fl2: NULL or the [lmax+1] filter of the spin-0 / spin-2 maps.  niter = 0. */
+ * spin-2 fields first; fl0 / fl2: NULL or the [lmax+1] filter of the spin-0 / spin-2 maps.  niter > 0: the maps of a spin are
+ * gathered into one device array first (iterations need them resident) and transformed as a batch. */
 int hx_map2alm_list(hx_plan *plan, int nmaps, const int *spins, const double *const *maps, double *const *alms,
-                    const double *ring_weights, const double *pix_weights, const double *fl0, const double *fl2);
+                    const double *ring_weights, const double *pix_weights, const double *fl0, const double *fl2, int niter);
 
 /* ---- the two halves of hx_map2alm, for the m-sharded multi-GPU route (heracles/mapping.py:151-172 and
  * heracles/twopoint.py:198-215 are the loops it shards) -------------------------------------------------------------------

@@ -471,3 +471,9 @@ def test_map2alm_list_of_separate_arrays(oracle, device):
             k += 1
     with pytest.raises(ValueError):
         plan.map2alm_list([maps[0]], [2])
+    # with Jacobi iterations: the maps of a spin are gathered into one device array and iterated as a batch
+    it = plan.map2alm_list(args[:6], spins[:6], niter=2)
+    for i in (0, 1, 5):
+        got = it[i].cpu().numpy() if hasattr(it[i], "cpu") else np.asarray(it[i])
+        ref = oracle.map2alm(maps[i].reshape(-1, npix), nside, lmax, spin=spins[i], niter=2)
+        close(got.reshape(ref.shape), ref, 1e-10)
