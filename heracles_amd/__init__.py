@@ -11,6 +11,7 @@ from .core import DeviceArray, Result, TocDict, toc_match, update_metadata
 from .discrete import HipDiscreteMapper, PointSHT, alm_resample, get_point_sht
 from .jackknife import RegionAlms, jackknife_cls, region_alms
 from .mapper import HipHealpixMapper
+from .mapping import transform
 from .sht import Plan, get_plan
 from .transforms import cl2corr, corr2cl, gauss_legendre, wigner_d_table
 from .twopoint import (
@@ -30,5 +31,5 @@ __all__ = [
     "alm2cl", "alm2cl_pairs", "alm2lmax", "angular_power_spectra", "debias_cls",
     "mixing_matrices", "mixmat", "mixmat_eb", "cl2corr", "corr2cl", "gauss_legendre",
     "wigner_d_table", "naturalspice", "Result", "TocDict", "toc_match", "update_metadata", "DeviceArray",
-    "jackknife_cls", "region_alms", "RegionAlms",
+    "jackknife_cls", "region_alms", "RegionAlms", "transform",
 ]

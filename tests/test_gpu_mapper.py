@@ -101,6 +101,15 @@ def test_maps_to_cls_end_to_end(oracle):
         np.testing.assert_allclose(a, ref, atol=1e-11 * np.abs(ref).max())
         single = mapper.transform(maps[k], spin=a.dtype.metadata["spin"])
         np.testing.assert_array_equal(np.asarray(single), np.asarray(a))
+    # heracles.transform's interface over the same maps (heracles_amd.transform: one batched call per mapper)
+    from types import SimpleNamespace
+
+    fields = {"POS": SimpleNamespace(spin=0, mapper_or_error=mapper), "SHE": SimpleNamespace(spin=2, mapper_or_error=mapper)}
+    again = hx.transform(fields, maps)
+    assert list(again) == list(maps)
+    for k in maps:
+        np.testing.assert_array_equal(np.asarray(again[k]), np.asarray(alms[k]))
+        assert again[k].dtype.metadata["spin"] == alms[k].dtype.metadata["spin"]
     cls = hx.angular_power_spectra(alms)
     assert len(cls) == 10
     for (k1, k2, i1, i2), res in cls.items():

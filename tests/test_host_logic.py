@@ -287,3 +287,43 @@ def test_discrete_mapper_surface():
     if hx.device_count() == 0:  # no device: the HIP path fails loudly, nothing is computed on the host
         with pytest.raises(hx.HxError):
             mapper.map_values(np.zeros(3), np.zeros(3), mapper.create(), np.zeros(3))
+
+
+def test_transform_driver_mirrors_heracles_transform():
+    """heracles.transform (heracles/mapping.py:113-175) restated around a batched mapper call: keys in the order of the data, the
+    spin rule (a map without spin metadata takes its field's, a mismatch is a ValueError), the unknown-field error, maps wrapped in
+    objects with ``.array``, ``out=`` filled in place, one ``transform_many`` call per mapper and the per-map fallback."""
+    from types import SimpleNamespace
+
+    from heracles_amd import TocDict, transform, update_metadata
+
+    calls = []
+
+    class Batched:
+        def transform_many(self, maps, spins):
+            calls.append(("many", list(spins)))
+            return [np.full(3, 10.0 * s + float(np.asarray(m).ravel()[0])) for m, s in zip(maps, spins)]
+
+    class PerMap:
+        def transform(self, m, spin=0):
+            calls.append(("one", spin))
+            return np.full(2, -1.0 - spin)
+
+    a, b = Batched(), PerMap()
+    fields = {"POS": SimpleNamespace(spin=0, mapper_or_error=a), "SHE": SimpleNamespace(spin=2, mapper_or_error=a),
+              "VIS": SimpleNamespace(spin=0, mapper=b, mapper_or_error=None)}
+    m0, m1, m2, m3 = np.zeros(4) + 1, np.zeros((2, 4)) + 2, np.zeros(4) + 3, np.zeros(4) + 4
+    update_metadata(m1, spin=2)
+    data = {("SHE", 1): m1, ("POS", 0): m0, ("VIS", 0): SimpleNamespace(array=m3), ("POS", 1): m2}
+    out = TocDict()
+    res = transform(fields, data, out=out)
+    assert res is out and list(out) == list(data)
+    assert m0.dtype.metadata["spin"] == 0 and m3.dtype.metadata["spin"] == 0
+    assert calls == [("many", [2, 0, 0]), ("one", 0)]
+    assert out["SHE", 1][0] == 22.0 and out["POS", 0][0] == 1.0 and out["POS", 1][0] == 3.0 and out["VIS", 0][0] == -1.0
+    with pytest.raises(ValueError, match="unknown field name: NOPE"):
+        transform(fields, {("NOPE", 0): m0})
+    bad = np.zeros(4)
+    update_metadata(bad, spin=2)
+    with pytest.raises(ValueError, match="spin mismatch for field 'POS': map has spin 2, field has spin 0"):
+        transform(fields, {("POS", 0): bad})
