@@ -904,22 +904,16 @@ int analysis_max_comp(int spin) { return (spin == 2 && oneset_enabled()) ? 8 * N
 // dead stages whatever it holds, so 13 spin-2 fields are 8 + 5 (two full shapes: 316 + 224) rather than 7 + 6 (two padded
 // 32-column sweeps: 632), 26 spin-0 maps 16 + 10 rather than 13 + 13, ten fields one 40-column sweep, and one or two left-over
 // maps / fields go to the vector-unit kernel.  Ties take the larger sweep first.
-// from_host: the maps are uploaded sweep by sweep while the previous sweep is transformed (hx_map2alm): as few equal sweeps of at
-// most 16 components as possible, so that ten spin-2 fields from host memory are two overlapped sweeps of five rather than one sweep
-// behind its whole upload.
 static double sweep_cost(int spin, int units)
 {
     if (spin == 0) return units <= 4 ? 21.6 * units : (units <= 8 ? 100.0 : (units <= 10 ? 115.0 : 162.0));
     return units <= 2 ? 61.0 * units : (units <= 4 ? 196.0 : (units == 5 ? 224.0 : (units <= 8 ? 316.0 : (units == 9 ? 360.0 : 400.0))));
 }
-int analysis_next_batch(int spin, int remaining, bool from_host)
+int analysis_next_batch(int spin, int remaining)
 {
-    const int unit = spin == 0 ? 1 : 2, maxu = (from_host ? 8 * NGMAX : analysis_max_comp(spin)) / unit;
+    const int unit = spin == 0 ? 1 : 2, maxu = analysis_max_comp(spin) / unit;
     const int units = remaining / unit;
-    if (from_host || units <= 0) {
-        const int nsweep = (units + maxu - 1) / maxu;
-        return unit * (nsweep ? (units + nsweep - 1) / nsweep : 0);
-    }
+    if (units <= 0) return 0;
     std::vector<double> best(units + 1, 0.0);
     std::vector<int> first(units + 1, 0);
     for (int r = 1; r <= units; ++r) {
@@ -936,7 +930,7 @@ int analysis_max_batch(int spin, int ncomp)
 {
     int mx = 0;
     for (int left = ncomp; left > 0;) {
-        const int nb = analysis_next_batch(spin, left, false);
+        const int nb = analysis_next_batch(spin, left);
         if (nb <= 0) break;
         mx = std::max(mx, nb);
         left -= nb;

@@ -1111,6 +1111,9 @@ static int apply_fl(hx_plan *pl, int nb, double2 *alm, const double *fl)
     return HX_OK;
 }
 
+static int map2alm_multi_impl(hx_plan *pl, int njobs, const int *spins, const int *ncomps, const double *const *maps, const double *const *const *comp_maps,
+                              double *const *alms, const double *ring_weights, const double *pix_weights, const double *const *fls);
+
 extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, double *alms,
                           const double *ring_weights, const double *pix_weights, const double *fl, int niter)
 {
@@ -1119,10 +1122,11 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
     if (niter < 0) return fail(HX_ERR_ARG, "niter < 0");
     InView vmaps, vrw, vpw, vfl;
     OutView valms;
-    // Host maps of a call that takes several sweeps are uploaded sweep by sweep on a second stream, into two buffers of
-    // the plan: the host thread stages sweep k + 1 (pageable -> pinned -> HBM) while the GPU transforms sweep k.
-    const bool piped = niter == 0 && !is_device_ptr(maps) && analysis_next_batch(spin, ncomp, true) < ncomp && copy_stream() != nullptr;
-    if (!piped) HX_TRY(vmaps.bind(maps, sizeof(double) * (size_t)ncomp * pl->npix));
+    // Host maps without iterations go through the upload pipeline of hx_map2alm_multi (one job): sweep k + 1 is staged (pageable ->
+    // pinned -> HBM, second stream, three plan-owned buffers) while the GPU transforms sweep k
+    if (niter == 0 && !is_device_ptr(maps) && copy_stream() != nullptr)
+        return map2alm_multi_impl(pl, 1, &spin, &ncomp, &maps, nullptr, &alms, ring_weights, pix_weights, &fl);
+    HX_TRY(vmaps.bind(maps, sizeof(double) * (size_t)ncomp * pl->npix));
     HX_TRY(vrw.bind(ring_weights, sizeof(double) * pl->nrp));
     HX_TRY(vpw.bind(pix_weights, sizeof(double) * (size_t)pl->npix));
     HX_TRY(classify_pixel_weights(pl, vpw.as<double>()));
@@ -1133,31 +1137,7 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
     // the sweeps are sized by analysis_next_batch(); the synthesis of the Jacobi iterations takes the maps / fields of a sweep in its
     // own sweeps of four maps / two fields
     if (niter > 0) HX_TRY(resid.alloc(sizeof(double) * (size_t)analysis_max_batch(spin, ncomp) * pl->npix));
-    if (piped) {
-        const size_t sweep_bytes = sizeof(double) * (size_t)analysis_next_batch(spin, ncomp, true) * pl->npix;
-        for (int i = 0; i < 2; ++i) {
-            HX_TRY(pl->stage[i].alloc(sweep_bytes));
-            if (!pl->stage_up[i]) HX_HIP(hipEventCreateWithFlags(&pl->stage_up[i], hipEventDisableTiming));
-            if (!pl->stage_done[i]) HX_HIP(hipEventCreateWithFlags(&pl->stage_done[i], hipEventDisableTiming));
-        }
-        auto upload = [&](int k, int c0, int nb) -> int {
-            const int b = k & 1;
-            if (k >= 2) HX_HIP(hipEventSynchronize(pl->stage_done[b]));  // sweep k - 2 has read this buffer
-            HX_TRY(copy_h2d(pl->stage[b].p, maps + (size_t)c0 * pl->npix, sizeof(double) * (size_t)nb * pl->npix, copy_stream()));
-            HX_HIP(hipEventRecord(pl->stage_up[b], copy_stream()));
-            return HX_OK;
-        };
-        HX_TRY(upload(0, 0, analysis_next_batch(spin, ncomp, true)));
-        for (int c0 = 0, nb = 0, k = 0; c0 < ncomp; c0 += nb, ++k) {
-            nb = analysis_next_batch(spin, ncomp - c0, true);
-            HX_HIP(hipStreamWaitEvent(rt().stream, pl->stage_up[k & 1], 0));
-            HX_TRY(analysis_batch(pl, spin, nb, pl->stage[k & 1].as<double>(), valms.as<double2>() + (size_t)c0 * pl->nlm,
-                                  vrw.as<double>(), vpw.as<double>(), vfl.as<double>(), 0));
-            HX_HIP(hipEventRecord(pl->stage_done[k & 1], rt().stream));
-            if (c0 + nb < ncomp) HX_TRY(upload(k + 1, c0 + nb, analysis_next_batch(spin, ncomp - c0 - nb, true)));
-        }
-    }
-    for (int c0 = 0, nb = 0; !piped && c0 < ncomp; c0 += nb) {
+    for (int c0 = 0, nb = 0; c0 < ncomp; c0 += nb) {
         nb = analysis_next_batch(spin, ncomp - c0);
         const double *dm = vmaps.as<double>() + (size_t)c0 * pl->npix;
         double2 *da = valms.as<double2>() + (size_t)c0 * pl->nlm;
@@ -1171,7 +1151,7 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
     }
     HX_TRY(valms.finish());
     // staging buffers of host arguments are released on return: only an all-device call may stay asynchronous
-    if (piped || vmaps.tmp.p || vrw.tmp.p || vpw.tmp.p || vfl.tmp.p || valms.tmp.p) {
+    if (vmaps.tmp.p || vrw.tmp.p || vpw.tmp.p || vfl.tmp.p || valms.tmp.p) {
         HX_HIP(hipStreamSynchronize(rt().stream));
         return HX_OK;
     }

@@ -316,7 +316,7 @@ struct hx_plan {
     hx::DevBuf Y, F, partial, d_dbg, resid, resid_maps, Fsyn, pw_sym;
     const double *pw_checked = nullptr;       // the pixel-weight array of the current call that pw_mode describes
     int pw_mode = 0;                          // 1: one weight per pixel; 2: the array repeats over the quadrants of every ring and from north to south (healpy's weights)
-    static constexpr int NSTAGE = 3;          // (hx_map2alm uses two of them, hx_map2alm_multi all three)
+    static constexpr int NSTAGE = 3;          // staging buffers of the upload pipeline (hx_map2alm_multi / _list; hx_map2alm of host maps is one job of it)
     hx::DevBuf stage[NSTAGE];                 // maps of one sweep each: host input uploaded sweep by sweep
     hipEvent_t stage_up[NSTAGE] = {nullptr, nullptr, nullptr}, stage_done[NSTAGE] = {nullptr, nullptr, nullptr};
     hx::PlanDev dev() const;
@@ -333,7 +333,7 @@ int build_tasks(hx_plan *pl, int spin);
 int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 *d_alms, const double *d_rw,
                    const double *d_pw, const double *d_fl, int add);
 int analysis_max_comp(int spin);
-int analysis_next_batch(int spin, int remaining, bool from_host = false);
+int analysis_next_batch(int spin, int remaining);
 int analysis_max_batch(int spin, int ncomp);
 // hx_legendre_valu.hip: one map (spin 0) / one field (spin 2) per sweep on the FP64 vector unit
 int launch_valu_chunk(hx_plan *pl, int spin, hx_plan::TaskSet &ts, int m0, int m1, int c0, const double *d_rw);

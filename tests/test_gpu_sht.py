@@ -264,7 +264,7 @@ def test_long_l_ranges_small_batches(oracle):
 @pytest.mark.parametrize("spin,ncomp", [(0, 10), (2, 20), (0, 16), (2, 8), (0, 3), (2, 2)])
 def test_map2alm_m_chunked_batches_medium(oracle, spin, ncomp):
     """The sweep shapes bench.py times -- 10 spin-0 maps in one sweep (one 16-column group + one 4-column block),
-    20 spin-2 components as two sweeps of 5 fields, full two-group sweeps -- at a size where the sweep is cut into
+    20 spin-2 components in one 40-column sweep, full two-group sweeps -- at a size where the sweep is cut into
     several m-chunks (scratch budget lowered through hx_set_scratch_budget) and polar pruning is active
     (nside 256: rings beyond m > lmax sin(theta) + 100 are skipped), against the oracle on every 16th m."""
     import heracles_amd as hx
@@ -272,18 +272,23 @@ def test_map2alm_m_chunked_batches_medium(oracle, spin, ncomp):
     rng = np.random.default_rng(400 + 10 * spin + ncomp)
     nside, lmax = 256, 511
     maps = rng.standard_normal((ncomp, 12 * nside**2))
+    import torch
+
     plan = hx.get_plan(nside, lmax)
-    whole = plan.map2alm(maps, spin)
+    dev = torch.as_tensor(maps).cuda()  # (resident maps, as in the bench: host maps are cut into the upload pipeline's sweeps)
+    whole = plan.map2alm(dev, spin).cpu().numpy()
     nchunk_default = plan.last_chunks
     # (<= 4 components go through one vector-unit sweep per map / field, whose operands and rows are a fraction of a 16-column sweep's)
     hx._lib.set_scratch_budget(2.5e6 * min(ncomp, 10) if ncomp > 4 else 2.0e6)
     try:
-        out = plan.map2alm(maps, spin)
+        out = plan.map2alm(dev, spin).cpu().numpy()
         assert plan.last_chunks >= 3, plan.last_chunks
     finally:
         hx._lib.set_scratch_budget(0)
     assert nchunk_default == 1
     np.testing.assert_array_equal(out, whole)  # the chunking does not change a bit
+    host = plan.map2alm(maps, spin)  # the same from host arrays: other sweeps, same alms to rounding
+    assert np.abs(host - out).max() <= 1e-12 * np.abs(out).max()
     stride = 16
     oracle.set_mstride(stride)
     try:
