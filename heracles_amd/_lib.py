@@ -26,7 +26,7 @@ SYMBOLS = (
     "hx_version", "hx_last_error", "hx_device_count", "hx_init", "hx_set_stream",
     "hx_get_stream", "hx_set_async", "hx_synchronize", "hx_timer_start", "hx_timer_stop",
     "hx_profile_enable", "hx_profile_reset", "hx_profile_get", "hx_plan_create", "hx_set_max_lds_fft",
-    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_set_scratch_budget", "hx_plan_last_chunks", "hx_plan_mfma_flops", "hx_plan_executed_flops", "hx_executed_flops", "hx_measure_peaks", "hx_measured_mfma_clock", "hx_map2alm", "hx_map2alm_multi", "hx_map2alm_list", "hx_alm2map",
+    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_set_scratch_budget", "hx_plan_last_chunks", "hx_plan_mfma_flops", "hx_plan_executed_flops", "hx_executed_flops", "hx_measure_peaks", "hx_measured_mfma_clock", "hx_map2alm", "hx_map2alm_multi", "hx_map2alm_list", "hx_alm2map", "hx_copy",
     "hx_alm2cl_pairs", "hx_alm2cl_pairs_range", "hx_gauss_legendre", "hx_wigner_d_table", "hx_mixmat",
     "hx_mixmat_eb", "hx_mixmat_batch", "hx_mixctx_create", "hx_mixctx_apply", "hx_mixctx_destroy", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_alm_resample", "hx_region_maps", "hx_alm_subtract", "hx_fits_unpack_f64", "hx_fits_pack_f64",
     "hx_pointsht_create", "hx_pointsht_destroy", "hx_pointsht_info", "hx_pointsht_adjoint",
@@ -89,6 +89,7 @@ def load():
         L.hx_alm2map.argtypes = [vp, i, i, dp, dp]
         L.hx_map2alm_multi.argtypes = [vp, i, vp, vp, vp, vp, dp, dp, vp]
         L.hx_map2alm_list.argtypes = [vp, i, vp, vp, vp, dp, dp, dp, dp, i]
+        L.hx_copy.argtypes = [vp, vp, C.c_int64]
         L.hx_alm2cl_pairs.argtypes = [i, vp, vp, i, i, vp, vp, dp]
         L.hx_alm2cl_pairs_range.argtypes = [i, vp, vp, i, i, vp, vp, i, i, i, dp]
         L.hx_gauss_legendre.argtypes = [i, dp, dp]
@@ -193,6 +194,15 @@ def measure_peaks():
 
 def synchronize():
     check(load().hx_synchronize())
+
+
+def copy(dst, src):
+    """dst <- src (arrays or tensors of equal byte size, host or device) through the library's staging pipeline."""
+    nb = int(src.nbytes) if hasattr(src, "nbytes") else int(src.numel() * src.element_size())
+    nd = int(dst.nbytes) if hasattr(dst, "nbytes") else int(dst.numel() * dst.element_size())
+    if nb != nd:
+        raise ValueError(f"copy of {nb} bytes into {nd}")
+    check(load().hx_copy(ptr(dst), ptr(src), nb))
 
 
 def executed_flops(reset=False):

@@ -479,6 +479,28 @@ int hx_set_stream(void *stream)
     return HX_OK;
 }
 
+// dst <- src: either side host or device memory.  Host <-> device goes through the pinned staging pipeline (~55 GB/s from / to
+// pageable memory, several host threads), which the runtime's own hipMemcpy of pageable memory does not (14 GB/s).  Complete on return.
+int hx_copy(void *dst, const void *src, int64_t bytes)
+{
+    HX_TRY(ensure_ready());
+    if (bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(HX_ERR_ARG, "hx_copy: bad arguments");
+    if (bytes == 0) return HX_OK;
+    const bool dd = is_device_ptr(dst), sd = is_device_ptr(src);
+    if (dd && sd) {
+        HX_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, rt().stream));
+    } else if (dd) {
+        HX_TRY(copy_h2d(dst, src, (size_t)bytes));
+    } else if (sd) {
+        return copy_d2h(dst, src, (size_t)bytes);
+    } else {
+        memcpy(dst, src, (size_t)bytes);
+        return HX_OK;
+    }
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    return HX_OK;
+}
+
 void *hx_get_stream(void)
 {
     if (ensure_ready() != HX_OK) return nullptr;

@@ -46,6 +46,9 @@ int hx_set_stream(void *stream);  /* use a caller-owned hipStream_t (NULL = own 
 void *hx_get_stream(void);
 int hx_set_async(int on);         /* 1: do not synchronise before returning (device ptrs) */
 int hx_synchronize(void);
+/* dst <- src (bytes), either side host or device memory; host <-> device through the library's pinned staging pipeline (~55 GB/s
+ * from / to pageable memory).  Complete on return. */
+int hx_copy(void *dst, const void *src, int64_t bytes);
 
 /* HIP-event timers on the library stream (bench.py's timed region / roofline). */
 int hx_timer_start(void);

@@ -390,3 +390,23 @@ def test_device_resident_catalogue_to_alm(oracle):
     assert np.abs(np.asarray(halm) - ref).max() <= 1e-11 * np.abs(ref).max()
     with pytest.raises(ValueError, match="spin-2 maps"):
         mapper.transform(dmaps[0], spin=2)
+
+
+def test_hx_copy_between_host_and_device():
+    """hx_copy: host -> device -> device -> host through the library's staging pipeline, sizes below and above its chunk."""
+    import torch
+
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(1)
+    for n in (1000, 5_000_000):
+        src = rng.standard_normal(n)
+        d1 = torch.empty(n, dtype=torch.float64, device="cuda")
+        d2 = torch.empty(n, dtype=torch.float64, device="cuda")
+        back = np.empty(n)
+        hx._lib.copy(d1, src)
+        hx._lib.copy(d2, d1)
+        hx._lib.copy(back, d2)
+        np.testing.assert_array_equal(back, src)
+    with pytest.raises(ValueError):
+        hx._lib.copy(np.empty(3), np.empty(4))
