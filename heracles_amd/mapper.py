@@ -15,7 +15,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import sht
-from .core import update_metadata
+from .core import DeviceArray, update_metadata
 
 
 def pixel_window(nside, lmax, pixwin=None):
@@ -274,23 +274,34 @@ class HipHealpixMapper:
         update_metadata(alm, **{**md, "deconv": self.__deconv})
         return alm
 
-    def transform_many(self, maps, spins):
+    def transform_many(self, maps, spins, *, device=None):
         """Batched transform of a list of maps (the loop of heracles/mapping.py:151-172 as one call): the arrays go to
         ``hx_map2alm_list`` as they are -- no stacked copy on the host, one upload pipeline across spins (``niter = 0``) or one
-        resident batch per spin (``niter > 0``)."""
+        resident batch per spin (``niter > 0``).  ``device="cuda"``: the alms stay in HBM and come back as ``DeviceArray``s (what
+        ``angular_power_spectra`` takes without another PCIe round trip); default: numpy arrays, as the reference returns."""
         for sp in spins:
             if sp not in (0, 2):
                 raise NotImplementedError(f"spin-{sp} maps not yet supported")
         plan = sht.get_plan(self.__nside, self.__lmax)
         self._load_weights()
-        npix = 12 * self.__nside**2
-        native = [np.ascontiguousarray(_native(m), dtype=np.float64).reshape((npix,) if sp == 0 else (2, npix)) for m, sp in zip(maps, spins)]
-        alms = plan.map2alm_list(native, spins, ring_weights=self.ring_weights, pix_weights=self.pixel_weights,
+        npix, nlm = 12 * self.__nside**2, (self.__lmax + 1) * (self.__lmax + 2) // 2
+        native = [m if hasattr(m, "data_ptr") else np.ascontiguousarray(_native(m), dtype=np.float64) for m in maps]
+        native = [m.reshape((npix,) if sp == 0 else (2, npix)) for m, sp in zip(native, spins)]
+        outs = None
+        if device is not None:
+            import torch
+
+            outs = [torch.empty((nlm,) if sp == 0 else (2, nlm), dtype=torch.complex128, device=device) for sp in spins]
+        alms = plan.map2alm_list(native, spins, outs=outs, ring_weights=self.ring_weights, pix_weights=self.pixel_weights,
                                  fl0=self._fl(0), fl2=self._fl(2), niter=self.niter)
         out = []
-        for m, a in zip(maps, alms):
+        for m, a, sp in zip(maps, alms, spins):
+            md = {**((m.dtype.metadata or {}) if isinstance(m, np.ndarray) else {"spin": sp}), "deconv": self.__deconv}
+            if device is not None:
+                out.append(DeviceArray(a, md))
+                continue
             a = a if isinstance(a, np.ndarray) else np.array(a)
-            update_metadata(a, **{**(m.dtype.metadata or {}), "deconv": self.__deconv})
+            update_metadata(a, **md)
             out.append(a)
         return out
 

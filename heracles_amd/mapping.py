@@ -16,9 +16,10 @@ def _mapper_of(field):
     return m if m is not None else field.mapper
 
 
-def transform(fields, data, *, out=None, progress=None):
+def transform(fields, data, *, out=None, progress=None, device=None):
     """Alms of the maps in ``data`` for the ``fields`` they belong to; ``out`` (any mutable mapping) receives ``out[k, i]`` in the
-    order of ``data``."""
+    order of ``data``.  ``device="cuda"`` (not in the reference): the alms stay in HBM as ``DeviceArray``s, which
+    ``angular_power_spectra`` takes as they are."""
     if out is None:
         out = TocDict()
     items = []
@@ -48,7 +49,8 @@ def transform(fields, data, *, out=None, progress=None):
     for group in groups.values():
         mapper = group[0][3]
         if hasattr(mapper, "transform_many"):
-            res = mapper.transform_many([it[1] for it in group], [it[2] for it in group])
+            kw = {} if device is None else {"device": device}
+            res = mapper.transform_many([it[1] for it in group], [it[2] for it in group], **kw)
         else:
             res = [mapper.transform(it[1], spin=it[2]) for it in group]
         for it, a in zip(group, res):

@@ -110,8 +110,15 @@ def test_maps_to_cls_end_to_end(oracle):
     for k in maps:
         np.testing.assert_array_equal(np.asarray(again[k]), np.asarray(alms[k]))
         assert again[k].dtype.metadata["spin"] == alms[k].dtype.metadata["spin"]
+    # ... with the alms kept in HBM (DeviceArrays): the same spectra without a PCIe round trip of the alms
+    resident = hx.transform(fields, maps, device="cuda")
+    assert all(isinstance(v, hx.DeviceArray) for v in resident.values())
+    cls_res = hx.angular_power_spectra(resident)
     cls = hx.angular_power_spectra(alms)
-    assert len(cls) == 10
+    assert len(cls) == 10 and list(cls_res) == list(cls)
+    for k in cls:
+        np.testing.assert_array_equal(np.asarray(cls_res[k].array), np.asarray(cls[k].array))
+        assert cls_res[k].array.dtype.metadata == cls[k].array.dtype.metadata
     for (k1, k2, i1, i2), res in cls.items():
         ref = oracle.alm2cl(np.asarray(alms[k1, i1]), np.asarray(alms[k2, i2]))
         md = res.array.dtype.metadata
