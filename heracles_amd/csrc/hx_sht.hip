@@ -920,7 +920,7 @@ extern "C" void hx_plan_destroy(hx_plan *plan)
 extern "C" int64_t hx_plan_scratch_bytes(const hx_plan *pl)
 {
     if (!pl) return 0;
-    return (int64_t)(pl->stage[0].bytes + pl->stage[1].bytes + pl->Y.bytes + pl->F.bytes + pl->partial.bytes + pl->rec0.bytes + pl->rec2.bytes + pl->cn0.bytes + pl->al0.bytes + pl->cn2.bytes + pl->al2.bytes +
+    return (int64_t)(pl->stage[0].bytes + pl->stage[1].bytes + pl->stage[2].bytes + pl->resid_maps.bytes + pl->Y.bytes + pl->F.bytes + pl->partial.bytes + pl->rec0.bytes + pl->rec2.bytes + pl->cn0.bytes + pl->al0.bytes + pl->cn2.bytes + pl->al2.bytes +
                      pl->bhat.bytes + pl->resid.bytes + pl->Fsyn.bytes);
 }
 
