@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "hx_sht_common.h"
 
@@ -779,6 +780,359 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
 }
 
 // =====================================================================================
+// Legendre analysis, TWO independent work-groups per CU ("duo", round 4)
+// =====================================================================================
+// k_legendre_pipe keeps ONE work-group per CU: whatever one of its waves cannot overlap inside its own instruction stream -- the
+// flush (D tiles through LDS, two barriers, atomics), waits on operands -- is idle time of that SIMD's FP64 pipe (busy 0.51-0.58 by
+// counters).  Here a work-group is 4 waves of <= 256 registers with <= 80 KiB of LDS, so that TWO of them share a CU, each wave
+// beside a wave of the OTHER group on its SIMD.  The two groups work on different orders m and never synchronise with each other.
+// What the second wave can and cannot hide was measured first (tools/ubench_duo.hip, profiles/r04_ubench_duo.txt): a wave that streams
+// FP64 matrix instructions back to back STARVES the FP64 vector instructions of the other wave of its SIMD completely (not one FMA
+// gets through, whatever s_setprio says), so recursion and matrix work of the two waves can only alternate; LDS traffic, barrier
+// waits and memory latency of one wave do sit under the other's matrix block.  The recipe is therefore: as much matrix work per
+// recursion step and per flush as the registers allow, and nothing but matrix instructions + LDS reads inside a matrix block.
+//   per 32-l block:  recursion of the wave's ring set (32 steps, values into its 16 KiB tile)  ->  16 slot pairs of matrix
+//   instructions out of that tile  ->  flush: D tiles of the 4 waves through their own tiles (consumed by then), fixed order,
+//   added in place into the rows of this m (as k_legendre_pipe: one work-group per m, ring groups in order).
+// One ring set per wave (spin 0: 64 ring pairs, both parity chains in a lane; spin 2: 32 ring pairs x the two functions): a task
+// is 8 / 4 ring blocks.
+// HALFB (spin 2, HX_HALF_F): the operand of the odd-parity position is the operand of the even one with the four columns of every
+// field reversed (see HX_HALF_F) -- a quad_perm:[3,2,1,0] of the lanes.  Only ONE of the two is kept in registers; the other is made
+// by two v_mov_b32_dpp in the shadow of the matrix instruction before it.  40 columns (ten fields) then need 128 operand registers
+// instead of 256 and fit a 256-register wave.
+#ifndef HX_DUO_ABL
+#define HX_DUO_ABL 0  // timing experiments only: 1 no matrix instructions, 2 no recursion, 4 no flush, 8 plain stores instead of atomics, 32 cycle accounting
+#endif
+// the four columns of every field reversed across the lanes (quad-perm [3,2,1,0]) through the LDS crossbar: two ds_swizzle_b32, which
+// ride in the shadow of a matrix instruction like any other LDS traffic.  (As two v_mov_b32_dpp the same permutation costs ~12
+// cycles of matrix-pipe time per VALU instruction: 417 instead of 357 cycles per slot pair of 40 columns, tools/ubench_mblock.hip.)
+__device__ __forceinline__ double quad_rev(double v)
+{
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x801B);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x801B);
+    return __hiloint2double(hi, lo);
+}
+
+// lane K of every row of 16 lanes broadcast to its row: the only DPP control the FP64 ALU takes (one v_mov_b64_dpp)
+template <int K>
+__device__ __forceinline__ double row_bcast(double v)
+{
+    double d;
+    asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v), "n"(K));
+    return d;
+}
+
+template <int SPIN, int NG, int NBX>
+__global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const double2 *__restrict__ coefn)
+{
+    using C = PipeCfg<SPIN>;
+    constexpr int NW = 4, NOP = C::NOP, NCH = C::NCH, NPAIR = 16;
+    constexpr int NXA = NBX > 0 ? NBX : 1;
+    constexpr int DQ0 = NG * 512, DSZ = NG * 512 + NBX * 128;
+    constexpr bool HALFB = SPIN == 2;
+    constexpr int NPB = HALFB ? 1 : 2;  // operand positions kept in registers
+    static_assert(NG >= 1 && NG <= 2 && DSZ <= 2048, "the D tiles of a wave fit its tile");
+    static_assert(SPIN == 0 || HX_HALF_F, "spin 2: the lambda- chain carries (-1)^(l + m) lambda- (one operand row, wave-uniform coefficients)");
+    __shared__ double tile[NW][2048];          // 64 KiB; doubles as the D staging area of the flush
+#if HX_DUO_ABL & 64  // diagnostic: ONE work-group per CU (the phase durations of a wave that is alone on its SIMD)
+    __shared__ double lds_hog[3072];
+    if (A.ncol < 0) lds_hog[threadIdx.x] = 1.0;
+    if (A.ncol < -1) A.partial[1] = lds_hog[threadIdx.x ^ 1];
+#endif
+    const PlanDev &P = A.P;
+    const int m = A.m0 + blockIdx.x * A.ms, lmax = P.lmax;
+    const MTasks mt = A.of_m[m];
+    const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
+    const int off = (l0 + m) & 1;
+    const int nblk = (lmax - l0) / LBLK + 1;
+    const long long orow = A.arow[m] - A.arow0;
+    // recursion coefficients (p', q') of this m: WAVE-UNIFORM (spin 2: the lambda- chain, upper half of the wave, runs with (-p', +q'), i.e.
+    // with the same coefficients and -x: HX_HALF_F).  Lane j of every 16-lane row loads the pair of step j (one 16-byte load per 16 steps
+    // and wave, requested a block ahead) and a step takes its pair from there with two row broadcasts (v_mov_b64_dpp row_newbcast) -- no
+    // LDS hand-over, no LDS read per step (32 of the 48 LDS instructions of a block's recursion: 1760 -> cycles per block for a lone
+    // wave), no scalar load (their latency cannot be covered: out-of-order return allows no load in flight across a wait: 5000 cycles)
+    const double2 *__restrict__ cfm = coefn + almidx(lmax, 0, m) + l0 + (SPIN == 0 ? 0 : 1) + (threadIdx.x & 15);
+    auto put = [](double *p, double v) __attribute__((always_inline)) {
+#if HX_DUO_ABL & 8
+        *p = v;
+#else
+        __builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)p, v);
+#endif
+    };
+    auto lds_barrier = []() __attribute__((always_inline)) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): global atomics in flight do not hold the barrier
+        __builtin_amdgcn_s_barrier();
+    };
+    int n_mf = 0, n_rec = 0;
+#if HX_DUO_ABL & 32
+    // cycle accounting (diagnostic build): [0] task prologue, [1] recursion (live / mixed), [2] recursion (dead), [3] matrix block, [4] staging + wait at the
+    // first barrier, [5] reduction, [6] wait at the second barrier
+    unsigned long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#define DUO_STAMP(i) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); cyc[i] += tn_ - tlast; tlast = tn_; } while (0)
+#else
+#define DUO_STAMP(i) do { } while (0)
+#endif
+    for (int ti = 0; ti < mt.count; ++ti) {
+        const LegTask task = A.tasks[mt.first + ti];
+        int tid = threadIdx.x;
+        asm volatile("; ring group" : "+v"(tid));
+        const int w = tid >> 6, lane = tid & 63;
+        const int ai = lane & 15, ak = lane >> 4;
+        if (ti) __syncthreads();  // the previous ring group's last readers of the tiles
+
+        // ring of this lane: wave w holds ring block w (spin 2) / blocks 2 w, 2 w + 1 (spin 0) of the task
+        const int rbi = SPIN == 0 ? 2 * w + (lane >> 5) : w;
+        const int rpl = (task.rb0 + rbi) * RBLK + (lane & 31);
+        const bool valid = rbi < task.nrb && rpl < P.nrp;
+        const double x = valid ? P.z[rpl] : 0.0;
+        const double xx = SPIN == 0 ? x * x : ((lane >> 5) ? -x : x);
+
+        // B operands: lane (k = lane >> 4, j = lane & 15) holds F[ring k of the slot][parity of the position][op][column]
+        // (HALFB: position 0 only -- position 1 is its quad-reversed image)
+        double fr[NPAIR][NPB][NG], frx[NPAIR][NPB][NXA];
+#pragma unroll
+        for (int sp = 0; sp < NPAIR; ++sp) {
+            const int op = SPIN == 0 ? 0 : sp & 1, q = SPIN == 0 ? sp : sp >> 1;
+            const int rbq = SPIN == 0 ? 2 * w + (q >> 3) : w;
+            const bool on = rbq < task.nrb;
+            const long long row = (long long)blockIdx.x * P.nrp_pad + (task.rb0 + rbq) * RBLK + pipe_rho(q & 7, ak);
+            if (HALFB) {
+                const double *f = A.F + (row * NOP + op) * A.ncol;
+                const int cx = off ? 3 : 0;  // position 0 has parity off
+#pragma unroll
+                for (int g = 0; g < NG; ++g) fr[sp][0][g] = on ? f[g * NCOL + (ai ^ cx)] : 0.0;
+#pragma unroll
+                for (int g = 0; g < NXA; ++g) frx[sp][0][g] = (NBX > 0 && on) ? f[NG * NCOL + 4 * g + ((lane & 3) ^ cx)] : 0.0;
+            } else {
+#pragma unroll
+                for (int pos = 0; pos < NPB; ++pos) {
+                    const double *f = A.F + ((row * 2 + (pos ^ off)) * NOP + op) * A.ncol;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) fr[sp][pos][g] = on ? f[g * NCOL + ai] : 0.0;
+#pragma unroll
+                    for (int g = 0; g < NXA; ++g) frx[sp][pos][g] = (NBX > 0 && on) ? f[NG * NCOL + 4 * g + (lane & 3)] : 0.0;
+                }
+            }
+        }
+
+        // seeds
+        double vc[NCH], vp[NCH];
+        int sc[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { vc[c] = 0.0; vp[c] = 0.0; sc[c] = -100; }
+        if (valid) {
+            if (SPIN == 0) {
+                SVal a = spow(P.sth[rpl], m);
+                a.v *= P.mfac[m];
+                SVal b = a;
+                b.v *= sqrt(2.0 * m + 3.0) * P.z[rpl];
+                snorm_small(a);
+                snorm_small(b);
+                vc[0] = a.v; sc[0] = a.e;
+                vc[NCH - 1] = b.v; sc[NCH - 1] = b.e;
+            } else {
+                SVal sp, sm;
+                spin2_seeds(m, P.sth[rpl], P.omz[rpl], P.kfac2[m], sp, sm);
+                vc[0] = (lane >> 5) ? (off ? -sm.v : sm.v) : sp.v;  // the lambda- chain alternates in sign, + at even l + m
+                sc[0] = (lane >> 5) ? sm.e : sp.e;
+            }
+        }
+
+        auto rec_step = [&](auto RMM, int c, int step, const double2 cc) __attribute__((always_inline)) {
+            constexpr int RM = decltype(RMM)::value;
+            if (RM != 3 && (step & 3) == 0) {
+                const int hc = __double2hiint(vc[c]), hp = __double2hiint(vp[c]);
+                const bool up = sc[c] < 0 && (hc & 0x7ff00000) >= 0x3ff00000;
+                const int sub = up ? (300 << 20) : 0;
+                const bool pz = up && (hp & 0x7ff00000) <= (300 << 20);
+                vc[c] = __hiloint2double(hc - sub, __double2loint(vc[c]));
+                vp[c] = pz ? 0.0 : __hiloint2double(hp - sub, __double2loint(vp[c]));
+                sc[c] += up ? 1 : 0;
+            }
+            const double cur = (RM == 3 || sc[c] == 0) ? vc[c] : 0.0;
+            const double vn = fma(fma(cc.x, xx, cc.y), vc[c], -vp[c]);
+            vp[c] = vc[c];
+            vc[c] = vn;
+            return cur;
+        };
+        constexpr int HB = 8;
+        double *tw = &tile[w][0];
+        // the 32 steps of a block; cl[i] = this lane's coefficient pair of steps 16 i + (lane & 15)
+        auto recursion = [&](auto RMM, const double2 (&cl)[2]) __attribute__((always_inline)) {
+            constexpr int RM = decltype(RMM)::value;
+#pragma unroll
+            for (int h = 0; h < LBLK / HB; ++h) {
+                double cur[HB];
+#pragma unroll
+                for (int k = 0; k < HB; ++k) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int kk = HB * h + k;
+                    double2 cc;
+                    // (the lane index of the broadcast is an immediate: the loop is fully unrolled)
+                    switch (kk & 15) {
+#define HX_BC(K) case K: cc.x = row_bcast<K>(cl[kk >> 4].x); cc.y = row_bcast<K>(cl[kk >> 4].y); break;
+                        HX_BC(0) HX_BC(1) HX_BC(2) HX_BC(3) HX_BC(4) HX_BC(5) HX_BC(6) HX_BC(7)
+                        HX_BC(8) HX_BC(9) HX_BC(10) HX_BC(11) HX_BC(12) HX_BC(13) HX_BC(14) HX_BC(15)
+#undef HX_BC
+                    }
+                    cur[k] = rec_step(RMM, SPIN == 0 ? ((kk & 1) ? NCH - 1 : 0) : 0, SPIN == 0 ? kk >> 1 : kk, cc);
+                }
+                if (RM >= 2) {
+#pragma unroll
+                    for (int j = 0; j < HB / 2; ++j)
+                        *reinterpret_cast<double2 *>(tw + pipe_tile_idx(lane, h * (HB / 2) + j)) = make_double2(cur[2 * j], cur[2 * j + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto set_mode = [&]() __attribute__((always_inline)) {
+            bool dead = !valid || sc[0] < 0, live = !valid || sc[0] == 0;
+            if (NCH == 2) {
+                dead = dead && (!valid || sc[NCH - 1] < 0);
+                live = live && (!valid || sc[NCH - 1] == 0);
+            }
+            return __all(dead) ? 1 : (__all(live) ? 3 : 2);
+        };
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+
+        // flush roles (as k_legendre_pipe): 16-byte chunk (col, c) of a group tile = rows (c >> 1) + 8 (c & 1) and + 4
+        const int fcol = tid & 15, fch = (tid >> 4) & 7, fpos = (tid >> 7) & 1;
+        const int frow = (fch >> 1) + 8 * (fch & 1);
+        const int qrow = tid / (4 * NXA), qcol = tid % (4 * NXA);
+        double *pgrp = A.partial + (orow + 2 * frow + fpos) * A.pcol + fcol;
+        double *pquad = A.partial + (orow + 2 * qrow) * A.pcol + NG * NCOL + qcol;
+        double2 cnext[2] = {cfm[0], cfm[16]};
+        DUO_STAMP(0);
+        for (int b = 0; b < nblk; ++b) {
+            const int rm = (HX_DUO_ABL & 2) ? 3 : set_mode();
+            const double2 cl[2] = {cnext[0], cnext[1]};
+            if (HX_DUO_ABL & 2) {
+            } else if (rm == 3) recursion(I3{}, cl);
+            else if (rm == 2) recursion(I2{}, cl);
+            else recursion(I1{}, cl);
+            // coefficients of the next block: requested in front of this block's matrix work and of its flush (vmcnt retires in order: a load
+            // behind the atomics of the flush could not be waited for without waiting for them)
+            cnext[0] = cfm[(b + 1) * LBLK];
+            cnext[1] = cfm[(b + 1) * LBLK + 16];
+            n_rec = __builtin_amdgcn_readfirstlane(n_rec + 1);
+            if (rm >= 2) DUO_STAMP(1); else DUO_STAMP(2);
+            double4_t acc[NG][2];
+            double accx[NXA][2];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g][0] = acc[g][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int g = 0; g < NXA; ++g) accx[g][0] = accx[g][1] = 0.0;
+            if (rm >= 2 && !(HX_DUO_ABL & 1)) {
+                n_mf = __builtin_amdgcn_readfirstlane(n_mf + 1);
+                if (HALFB) {  // the operands pass an empty asm statement once per block: what is derived from them (the swizzles) stays inside this loop
+#pragma unroll
+                    for (int sp = 0; sp < NPAIR; ++sp) {
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) asm volatile("" : "+v"(fr[sp][0][g]));
+#pragma unroll
+                        for (int g = 0; g < NBX; ++g) asm volatile("" : "+v"(frx[sp][0][g]));
+                    }
+                }
+                constexpr int PF = 3;
+                auto a_fetch = [&](int sp) __attribute__((always_inline)) {
+                    const int op = SPIN == 0 ? 0 : sp & 1, q = SPIN == 0 ? sp : sp >> 1;
+                    const int c = SPIN == 0 ? (q >> 3) * 32 + pipe_rho(q & 7, ak) : op * 32 + pipe_rho(q, ak);
+                    return *reinterpret_cast<const double2 *>(tw + pipe_tile_idx(c, ai));
+                };
+                double2 aq[PF + 1];
+#pragma unroll
+                for (int j = 0; j < PF; ++j) aq[j] = a_fetch(j);
+#pragma unroll
+                for (int sp = 0; sp < NPAIR; ++sp) {
+                    if (sp + PF < NPAIR) aq[(sp + PF) % (PF + 1)] = a_fetch(sp + PF);
+                    const double a0 = aq[sp % (PF + 1)].x, a1 = aq[sp % (PF + 1)].y;
+                    // first matrix instruction of the pair; in its shadow the LDS-crossbar permutations that make the position-1 operands (HALFB)
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, fr[sp][0][0], acc[0][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    double bg[NG], bx[NXA];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) bg[g] = HALFB ? quad_rev(fr[sp][0][g]) : fr[sp][NPB - 1][g];
+#pragma unroll
+                    for (int g = 0; g < NXA; ++g) bx[g] = HALFB ? (NBX > 0 ? quad_rev(frx[sp][0][g]) : 0.0) : frx[sp][NPB - 1][g];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 1; g < NG; ++g) acc[g][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, fr[sp][0][g], acc[g][0], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NBX; ++g) accx[g][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, frx[sp][0][g], accx[g][0], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acc[g][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bg[g], acc[g][1], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NBX; ++g) accx[g][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, bx[g], accx[g][1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            DUO_STAMP(3);
+            if (HX_DUO_ABL & 4) {
+                double chk = 0.0;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) chk += acc[g][0][0] + acc[g][0][1] + acc[g][0][2] + acc[g][0][3] + acc[g][1][0] + acc[g][1][1] + acc[g][1][2] + acc[g][1][3];
+#pragma unroll
+                for (int g = 0; g < NXA; ++g) chk += accx[g][0] + accx[g][1];
+                if (chk == 1.2345e-300) A.partial[0] = 1.0;
+                continue;
+            }
+            // ---- flush: D tiles of the 4 waves through their own tiles (consumed above), fixed order; the output scaling alpha_l is
+            // applied by k_alm_reduce (the same factor for every ring group of the m) ----
+            // staging of (group g, position p): column-major, 16-byte chunk c = 2 (lane >> 4) + (reg >> 1) of column col at
+            // (g 2 + p) 256 + col 16 + (c ^ (col & 7)) 2;  4-column blocks: lane (i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3) = row 4 blk + i,
+            // column j, both positions in one 16-byte store at DQ0 + ((row 4 NBX + 4 x + j) 2)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int pos = 0; pos < 2; ++pos)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        *reinterpret_cast<double2 *>(tw + (g * 2 + pos) * 256 + ai * 16 + (((2 * ak + h) ^ (ai & 7)) * 2)) = make_double2(acc[g][pos][2 * h], acc[g][pos][2 * h + 1]);
+#pragma unroll
+            for (int g = 0; g < NBX; ++g)
+                *reinterpret_cast<double2 *>(tw + DQ0 + ((4 * ((lane >> 2) & 3) + ak) * 4 * NBX + 4 * g + (lane & 3)) * 2) = make_double2(accx[g][0], accx[g][1]);
+            lds_barrier();
+            DUO_STAMP(4);
+            {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const double *src = &tile[0][0] + (g * 2 + fpos) * 256 + fcol * 16 + ((fch ^ (fcol & 7)) * 2);
+                    double2 s4[NW];
+#pragma unroll
+                    for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(src + ww * 2048);
+                    put(pgrp + g * NCOL, (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x));
+                    put(pgrp + g * NCOL + 8 * (long long)A.pcol, (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y));
+                }
+                if (NBX > 0 && tid < 64 * NBX) {
+                    double2 s4[NW];
+#pragma unroll
+                    for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(&tile[0][0] + ww * 2048 + DQ0 + tid * 2);
+                    put(pquad, (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x));
+                    put(pquad + A.pcol, (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y));
+                }
+            }
+            pgrp += (long long)LBLK * A.pcol;
+            pquad += (long long)LBLK * A.pcol;
+            DUO_STAMP(5);
+            lds_barrier();  // D tiles consumed: the tiles may be overwritten by the next block's recursion
+            DUO_STAMP(6);
+        }
+    }  // ring groups of this m
+#if HX_DUO_ABL & 32
+    if ((threadIdx.x & 63) == 0 && A.counters)
+        for (int i = 0; i < 8; ++i) atomicAdd(&A.counters[i], cyc[i]);
+    if ((threadIdx.x & 63) == 0 && A.counters) { atomicAdd(&A.counters[8], (unsigned long long)n_rec); atomicAdd(&A.counters[9], (unsigned long long)n_mf); }
+#endif
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_exec_flops[0], (unsigned long long)n_mf * (32ull * (NG * 2048ull + NBX * 512ull)));
+        atomicAdd(&g_exec_flops[1], (unsigned long long)n_rec * (64ull * LBLK * 4ull));
+    }
+}
+
+// =====================================================================================
 // partial sums -> alm (4x4x4 kernels: fixed order over the ring groups of each m; pipelined kernel: rows already summed)
 // =====================================================================================
 template <int SPIN>
@@ -787,7 +1141,7 @@ __global__ __launch_bounds__(256) void k_alm_reduce(PlanDev P, const LegTask *__
                                                     const double *__restrict__ partial, long long row0, int m0, int ms,
                                                     int ncomp, int ng, int ncol, const double *__restrict__ fl, int add,
                                                     double2 *__restrict__ alm, long long alm_stride,
-                                                    const long long *__restrict__ arow)
+                                                    const long long *__restrict__ arow, const double *__restrict__ alphan)
 {
     const int m = m0 + blockIdx.x * ms, lmax = P.lmax;
     const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
@@ -806,6 +1160,11 @@ __global__ __launch_bounds__(256) void k_alm_reduce(PlanDev P, const LegTask *__
                 if (SPIN == 2 && HX_HALF_F && ((l + m) & 1)) {  // odd-parity rows carry the signs (-, +, +, -) on (E_re, E_im, B_re, B_im)
                     if (c & 1) v.y = -v.y;
                     else v.x = -v.x;
+                }
+                if (alphan) {  // k_legendre_duo leaves the output scaling alpha_l of the normalised recursion to this pass
+                    const double al = alphan[almidx(lmax, l, m)];
+                    v.x *= al;
+                    v.y *= al;
                 }
                 if (fl) { v.x *= fl[l]; v.y *= fl[l]; }
             }
@@ -860,8 +1219,19 @@ static int ring_mlim(int lmax, int spin, double sth, double cth)
 // The pipelined kernel is matrix-bound, so a sweep costs what its (4-column padded) columns cost whatever the
 // split; 32 columns is what the B operands of two ring sets leave of the register file.
 struct SweepShape {
-    int ng, nbx, valu, ncol, oneset;
+    int ng, nbx, valu, ncol, oneset, duo;
 };
+// k_legendre_duo (two work-groups per CU, round 4) runs every sweep of the matrix unit; HX_LEG_KERNEL=pipe restores k_legendre_pipe
+// (one work-group per CU, rounds 2-3): A/B switch
+static bool leg_duo()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("HX_LEG_KERNEL");
+        v = (e && !strcmp(e, "pipe")) ? 0 : 1;
+    }
+    return v == 1;
+}
 // HX_PIPE_ONESET=0 keeps ten spin-2 fields as two sweeps of five (the kernel of the first half of round 2): A/B switch
 static bool oneset_enabled()
 {
@@ -875,7 +1245,21 @@ static bool oneset_enabled()
 static SweepShape sweep_shape(int spin, int nb)
 {
     const int cols = 2 * nb;
-    SweepShape sh = {0, 0, 0, 0, 0};
+    SweepShape sh = {0, 0, 0, 0, 0, 0};
+    if (leg_duo()) {
+        // one ring set per wave; spin 2 keeps one operand of the two positions in registers (HALFB): up to two 16-column groups + two
+        // 4-column blocks (ten fields); spin 0 one group + one block (ten maps) or two groups (sixteen)
+        if (cols <= 8) { sh.valu = 1; return sh; }
+        sh.duo = 1;
+        sh.oneset = spin == 2;  // (task set of 4 ring blocks)
+        sh.ng = std::max(cols / NCOL, 1);
+        const int rem = cols > NCOL ? cols % NCOL : 0;
+        const int maxbx = spin == 2 ? 2 : (sh.ng == 1 ? 1 : 0);
+        if (rem > 4 * maxbx) sh.ng += 1;
+        else sh.nbx = (rem + 3) / 4;
+        sh.ncol = NCOL * sh.ng + 4 * sh.nbx;
+        return sh;
+    }
     if (spin == 2 && cols > 2 * NCOL && cols <= 2 * NCOL + 8 && oneset_enabled()) {  // 9 or 10 fields: two groups + one or two blocks, one ring set per wave
         sh.ng = 2;
         sh.nbx = (cols - 2 * NCOL) / 4;
@@ -897,7 +1281,7 @@ static SweepShape sweep_shape(int spin, int nb)
     sh.ncol = NCOL * sh.ng + 4 * sh.nbx;
     return sh;
 }
-int analysis_max_comp(int spin) { return (spin == 2 && oneset_enabled()) ? 8 * NGMAX + 4 : 8 * NGMAX; }
+int analysis_max_comp(int spin) { return (spin == 2 && (leg_duo() || oneset_enabled())) ? 8 * NGMAX + 4 : 8 * NGMAX; }
 
 // Components of the next sweep when `remaining` are left.  Resident inputs: the split that costs least by the measured sweep times
 // (ms at nside 4096 / lmax 6144; only their ratios matter): a sweep pays for its PADDED columns and ~76 ms of recursion, flush and
@@ -906,6 +1290,10 @@ int analysis_max_comp(int spin) { return (spin == 2 && oneset_enabled()) ? 8 * N
 // maps / fields go to the vector-unit kernel.  Ties take the larger sweep first.
 static double sweep_cost(int spin, int units)
 {
+    if (leg_duo()) {  // k_legendre_duo, round 4 (gpurun_out/r4_t6_shapes.log)
+        if (spin == 0) return units <= 4 ? 21.6 * units : (units <= 8 ? 87.0 : (units <= 10 ? 105.0 : 147.0));
+        return units <= 2 ? 61.0 * units : (units <= 4 ? 176.0 : (units == 5 ? 207.0 : (units == 6 ? 245.0 : (units <= 8 ? 285.0 : (units == 9 ? 317.0 : 346.0)))));
+    }
     if (spin == 0) return units <= 4 ? 21.6 * units : (units <= 8 ? 100.0 : (units <= 10 ? 115.0 : 162.0));
     return units <= 2 ? 61.0 * units : (units <= 4 ? 196.0 : (units == 5 ? 224.0 : (units <= 8 ? 316.0 : (units == 9 ? 360.0 : 400.0))));
 }
@@ -998,15 +1386,29 @@ static int pipe_nsub(int spin)
     return v == 2 ? 2 : 1;
 }
 
+static bool duo_shape(const SweepShape &sh) { return sh.duo != 0; }
+// doubles per accumulation row of a sweep (rows of the one-ring-set kernel start on 128-byte lines: the atomics of a flush -- 16 lanes
+// x 8 B per row and column group -- then touch whole aligned lines instead of straddling two: -10 ms for its 40-column sweep, nothing
+// for the other shapes of k_legendre_pipe)
+static int sweep_pcol(const SweepShape &sh)
+{
+    if (duo_shape(sh)) {
+        static int pad = -1;
+        if (pad < 0) { const char *e = getenv("HX_DUO_PCOL"); pad = e ? atoi(e) : 0; }  // (experiments)
+        if (pad > 0) return (sh.ncol + pad - 1) / pad * pad;
+        return sh.ncol > 2 * NCOL ? (sh.ncol + 15) / 16 * 16 : sh.ncol;
+    }
+    if (sh.oneset) return (sh.ncol + 15) / 16 * 16;
+    return sh.ncol;
+}
+
 template <int SPIN>
 static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int nb, const SweepShape &sh, const double *d_rw,
                         const double *d_fl, int add, double2 *d_alms)
 {
     // column groups of the F / partial rows: full groups (+ 1 holding the extra blocks)
     const int ng = sh.ng + (sh.nbx > 0 ? 1 : 0), ncol = sh.ncol;
-    // rows of the one-ring-set kernel start on 128-byte lines: the atomics of a flush (16 lanes x 8 B per row and column group)
-    // then touch whole aligned lines instead of straddling two (-10 ms for its 40-column sweep; nothing for the other shapes)
-    const int pcol = sh.oneset ? (ncol + 15) / 16 * 16 : ncol;
+    const int pcol = sweep_pcol(sh);
     hipStream_t st = rt().stream;
     PlanDev P = pl->dev();
     const int t0 = ts.of_m[m0].first;
@@ -1028,7 +1430,7 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         A.of_m = ts.d_of_m.as<MTasks>(); A.arow = ts.d_arow.as<long long>(); A.arow0 = ts.arow[m0];
         A.tasks = ts.d_tasks.as<LegTask>();  // the pipelined kernel indexes the whole list through of_m
         HX_HIP(hipMemsetAsync(pl->partial.p, 0, (size_t)(ts.arow[m1] - ts.arow[m0]) * pcol * sizeof(double), st));
-#if defined(HX_DIAG) && (HX_PIPE_ABL & 8)
+#if defined(HX_DIAG) && ((HX_PIPE_ABL & 8) || (HX_DUO_ABL & 32))
         HX_TRY(pl->d_dbg.alloc(144));
         HX_HIP(hipMemsetAsync(pl->d_dbg.p, 0, 144, st));
         A.counters = pl->d_dbg.as<unsigned long long>();
@@ -1036,7 +1438,18 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         const double2 *cn = SPIN == 0 ? pl->cn0.as<double2>() : pl->cn2.as<double2>();
         const double *al = SPIN == 0 ? pl->al0.as<double>() : pl->al2.as<double>();
         dim3 pblock(PipeCfg<SPIN>::NW * 64), pgrid((unsigned)nm);
-        if (sh.ng == 1 && sh.nbx == 0 && pipe_nsub(SPIN) == 2)
+        if (duo_shape(sh)) {
+            const dim3 db(256);
+            const int key = sh.ng * 10 + sh.nbx;
+            if (key == 10) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 0>), pgrid, db, 0, st, A, cn);
+            else if (key == 11) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 1>), pgrid, db, 0, st, A, cn);
+            else if (key == 20) hipLaunchKernelGGL((k_legendre_duo<SPIN, 2, 0>), pgrid, db, 0, st, A, cn);
+            else if (key == 12 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 1, 2>), pgrid, db, 0, st, A, cn);
+            else if (key == 21 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 2, 1>), pgrid, db, 0, st, A, cn);
+            else if (key == 22 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 2, 2>), pgrid, db, 0, st, A, cn);
+            else return fail(HX_ERR_ARG, "legendre analysis: no two-group kernel for %d groups + %d blocks", sh.ng, sh.nbx);
+        }
+        else if (sh.ng == 1 && sh.nbx == 0 && pipe_nsub(SPIN) == 2)
             hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 0, 2>), pgrid, pblock, 0, st, A, cn, al);
         else if (sh.ng == 1 && sh.nbx == 0)
             hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 0, 1>), pgrid, pblock, 0, st, A, cn, al);
@@ -1052,6 +1465,19 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
             hipLaunchKernelGGL((k_legendre_pipe<SPIN, 2, 0, 1>), pgrid, pblock, 0, st, A, cn, al);  // a second accumulator set spills 20-76 registers
         else
             return fail(HX_ERR_ARG, "legendre analysis: no kernel for %d groups + %d blocks", sh.ng, sh.nbx);
+#if defined(HX_DIAG) && (HX_DUO_ABL & 32)
+        if (duo_shape(sh)) {
+            unsigned long long hc[18];
+            HX_HIP(hipStreamSynchronize(st));
+            HX_HIP(hipMemcpy(hc, pl->d_dbg.p, 144, hipMemcpyDeviceToHost));
+            const char *nm[7] = {"prologue", "rec live", "rec dead", "matrix", "stage+bar1", "reduce", "bar2"};
+            double tot = 0;
+            for (int i = 0; i < 7; ++i) tot += (double)hc[i];
+            for (int i = 0; i < 7; ++i)
+                fprintf(stderr, "[hx] duo spin %d: %-11s %5.1f %%  %8.1f cycles per wave-block\n", SPIN, nm[i], 100.0 * hc[i] / tot, (double)hc[i] / (double)hc[8]);
+            fprintf(stderr, "[hx] duo spin %d: %llu wave-blocks, %llu with matrix work, %.1f cycles per wave-block in all\n", SPIN, hc[8], hc[9], tot / (double)hc[8]);
+        }
+#endif
 #if defined(HX_DIAG) && (HX_PIPE_ABL & 8)
         {
             unsigned long long hc[18];
@@ -1070,7 +1496,8 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
     {
         ProfScope ps("alm_reduce");
         hipLaunchKernelGGL(k_alm_reduce<SPIN>, dim3(nm), dim3(256), 0, st, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
-                           pl->partial.as<double>(), ts.arow[m0], m0, ms, nb, ng, pcol, d_fl, add, d_alms, pl->nlm, ts.d_arow.as<long long>());
+                           pl->partial.as<double>(), ts.arow[m0], m0, ms, nb, ng, pcol, d_fl, add, d_alms, pl->nlm, ts.d_arow.as<long long>(),
+                           duo_shape(sh) ? (SPIN == 0 ? pl->al0.as<double>() : pl->al2.as<double>()) : (const double *)nullptr);
     }
     HX_HIP(hipGetLastError());
     return HX_OK;
@@ -1139,10 +1566,10 @@ static int analysis_batch_valu(hx_plan *pl, int spin, int nb, const double *d_ma
             ProfScope ps("alm_reduce");
             if (spin == 0)
                 hipLaunchKernelGGL(k_alm_reduce<0>, dim3(nm), dim3(256), 0, rt().stream, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
-                                   pl->partial.as<double>(), ts.rows_before_m[m0], m0, ms, 1, 1, pcol, d_fl, add, d_alms + (size_t)c0 * pl->nlm, pl->nlm, nullptr);
+                                   pl->partial.as<double>(), ts.rows_before_m[m0], m0, ms, 1, 1, pcol, d_fl, add, d_alms + (size_t)c0 * pl->nlm, pl->nlm, nullptr, nullptr);
             else
                 hipLaunchKernelGGL(k_alm_reduce<2>, dim3(nm), dim3(256), 0, rt().stream, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(),
-                                   pl->partial.as<double>(), ts.rows_before_m[m0], m0, ms, 2, 1, pcol, d_fl, add, d_alms + (size_t)c0 * pl->nlm, pl->nlm, nullptr);
+                                   pl->partial.as<double>(), ts.rows_before_m[m0], m0, ms, 2, 1, pcol, d_fl, add, d_alms + (size_t)c0 * pl->nlm, pl->nlm, nullptr, nullptr);
             HX_HIP(hipGetLastError());
         }
     return HX_OK;
@@ -1161,8 +1588,10 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     // doubles per F / partial row: only the columns in use are stored -- 4-column granularity on the
     // 4x4x4 path (<= 8 columns), 16 per full group + 4 per extra block on the pipelined kernel
     const SweepShape sh = sweep_shape(spin, nb);
-    if (sh.oneset) HX_TRY(build_task_set(pl, 2, PipeCfg<2>::NW * PipeCfg<2>::RBS, pl->ts[3]));  // one ring set per wave: 4 ring blocks per task
-    hx_plan::TaskSet &ts = sh.oneset ? pl->ts[3] : pl->ts[sidx];
+    // one ring set per wave: 4 (spin 2) / 8 (spin 0) ring blocks per task
+    const bool one_set = sh.oneset || duo_shape(sh);  // (spin 0: 8 ring blocks per task in ts[2])
+    if (one_set) HX_TRY(build_task_set(pl, spin, PipeCfg<2>::NW * (spin ? PipeCfg<2>::RBS : PipeCfg<0>::RBS), spin ? pl->ts[3] : pl->ts[2]));
+    hx_plan::TaskSet &ts = one_set ? (spin ? pl->ts[3] : pl->ts[2]) : pl->ts[sidx];
     const int ncol = sh.ncol;
     if (pl->hsrc == nullptr && pl->nssrc == nullptr) {
         HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
@@ -1183,7 +1612,7 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
     const int lmax = pl->lmax;
     // rows of the partial buffer: one span per m (the pipelined kernel adds its ring groups in place)
     const std::vector<long long> &prow = ts.arow;
-    const int pcol = sh.oneset ? (ncol + 15) / 16 * 16 : ncol;  // doubles per row of the partial buffer (launch_chunk)
+    const int pcol = sweep_pcol(sh);  // doubles per row of the partial buffer (launch_chunk)
     std::vector<std::pair<int, int>> chunks;
     size_t maxF = 16, maxP = 16;
     // a chunk [m0, m1) holds the orders m0, m0 + ms, ... < m1 (ms = 1 but on the m-sharded route); m1 - 1 is its last order
