@@ -797,22 +797,18 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
 // One ring set per wave (spin 0: 64 ring pairs, both parity chains in a lane; spin 2: 32 ring pairs x the two functions): a task
 // is 8 / 4 ring blocks.
 // HALFB (spin 2, HX_HALF_F): the operand of the odd-parity position is the operand of the even one with the four columns of every
-// field reversed (see HX_HALF_F) -- a quad_perm:[3,2,1,0] of the lanes.  Only ONE of the two is kept in registers; the other is made
-// by two v_mov_b32_dpp in the shadow of the matrix instruction before it.  40 columns (ten fields) then need 128 operand registers
-// instead of 256 and fit a 256-register wave.
+// field reversed (see HX_HALF_F): B_odd[k][j] = B_even[k][j ^ 3].  A matrix instruction that takes B_even for an odd-parity row block
+// therefore yields that block's rows with the columns of every field reversed -- D_odd[i][j] = (A B_even)[i][j ^ 3] -- which
+// k_alm_reduce undoes when it changes the layout.  ONE operand per (slot pair, column group) for both positions: 40 columns (ten
+// fields) need 128 operand registers instead of 256 and fit a 256-register wave, with no instruction spent on the permutation.
+// (Measured on the way, tools/ubench_mblock.hip: the permutation as two v_mov_b32_dpp per operand costs ~12 cycles of matrix-pipe
+// time per VALU instruction -- 417 instead of 357 cycles per slot pair of 40 columns; as two ds_swizzle_b32 it is free.)
+#ifndef HX_DUO_FMACDPP
+#define HX_DUO_FMACDPP 1  // p' x + q' as (row broadcast, multiply-add with a broadcast source) instead of (two row broadcasts, multiply-add)
+#endif
 #ifndef HX_DUO_ABL
 #define HX_DUO_ABL 0  // timing experiments only: 1 no matrix instructions, 2 no recursion, 4 no flush, 8 plain stores instead of atomics, 32 cycle accounting
 #endif
-// the four columns of every field reversed across the lanes (quad-perm [3,2,1,0]) through the LDS crossbar: two ds_swizzle_b32, which
-// ride in the shadow of a matrix instruction like any other LDS traffic.  (As two v_mov_b32_dpp the same permutation costs ~12
-// cycles of matrix-pipe time per VALU instruction: 417 instead of 357 cycles per slot pair of 40 columns, tools/ubench_mblock.hip.)
-__device__ __forceinline__ double quad_rev(double v)
-{
-    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x801B);
-    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x801B);
-    return __hiloint2double(hi, lo);
-}
-
 // lane K of every row of 16 lanes broadcast to its row: the only DPP control the FP64 ALU takes (one v_mov_b64_dpp)
 template <int K>
 __device__ __forceinline__ double row_bcast(double v)
@@ -822,7 +818,16 @@ __device__ __forceinline__ double row_bcast(double v)
     return d;
 }
 
-template <int SPIN, int NG, int NBX>
+// t += p[lane K of the row] * x  (v_fmac_f64 with a row broadcast on its first source)
+template <int K>
+__device__ __forceinline__ double row_bcast_fmac(double t, double p, double x)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(p), "v"(x), "n"(K));
+    return t;
+}
+
+// NSUB: 32-l blocks per flush (their D tiles stay in registers; one staging round and one pair of barriers per NSUB blocks)
+template <int SPIN, int NG, int NBX, int NSUB = 1>
 __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const double2 *__restrict__ coefn)
 {
     using C = PipeCfg<SPIN>;
@@ -831,7 +836,7 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
     constexpr int DQ0 = NG * 512, DSZ = NG * 512 + NBX * 128;
     constexpr bool HALFB = SPIN == 2;
     constexpr int NPB = HALFB ? 1 : 2;  // operand positions kept in registers
-    static_assert(NG >= 1 && NG <= 2 && DSZ <= 2048, "the D tiles of a wave fit its tile");
+    static_assert(NG >= 1 && NG <= 2 && NSUB * DSZ <= 2048, "the D tiles of a wave fit its tile");
     static_assert(SPIN == 0 || HX_HALF_F, "spin 2: the lambda- chain carries (-1)^(l + m) lambda- (one operand row, wave-uniform coefficients)");
     __shared__ double tile[NW][2048];          // 64 KiB; doubles as the D staging area of the flush
 #if HX_DUO_ABL & 64  // diagnostic: ONE work-group per CU (the phase durations of a wave that is alone on its SIMD)
@@ -898,12 +903,11 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
             const bool on = rbq < task.nrb;
             const long long row = (long long)blockIdx.x * P.nrp_pad + (task.rb0 + rbq) * RBLK + pipe_rho(q & 7, ak);
             if (HALFB) {
-                const double *f = A.F + (row * NOP + op) * A.ncol;
-                const int cx = off ? 3 : 0;  // position 0 has parity off
+                const double *f = A.F + (row * NOP + op) * A.ncol;  // the even-parity row, for both positions
 #pragma unroll
-                for (int g = 0; g < NG; ++g) fr[sp][0][g] = on ? f[g * NCOL + (ai ^ cx)] : 0.0;
+                for (int g = 0; g < NG; ++g) fr[sp][0][g] = on ? f[g * NCOL + ai] : 0.0;
 #pragma unroll
-                for (int g = 0; g < NXA; ++g) frx[sp][0][g] = (NBX > 0 && on) ? f[NG * NCOL + 4 * g + ((lane & 3) ^ cx)] : 0.0;
+                for (int g = 0; g < NXA; ++g) frx[sp][0][g] = (NBX > 0 && on) ? f[NG * NCOL + 4 * g + (lane & 3)] : 0.0;
             } else {
 #pragma unroll
                 for (int pos = 0; pos < NPB; ++pos) {
@@ -939,7 +943,7 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
             }
         }
 
-        auto rec_step = [&](auto RMM, int c, int step, const double2 cc) __attribute__((always_inline)) {
+        auto rec_step = [&](auto RMM, int c, int step, const double tq) __attribute__((always_inline)) {
             constexpr int RM = decltype(RMM)::value;
             if (RM != 3 && (step & 3) == 0) {
                 const int hc = __double2hiint(vc[c]), hp = __double2hiint(vp[c]);
@@ -951,7 +955,7 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
                 sc[c] += up ? 1 : 0;
             }
             const double cur = (RM == 3 || sc[c] == 0) ? vc[c] : 0.0;
-            const double vn = fma(fma(cc.x, xx, cc.y), vc[c], -vp[c]);
+            const double vn = fma(tq, vc[c], -vp[c]);
             vp[c] = vc[c];
             vc[c] = vn;
             return cur;
@@ -968,15 +972,19 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
                 for (int k = 0; k < HB; ++k) {
                     constexpr int dummy = 0; (void)dummy;
                     const int kk = HB * h + k;
-                    double2 cc;
+                    double tq = 0.0;  // p' x + q' of this step: q' by a row broadcast, p' as the broadcast source of the multiply-add
                     // (the lane index of the broadcast is an immediate: the loop is fully unrolled)
                     switch (kk & 15) {
-#define HX_BC(K) case K: cc.x = row_bcast<K>(cl[kk >> 4].x); cc.y = row_bcast<K>(cl[kk >> 4].y); break;
+#if HX_DUO_FMACDPP
+#define HX_BC(K) case K: tq = row_bcast_fmac<K>(row_bcast<K>(cl[kk >> 4].y), cl[kk >> 4].x, xx); break;
+#else
+#define HX_BC(K) case K: tq = fma(row_bcast<K>(cl[kk >> 4].x), xx, row_bcast<K>(cl[kk >> 4].y)); break;
+#endif
                         HX_BC(0) HX_BC(1) HX_BC(2) HX_BC(3) HX_BC(4) HX_BC(5) HX_BC(6) HX_BC(7)
                         HX_BC(8) HX_BC(9) HX_BC(10) HX_BC(11) HX_BC(12) HX_BC(13) HX_BC(14) HX_BC(15)
 #undef HX_BC
                     }
-                    cur[k] = rec_step(RMM, SPIN == 0 ? ((kk & 1) ? NCH - 1 : 0) : 0, SPIN == 0 ? kk >> 1 : kk, cc);
+                    cur[k] = rec_step(RMM, SPIN == 0 ? ((kk & 1) ? NCH - 1 : 0) : 0, SPIN == 0 ? kk >> 1 : kk, tq);
                 }
                 if (RM >= 2) {
 #pragma unroll
@@ -1006,116 +1014,117 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
         double *pquad = A.partial + (orow + 2 * qrow) * A.pcol + NG * NCOL + qcol;
         double2 cnext[2] = {cfm[0], cfm[16]};
         DUO_STAMP(0);
-        for (int b = 0; b < nblk; ++b) {
-            const int rm = (HX_DUO_ABL & 2) ? 3 : set_mode();
-            const double2 cl[2] = {cnext[0], cnext[1]};
-            if (HX_DUO_ABL & 2) {
-            } else if (rm == 3) recursion(I3{}, cl);
-            else if (rm == 2) recursion(I2{}, cl);
-            else recursion(I1{}, cl);
-            // coefficients of the next block: requested in front of this block's matrix work and of its flush (vmcnt retires in order: a load
-            // behind the atomics of the flush could not be waited for without waiting for them)
-            cnext[0] = cfm[(b + 1) * LBLK];
-            cnext[1] = cfm[(b + 1) * LBLK + 16];
-            n_rec = __builtin_amdgcn_readfirstlane(n_rec + 1);
-            if (rm >= 2) DUO_STAMP(1); else DUO_STAMP(2);
-            double4_t acc[NG][2];
-            double accx[NXA][2];
+        for (int b0 = 0; b0 < nblk; b0 += NSUB) {
+            double4_t acc[NSUB][NG][2];
+            double accx[NSUB][NXA][2];
 #pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g][0] = acc[g][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const int b = b0 + sub;
 #pragma unroll
-            for (int g = 0; g < NXA; ++g) accx[g][0] = accx[g][1] = 0.0;
-            if (rm >= 2 && !(HX_DUO_ABL & 1)) {
-                n_mf = __builtin_amdgcn_readfirstlane(n_mf + 1);
-                if (HALFB) {  // the operands pass an empty asm statement once per block: what is derived from them (the swizzles) stays inside this loop
+                for (int g = 0; g < NG; ++g) acc[sub][g][0] = acc[sub][g][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int g = 0; g < NXA; ++g) accx[sub][g][0] = accx[sub][g][1] = 0.0;
+                if (b >= nblk) break;  // (rows are padded to whole blocks, the row span of an m to nblk blocks: nothing is stored beyond it)
+                const int rm = (HX_DUO_ABL & 2) ? 3 : set_mode();
+                const double2 cl[2] = {cnext[0], cnext[1]};
+                if (HX_DUO_ABL & 2) {
+                } else if (rm == 3) recursion(I3{}, cl);
+                else if (rm == 2) recursion(I2{}, cl);
+                else recursion(I1{}, cl);
+                // coefficients of the next block: requested in front of this block's matrix work and of its flush (vmcnt retires in order: a load
+                // behind the atomics of the flush could not be waited for without waiting for them)
+                cnext[0] = cfm[(b + 1) * LBLK];
+                cnext[1] = cfm[(b + 1) * LBLK + 16];
+                n_rec = __builtin_amdgcn_readfirstlane(n_rec + 1);
+                if (rm >= 2) DUO_STAMP(1); else DUO_STAMP(2);
+                if (rm >= 2 && !(HX_DUO_ABL & 1)) {
+                    n_mf = __builtin_amdgcn_readfirstlane(n_mf + 1);
+                    constexpr int PF = 3;
+                    auto a_fetch = [&](int sp) __attribute__((always_inline)) {
+                        const int op = SPIN == 0 ? 0 : sp & 1, q = SPIN == 0 ? sp : sp >> 1;
+                        const int c = SPIN == 0 ? (q >> 3) * 32 + pipe_rho(q & 7, ak) : op * 32 + pipe_rho(q, ak);
+                        return *reinterpret_cast<const double2 *>(tw + pipe_tile_idx(c, ai));
+                    };
+                    double2 aq[PF + 1];
+#pragma unroll
+                    for (int j = 0; j < PF; ++j) aq[j] = a_fetch(j);
 #pragma unroll
                     for (int sp = 0; sp < NPAIR; ++sp) {
+                        if (sp + PF < NPAIR) aq[(sp + PF) % (PF + 1)] = a_fetch(sp + PF);
+                        const double a0 = aq[sp % (PF + 1)].x, a1 = aq[sp % (PF + 1)].y;
+                        // (HALFB: position 1 takes the operand of position 0; its rows come out with the columns of every field reversed)
 #pragma unroll
-                        for (int g = 0; g < NG; ++g) asm volatile("" : "+v"(fr[sp][0][g]));
+                        for (int pos = 0; pos < 2; ++pos) {
+                            const double a = pos ? a1 : a0;
 #pragma unroll
-                        for (int g = 0; g < NBX; ++g) asm volatile("" : "+v"(frx[sp][0][g]));
+                            for (int g = 0; g < NG; ++g) acc[sub][g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[sp][HALFB ? 0 : pos][g], acc[sub][g][pos], 0, 0, 0);
+#pragma unroll
+                            for (int g = 0; g < NBX; ++g) accx[sub][g][pos] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[sp][HALFB ? 0 : pos][g], accx[sub][g][pos], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                constexpr int PF = 3;
-                auto a_fetch = [&](int sp) __attribute__((always_inline)) {
-                    const int op = SPIN == 0 ? 0 : sp & 1, q = SPIN == 0 ? sp : sp >> 1;
-                    const int c = SPIN == 0 ? (q >> 3) * 32 + pipe_rho(q & 7, ak) : op * 32 + pipe_rho(q, ak);
-                    return *reinterpret_cast<const double2 *>(tw + pipe_tile_idx(c, ai));
-                };
-                double2 aq[PF + 1];
-#pragma unroll
-                for (int j = 0; j < PF; ++j) aq[j] = a_fetch(j);
-#pragma unroll
-                for (int sp = 0; sp < NPAIR; ++sp) {
-                    if (sp + PF < NPAIR) aq[(sp + PF) % (PF + 1)] = a_fetch(sp + PF);
-                    const double a0 = aq[sp % (PF + 1)].x, a1 = aq[sp % (PF + 1)].y;
-                    // first matrix instruction of the pair; in its shadow the LDS-crossbar permutations that make the position-1 operands (HALFB)
-                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, fr[sp][0][0], acc[0][0], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    double bg[NG], bx[NXA];
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) bg[g] = HALFB ? quad_rev(fr[sp][0][g]) : fr[sp][NPB - 1][g];
-#pragma unroll
-                    for (int g = 0; g < NXA; ++g) bx[g] = HALFB ? (NBX > 0 ? quad_rev(frx[sp][0][g]) : 0.0) : frx[sp][NPB - 1][g];
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int g = 1; g < NG; ++g) acc[g][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, fr[sp][0][g], acc[g][0], 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < NBX; ++g) accx[g][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, frx[sp][0][g], accx[g][0], 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) acc[g][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bg[g], acc[g][1], 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < NBX; ++g) accx[g][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, bx[g], accx[g][1], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                DUO_STAMP(3);
             }
-            DUO_STAMP(3);
             if (HX_DUO_ABL & 4) {
                 double chk = 0.0;
 #pragma unroll
-                for (int g = 0; g < NG; ++g) chk += acc[g][0][0] + acc[g][0][1] + acc[g][0][2] + acc[g][0][3] + acc[g][1][0] + acc[g][1][1] + acc[g][1][2] + acc[g][1][3];
+                for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
-                for (int g = 0; g < NXA; ++g) chk += accx[g][0] + accx[g][1];
+                    for (int g = 0; g < NG; ++g) chk += acc[sub][g][0][0] + acc[sub][g][0][1] + acc[sub][g][0][2] + acc[sub][g][0][3] + acc[sub][g][1][0] + acc[sub][g][1][1] + acc[sub][g][1][2] + acc[sub][g][1][3];
+#pragma unroll
+                    for (int g = 0; g < NXA; ++g) chk += accx[sub][g][0] + accx[sub][g][1];
+                }
                 if (chk == 1.2345e-300) A.partial[0] = 1.0;
                 continue;
             }
             // ---- flush: D tiles of the 4 waves through their own tiles (consumed above), fixed order; the output scaling alpha_l is
-            // applied by k_alm_reduce (the same factor for every ring group of the m) ----
+            // applied by k_alm_reduce (the same factor for every ring group of the m).  (Measured and not kept: per-wave "issued matrix
+            // instructions" flags in LDS so that dead waves stage nothing and all-dead blocks skip the flush -- the flag read behind the
+            // barrier costs every flush more than the dead blocks save: 357 vs 345 ms for ten fields, same device.) ----
             // staging of (group g, position p): column-major, 16-byte chunk c = 2 (lane >> 4) + (reg >> 1) of column col at
             // (g 2 + p) 256 + col 16 + (c ^ (col & 7)) 2;  4-column blocks: lane (i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3) = row 4 blk + i,
-            // column j, both positions in one 16-byte store at DQ0 + ((row 4 NBX + 4 x + j) 2)
+            // column j, both positions in one 16-byte store at DQ0 + ((row 4 NBX + 4 x + j) 2); sub-block sub at + sub DSZ
+            const bool two = NSUB > 1 && b0 + 1 < nblk;
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int sub = 0; sub < NSUB; ++sub) {
+                double *dt = tw + sub * DSZ;
 #pragma unroll
-                for (int pos = 0; pos < 2; ++pos)
+                for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
-                        *reinterpret_cast<double2 *>(tw + (g * 2 + pos) * 256 + ai * 16 + (((2 * ak + h) ^ (ai & 7)) * 2)) = make_double2(acc[g][pos][2 * h], acc[g][pos][2 * h + 1]);
+                    for (int pos = 0; pos < 2; ++pos)
 #pragma unroll
-            for (int g = 0; g < NBX; ++g)
-                *reinterpret_cast<double2 *>(tw + DQ0 + ((4 * ((lane >> 2) & 3) + ak) * 4 * NBX + 4 * g + (lane & 3)) * 2) = make_double2(accx[g][0], accx[g][1]);
+                        for (int h = 0; h < 2; ++h)
+                            *reinterpret_cast<double2 *>(dt + (g * 2 + pos) * 256 + ai * 16 + (((2 * ak + h) ^ (ai & 7)) * 2)) = make_double2(acc[sub][g][pos][2 * h], acc[sub][g][pos][2 * h + 1]);
+#pragma unroll
+                for (int g = 0; g < NBX; ++g)
+                    *reinterpret_cast<double2 *>(dt + DQ0 + ((4 * ((lane >> 2) & 3) + ak) * 4 * NBX + 4 * g + (lane & 3)) * 2) = make_double2(accx[sub][g][0], accx[sub][g][1]);
+            }
             lds_barrier();
             DUO_STAMP(4);
-            {
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+                if (sub > 0 && !two) break;
+                const long long rsub = (long long)sub * LBLK * A.pcol;
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    const double *src = &tile[0][0] + (g * 2 + fpos) * 256 + fcol * 16 + ((fch ^ (fcol & 7)) * 2);
+                    const double *src = &tile[0][0] + sub * DSZ + (g * 2 + fpos) * 256 + fcol * 16 + ((fch ^ (fcol & 7)) * 2);
                     double2 s4[NW];
 #pragma unroll
                     for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(src + ww * 2048);
-                    put(pgrp + g * NCOL, (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x));
-                    put(pgrp + g * NCOL + 8 * (long long)A.pcol, (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y));
+                    put(pgrp + rsub + g * NCOL, (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x));
+                    put(pgrp + rsub + g * NCOL + 8 * (long long)A.pcol, (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y));
                 }
                 if (NBX > 0 && tid < 64 * NBX) {
                     double2 s4[NW];
 #pragma unroll
-                    for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(&tile[0][0] + ww * 2048 + DQ0 + tid * 2);
-                    put(pquad, (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x));
-                    put(pquad + A.pcol, (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y));
+                    for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(&tile[0][0] + ww * 2048 + sub * DSZ + DQ0 + tid * 2);
+                    put(pquad + rsub, (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x));
+                    put(pquad + rsub + A.pcol, (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y));
                 }
             }
-            pgrp += (long long)LBLK * A.pcol;
-            pquad += (long long)LBLK * A.pcol;
+            pgrp += (long long)NSUB * LBLK * A.pcol;
+            pquad += (long long)NSUB * LBLK * A.pcol;
             DUO_STAMP(5);
             lds_barrier();  // D tiles consumed: the tiles may be overwritten by the next block's recursion
             DUO_STAMP(6);
@@ -1156,7 +1165,13 @@ __global__ __launch_bounds__(256) void k_alm_reduce(PlanDev P, const LegTask *__
             if (c >= ncomp) continue;
             double2 v = make_double2(0.0, 0.0);
             if (l >= l0 && mt.count > 0) {
-                v = *reinterpret_cast<const double2 *>(partial + (r0 + (l - l0)) * ncol + (c >> 3) * NCOL + 2 * (c & 7));
+                const double *prow = partial + (r0 + (l - l0)) * ncol + (c >> 3) * NCOL;
+                v = *reinterpret_cast<const double2 *>(prow + 2 * (c & 7));
+                if (SPIN == 2 && alphan && ((l + m) & 1)) {
+                    // k_legendre_duo: odd-parity rows were formed with the even-parity operand, i.e. with the four columns of every field reversed
+                    const int j = 2 * (c & 7);
+                    v = make_double2(prow[j ^ 3], prow[(j + 1) ^ 3]);
+                }
                 if (SPIN == 2 && HX_HALF_F && ((l + m) & 1)) {  // odd-parity rows carry the signs (-, +, +, -) on (E_re, E_im, B_re, B_im)
                     if (c & 1) v.y = -v.y;
                     else v.x = -v.x;
@@ -1291,8 +1306,8 @@ int analysis_max_comp(int spin) { return (spin == 2 && (leg_duo() || oneset_enab
 static double sweep_cost(int spin, int units)
 {
     if (leg_duo()) {  // k_legendre_duo, round 4 (gpurun_out/r4_t6_shapes.log)
-        if (spin == 0) return units <= 4 ? 21.6 * units : (units <= 8 ? 87.0 : (units <= 10 ? 105.0 : 147.0));
-        return units <= 2 ? 61.0 * units : (units <= 4 ? 176.0 : (units == 5 ? 207.0 : (units == 6 ? 245.0 : (units <= 8 ? 285.0 : (units == 9 ? 317.0 : 346.0)))));
+        if (spin == 0) return units <= 4 ? 21.6 * units : (units <= 8 ? 84.5 : (units <= 10 ? 100.7 : 147.0));
+        return units <= 2 ? 61.0 * units : (units <= 4 ? 166.0 : (units == 5 ? 198.0 : (units == 6 ? 221.0 : (units <= 8 ? 276.0 : (units == 9 ? 317.0 : 345.0)))));
     }
     if (spin == 0) return units <= 4 ? 21.6 * units : (units <= 8 ? 100.0 : (units <= 10 ? 115.0 : 162.0));
     return units <= 2 ? 61.0 * units : (units <= 4 ? 196.0 : (units == 5 ? 224.0 : (units <= 8 ? 316.0 : (units == 9 ? 360.0 : 400.0))));
@@ -1441,7 +1456,15 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         if (duo_shape(sh)) {
             const dim3 db(256);
             const int key = sh.ng * 10 + sh.nbx;
-            if (key == 10) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 0>), pgrid, db, 0, st, A, cn);
+            // two l-blocks per flush wherever the second accumulator set fits the 256 registers (ten spin-0 maps 105 -> 101 ms, five spin-2 fields
+            // 206 -> 198, eight 289 -> 276; sixteen spin-0 maps spill: 147 -> 157); HX_DUO_NSUB=1 keeps one block per flush (bit-identical results)
+            static int nsub1 = -1;
+            if (nsub1 < 0) { const char *e = getenv("HX_DUO_NSUB"); nsub1 = (e && atoi(e) == 1) ? 1 : 0; }
+            if (key == 10 && !nsub1) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 0, 2>), pgrid, db, 0, st, A, cn);
+            else if (key == 11 && !nsub1) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 1, 2>), pgrid, db, 0, st, A, cn);
+            else if (key == 20 && !nsub1 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 2, 0, 2>), pgrid, db, 0, st, A, cn);
+            else if (key == 12 && !nsub1 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 1, 2, 2>), pgrid, db, 0, st, A, cn);
+            else if (key == 10) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 0>), pgrid, db, 0, st, A, cn);
             else if (key == 11) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 1>), pgrid, db, 0, st, A, cn);
             else if (key == 20) hipLaunchKernelGGL((k_legendre_duo<SPIN, 2, 0>), pgrid, db, 0, st, A, cn);
             else if (key == 12 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 1, 2>), pgrid, db, 0, st, A, cn);
