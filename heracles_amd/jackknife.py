@@ -105,6 +105,13 @@ def region_alms(fields, maps, jk_map, *, device="cuda"):
     region = torch.as_tensor(np.ascontiguousarray(jk_map, dtype=np.float64)).to(device)
     L = _lib.load()
 
+    # the weight file of a configured data path is part of a mapper's settings: load it before the mappers are compared, as
+    # HipHealpixMapper.transform does -- the reference transforms every jackknife map through mapper.transform
+    # (dices/jackknife.py:143-148), so the two must weight alike whichever runs first
+    for mp in {id(m): m for m in mappers.values()}.values():
+        if hasattr(mp, "_load_weights"):
+            mp._load_weights()
+
     def settings(k):
         """What a mapper contributes to the transform besides (nside, lmax): the fields of one batched call must agree on all
         of it -- the reference transforms every field with its OWN mapper (dices/jackknife.py:143-148 via mapping.transform)."""
@@ -142,11 +149,12 @@ def region_alms(fields, maps, jk_map, *, device="cuda"):
             dst = out[k, c0 : c0 + dmaps.shape[0]] if contiguous else work
             plan.map2alm(src, spin, ring_weights=mp.ring_weights, pix_weights=mp.pixel_weights, fl=fl, niter=mp.niter, out=dst)
             if not contiguous:
-                _lib.synchronize()
+                # scatter on the LIBRARY's stream (hx_copy, device to device): the next iteration's hx_region_maps / map2alm(out=work)
+                # run on that stream too and are ordered behind these copies -- a torch-stream copy would leave the reuse of `work` unordered
                 r = 0
                 for kk in ks:
                     n = comps[kk].stop - comps[kk].start
-                    out[k, comps[kk]] = work[r : r + n]
+                    _lib.copy(out[k, comps[kk]], work[r : r + n])
                     r += n
         del dmaps, scratch, work
     return RegionAlms(order, meta, comps, out)
@@ -195,7 +203,10 @@ def correct_footprint_naturalspice(cls, cls_mm, mls0, fields, unmixed=False):
     for key in wjk:
         alpha = wjk[key].array
         if not unmixed:
-            alpha = alpha / w0[key].array
+            # the reference divides without a guard (dices/jackknife.py:420): columns a mask pair does not populate (e.g. the B-mode
+            # columns of a scalar mask) are 0 / 0 = nan there too, and _naturalspice never reads them -- same values, no warning
+            with np.errstate(invalid="ignore", divide="ignore"):
+                alpha = alpha / w0[key].array
         alphas[key] = replace(mls0[key], array=alpha)
     first_cls, first_mls = next(iter(cls.values())), next(iter(mls0.values()))
     lmax = first_cls.shape[first_cls.axis[0]]

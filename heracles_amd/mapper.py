@@ -245,19 +245,23 @@ class HipHealpixMapper:
         if self.pixel_weights is None and self.ring_weights is None:
             path = self.datapath if self.datapath is not None else type(self).DATAPATH
             if path is not None:
-                from .weights import load_pixel_weights
+                from .weights import load_pixel_weights, weights_filename
 
                 self.pixel_weights = load_pixel_weights(path, self.__nside)
+                if self.pixel_weights is None:
+                    # healpy raises when use_pixel_weights=True finds no file under datapath; silently falling back to unit weights
+                    # would change the quadrature behind the caller's back
+                    raise FileNotFoundError(f"no pixel-weight file {weights_filename(self.__nside)} under datapath {path!r}")
 
     def transform(self, data, spin=0):
         """Spherical harmonic transform of HEALPix maps; heracles/healpy.py:162-203."""
         if spin not in (0, 2):
             raise NotImplementedError(f"spin-{spin} maps not yet supported")
         fl = self._fl(spin)
-        plan = sht.get_plan(self.__nside, self.__lmax)
         self._load_weights()
         if self.pixel_weights is None and self.ring_weights is None:
             _warn_unit_weights()
+        plan = sht.get_plan(self.__nside, self.__lmax)
         if hasattr(data, "data_ptr"):
             # device-resident maps (e.g. accumulated by map_values on the GPU): alms stay in HBM; a torch
             # tensor cannot carry dtype metadata, so none is attached
@@ -282,8 +286,10 @@ class HipHealpixMapper:
         for sp in spins:
             if sp not in (0, 2):
                 raise NotImplementedError(f"spin-{sp} maps not yet supported")
-        plan = sht.get_plan(self.__nside, self.__lmax)
         self._load_weights()
+        if self.pixel_weights is None and self.ring_weights is None:
+            _warn_unit_weights()
+        plan = sht.get_plan(self.__nside, self.__lmax)
         npix, nlm = 12 * self.__nside**2, (self.__lmax + 1) * (self.__lmax + 2) // 2
         native = [m if hasattr(m, "data_ptr") else np.ascontiguousarray(_native(m), dtype=np.float64) for m in maps]
         native = [m.reshape((npix,) if sp == 0 else (2, npix)) for m, sp in zip(native, spins)]
@@ -299,6 +305,11 @@ class HipHealpixMapper:
             md = {**((m.dtype.metadata or {}) if isinstance(m, np.ndarray) else {"spin": sp}), "deconv": self.__deconv}
             if device is not None:
                 out.append(DeviceArray(a, md))
+                continue
+            if hasattr(a, "data_ptr"):
+                # a device-resident map with device=None: the alm stays in HBM as a tensor, as transform() returns it (a torch tensor
+                # cannot carry dtype metadata)
+                out.append(a)
                 continue
             a = a if isinstance(a, np.ndarray) else np.array(a)
             update_metadata(a, **md)

@@ -1,19 +1,55 @@
-"""``heracles.transform`` (heracles/mapping.py:113-175) as a batched call.
+"""``heracles.transform`` (heracles/mapping.py:113-175) as one batched call per mapper.
 
-The reference walks ``data`` -- ``{(field name, bin): map}`` -- and calls ``field.mapper_or_error.transform(m, spin=s)`` once per
-map (mapping.py:171).  This mirror keeps its interface, key order, metadata rule and errors (unknown field name, spin mismatch:
-``ValueError`` with the reference's messages) and hands the maps of every mapper to ``transform_many`` in one call
-(``hx_map2alm_list``: one upload pipeline for all of them, no stacked host copy); a mapper without ``transform_many`` is called map
-by map, as in the reference."""
+The reference walks ``data`` -- ``{(field name, bin): map}`` -- and transforms one map at a time (mapping.py:171).  Here the walk
+only *plans*: every map becomes a ``_Job`` filed under the mapper that will transform it, and each mapper then receives all of its
+maps in a single ``transform_many`` call (``hx_map2alm_list``: one upload pipeline, no stacked host copy).  What a caller of the
+reference can observe is kept: the keys of ``out`` in the order of ``data``, a map without ``spin`` metadata taking its field's, and
+the two ``ValueError`` messages (unknown field name, spin mismatch), which are the reference's."""
+
+from dataclasses import dataclass
+from typing import Any
 
 from .core import TocDict, update_metadata
 
 __all__ = ["transform"]
 
 
-def _mapper_of(field):
-    m = getattr(field, "mapper_or_error", None)
-    return m if m is not None else field.mapper
+@dataclass
+class _Job:
+    key: tuple
+    array: Any
+    spin: int
+    alm: Any = None
+
+
+def _declared_spin(array):
+    """``spin`` from the dtype metadata of a numpy map; device tensors carry none."""
+    meta = getattr(getattr(array, "dtype", None), "metadata", None)
+    return None if not meta else meta.get("spin")
+
+
+def _plan(fields, data, progress):
+    """One pass over ``data``: validate every map against its field and file it under its mapper (first-seen order of mappers)."""
+    jobs, per_mapper = [], {}
+    for n, (key, entry) in enumerate(data.items(), 1):
+        if progress is not None:
+            progress.update(n, len(data))
+        name = key[0]
+        if name not in fields:
+            raise ValueError(f"unknown field name: {name}")
+        field = fields[name]
+        array = getattr(entry, "array", entry)
+        declared = _declared_spin(array)
+        if declared is None:
+            if hasattr(getattr(array, "dtype", None), "metadata"):
+                update_metadata(array, spin=field.spin)
+        elif declared != field.spin:
+            raise ValueError(f"spin mismatch for field {name!r}: map has spin {declared}, field has spin {field.spin}")
+        job = _Job(key, array, field.spin)
+        jobs.append(job)
+        mapper = getattr(field, "mapper_or_error", None) or field.mapper
+        per_mapper.setdefault(id(mapper), (mapper, []))[1].append(job)
+    return jobs, list(per_mapper.values())
 
 
 def transform(fields, data, *, out=None, progress=None, device=None):
@@ -22,39 +58,15 @@ def transform(fields, data, *, out=None, progress=None, device=None):
     ``angular_power_spectra`` takes as they are."""
     if out is None:
         out = TocDict()
-    items = []
-    current, total = 0, len(data)
-    for (k, i), m in data.items():
-        current += 1
-        if progress is not None:
-            progress.update(current, total)
-        m = getattr(m, "array", m)
-        try:
-            field = fields[k]
-        except KeyError:
-            msg = f"unknown field name: {k}"
-            raise ValueError(msg) from None
-        s = field.spin
-        m_spin = (m.dtype.metadata or {}).get("spin")
-        if m_spin is None:
-            update_metadata(m, spin=s)
-        elif m_spin != s:
-            msg = f"spin mismatch for field {k!r}: map has spin {m_spin}, field has spin {s}"
-            raise ValueError(msg)
-        items.append(((k, i), m, s, _mapper_of(field)))
-    groups = {}
-    for it in items:
-        groups.setdefault(id(it[3]), []).append(it)
-    alms = {}
-    for group in groups.values():
-        mapper = group[0][3]
+    jobs, batches = _plan(fields, data, progress)
+    for mapper, batch in batches:
         if hasattr(mapper, "transform_many"):
-            kw = {} if device is None else {"device": device}
-            res = mapper.transform_many([it[1] for it in group], [it[2] for it in group], **kw)
-        else:
-            res = [mapper.transform(it[1], spin=it[2]) for it in group]
-        for it, a in zip(group, res):
-            alms[it[0]] = a
-    for key, _, _, _ in items:
-        out[key] = alms[key]
+            extra = {} if device is None else {"device": device}
+            alms = mapper.transform_many([j.array for j in batch], [j.spin for j in batch], **extra)
+        else:  # a mapper of the reference: map by map, as it does
+            alms = [mapper.transform(j.array, spin=j.spin) for j in batch]
+        for job, alm in zip(batch, alms):
+            job.alm = alm
+    for job in jobs:
+        out[job.key] = job.alm
     return out

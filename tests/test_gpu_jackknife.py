@@ -190,3 +190,32 @@ def test_region_alms_use_each_fields_own_mapper(oracle):
             ref = ref * np.concatenate([fl[m:] for m in range(LMAX + 1)])
         np.testing.assert_allclose(full[name, 0].numpy(), ref, atol=1e-11 * np.abs(ref).max())
         assert full[name, 0].dtype.metadata["deconv"] == (name == "B")
+
+
+def test_region_alms_load_the_datapath_weights_like_transform(oracle, tmp_path):
+    """A mapper with a configured data path weights its jackknife alms exactly as ``mapper.transform`` does, whichever of the
+    two runs first (``region_alms`` read ``mp.pixel_weights`` before anything had loaded the file; the reference
+    transforms every jackknife map through the same ``mapper.transform``, heracles/dices/jackknife.py:143-148)."""
+    import heracles_amd as hx
+    from heracles_amd import weights as hw
+
+    rng = np.random.default_rng(81)
+    npix = 12 * NSIDE**2
+    comp = 1e-2 * rng.standard_normal(hw.compressed_size(NSIDE))
+    (tmp_path / "full_weights").mkdir()
+    hw.write_compressed_weights(tmp_path / "full_weights" / hw.weights_filename(NSIDE), NSIDE, comp)
+    mapper = hx.HipHealpixMapper(NSIDE, LMAX, deconvolve=False, niter=0, datapath=tmp_path)  # has not transformed anything yet
+    assert mapper.pixel_weights is None
+    fields = {"A": types.SimpleNamespace(spin=0, mapper_or_error=mapper, mask=None),
+              "S": types.SimpleNamespace(spin=2, mapper_or_error=mapper, mask=None)}
+    a = rng.standard_normal(npix)
+    a.dtype = np.dtype(a.dtype, metadata={"spin": 0, "nside": NSIDE})
+    s = rng.standard_normal((2, npix))
+    s.dtype = np.dtype(s.dtype, metadata={"spin": 2, "nside": NSIDE})
+    jk = 1.0 + (np.arange(npix) % 3)
+    full = hx.region_alms(fields, {("A", 0): a, ("S", 0): s}, jk).full()
+    assert mapper.pixel_weights is not None
+    np.testing.assert_array_equal(full["A", 0].numpy(), np.asarray(mapper.transform(a, spin=0)))
+    np.testing.assert_array_equal(full["S", 0].numpy(), np.asarray(mapper.transform(s, spin=2)))
+    ref = oracle.map2alm(np.asarray(a)[None], NSIDE, LMAX, spin=0, pix_weights=oracle.expand_full_weights(NSIDE, comp))[0]
+    np.testing.assert_allclose(full["A", 0].numpy(), ref, atol=1e-11 * np.abs(ref).max())

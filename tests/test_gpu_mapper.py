@@ -417,3 +417,35 @@ def test_hx_copy_between_host_and_device():
         np.testing.assert_array_equal(back, src)
     with pytest.raises(ValueError):
         hx._lib.copy(np.empty(3), np.empty(4))
+
+
+def test_transform_many_takes_device_maps_and_warns_like_transform(oracle):
+    """``transform_many`` with device-resident maps and the default ``device=None`` returns device tensors, as
+    ``transform`` does for such maps; ``heracles_amd.transform`` accepts them (no dtype metadata to read); the unit-weight note
+    of ``transform`` is not lost on the batched route."""
+    import types
+    import warnings
+
+    import torch
+
+    import heracles_amd as hx
+    from heracles_amd import mapper as hm
+
+    nside, lmax = 16, 24
+    rng = np.random.default_rng(5)
+    t = rng.standard_normal(12 * nside**2)
+    qu = rng.standard_normal((2, 12 * nside**2))
+    mp = hx.HipHealpixMapper(nside, lmax, deconvolve=False, niter=0)
+    hm._warned_unit_weights = False
+    with pytest.warns(UserWarning, match="unit quadrature"):
+        got = mp.transform_many([torch.as_tensor(t).cuda(), torch.as_tensor(qu).cuda()], [0, 2])
+    assert all(torch.is_tensor(a) and a.is_cuda for a in got)
+    r0 = oracle.map2alm(t[None], nside, lmax, spin=0)[0]
+    r2 = oracle.map2alm(qu, nside, lmax, spin=2)
+    np.testing.assert_allclose(got[0].cpu().numpy(), r0, atol=1e-11 * np.abs(r0).max())
+    np.testing.assert_allclose(got[1].cpu().numpy(), r2, atol=1e-11 * np.abs(r2).max())
+    fields = {"POS": types.SimpleNamespace(spin=0, mapper_or_error=mp)}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = hx.transform(fields, {("POS", 0): torch.as_tensor(t).cuda()})
+    np.testing.assert_allclose(out["POS", 0].cpu().numpy(), r0, atol=1e-11 * np.abs(r0).max())

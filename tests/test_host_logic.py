@@ -327,3 +327,15 @@ def test_transform_driver_mirrors_heracles_transform():
     update_metadata(bad, spin=2)
     with pytest.raises(ValueError, match="spin mismatch for field 'POS': map has spin 2, field has spin 0"):
         transform(fields, {("POS", 0): bad})
+
+
+def test_configured_datapath_without_a_weight_file_raises(tmp_path):
+    """healpy raises when ``use_pixel_weights=True`` finds no file under ``datapath`` (heracles/healpy.py:183-189 passes both):
+    a configured data path that holds no file for the resolution must not fall back to unit weights silently."""
+    import heracles_amd as hx
+
+    mapper = hx.HipHealpixMapper(8, 12, deconvolve=False, niter=0, datapath=tmp_path)
+    with pytest.raises(FileNotFoundError, match="healpix_full_weights_nside_0008.fits"):
+        mapper._load_weights()
+    with pytest.raises(FileNotFoundError):
+        mapper.transform(mapper.create())
