@@ -188,10 +188,15 @@ def main():
         pw = hxw.expand_pixel_weights(nside, 1e-3 * np.random.default_rng(7).standard_normal(hxw.compressed_size(nside)), device=dev)
 
     def step():
+        # N > 1: the exchange goes out in two parts -- the spin-2 shards as soon as their transform is done, the spin-0 transform runs
+        # under that transfer, then the spin-0 shards; all_pairs_cl starts the spin-2 x spin-2 blocks of its tiles when the first part has
+        # landed (ShardedTwoPoint.exchange_begin; nothing is communicated at N = 1)
         if n2:
             plan.map2alm(maps2.view(2 * n2, npix), 2, pix_weights=pw, out=alm2.view(2 * n2, nlm))
+        work.exchange_begin(2)
         if n0:
             plan.map2alm(maps0, 0, pix_weights=pw, out=alm0)
+        work.exchange_begin(0)
         return work.all_pairs_cl()  # rank 0: every Cl block on the host
 
     def sync():
@@ -260,7 +265,7 @@ def main():
         mf_model = plan.mfma_flops(spin, ncomp) if ncomp else 0.0
         sec = ms_ * 1e-3
         exe = (mf + vf) * args.steps / sec / 1e12 if sec > 0 else 0.0
-        traffic, tpath = pmc_traffic("hx::k_legendre_pipe<%d" % spin)
+        traffic, tpath = pmc_traffic("hx::k_legendre_duo<%d" % spin)
         return {"kernel": kernel, "bound": "mfma", "achieved": exe, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": exe / FP64_PEAK_TFLOPS,
                 "achieved_is": "EXECUTED FP64 flops, counted by the kernel itself (matrix instructions actually issued -- stages whose "
@@ -278,30 +283,46 @@ def main():
                 "launches": nl_, "avg_launch_ms": ms_ / nl_ if nl_ else None}
 
     nc0, nc2 = n0, 2 * n2
-    roofline = roof("legendre_analysis_s2", "hx::k_legendre_pipe<2,*>", n2 * 3 * F0, 2, nc2)
-    roofline_s0 = roof("legendre_analysis_s0", "hx::k_legendre_pipe<0,*>", n0 * F0, 0, nc0)
+    roofline = roof("legendre_analysis_s2", "hx::k_legendre_duo<2,*>", n2 * 3 * F0, 2, nc2)
+    roofline_s0 = roof("legendre_analysis_s0", "hx::k_legendre_duo<0,*>", n0 * F0, 0, nc0)
 
     # ---- N > 1: the FIXED job (one set of maps) on all N GPUs, sharded by m (MShardedTwoPoint): ring modes of the rank's maps ->
     # all-to-all by m-range -> full-batch Legendre on the rank's range -> partial Cl -> all-reduce.  Reported as value_strong. ----
-    strong = None
+    strong, verify_multi = None, None
     if world > 1:
         del maps0, maps2  # (the weak-scaling maps are not needed any more at N > 1: room for the fixed job's buffers)
         torch.cuda.empty_cache()
+        cdev = "cpu" if share else dev
+
+        def seeded_maps(gs):
+            """maps of the fixed job's global indices gs (spin-0 first, as the routes hold them), seeded by the index: the same
+            map on whichever rank and route it lands"""
+            m0 = [g for g in gs if per_set[g] == 0]
+            m2 = [g for g in gs if per_set[g] != 0]
+            t0 = torch.empty((len(m0), npix), dtype=torch.float64, device=dev)
+            t2 = torch.empty((len(m2), 2, npix), dtype=torch.float64, device=dev)
+            for k, g in enumerate(m0):
+                t0[k] = torch.randn(npix, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(7000 + g))
+            for k, g in enumerate(m2):
+                t2[k] = torch.randn((2, npix), dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(7000 + g))
+            return t0, t2
+
         # (a failure of this leg -- it has never run over RCCL, only over gloo and in a one-GPU rehearsal -- must not cost the line
-        # its weak-scaling value: an exception every rank raises alike is reported instead of the figure)
+        # its weak-scaling value: the ranks agree on success before every collective (guard=True) and an exception is raised by
+        # all of them alike and reported instead of the figure)
+        cls_strong = None
         try:
             ms = hxd.MShardedTwoPoint(per_set, world, rank, nlm, lmax, hxd.HipStages(plan, dev))
-            s0 = torch.randn((ms.n0_of[rank], npix), dtype=torch.float64, device=dev, generator=gen)
-            s2 = torch.randn((ms.n2_of[rank], 2, npix), dtype=torch.float64, device=dev, generator=gen)
+            s0, s2 = seeded_maps(ms.local_maps)
             for _ in range(max(args.warmup, 1)):
-                ms.run(s0, s2, pix_weights=pw)
+                ms.run(s0, s2, pix_weights=pw, guard=True)
             sync()
             ts = time.perf_counter()
             for _ in range(args.steps):
-                cls_strong = ms.run(s0, s2, pix_weights=pw)
+                cls_strong = ms.run(s0, s2, pix_weights=pw, guard=True)
             sync()
             dts = time.perf_counter() - ts
-            tt = torch.tensor([dts], dtype=torch.float64, device="cpu" if share else dev)
+            tt = torch.tensor([dts], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dts = float(tt.item())
             strong = {"value": len(ms.pairs) * args.steps / dts, "unit": "map->Cl pairs/s", "ms_per_step": dts / args.steps * 1e3,
@@ -313,6 +334,51 @@ def main():
             torch.cuda.empty_cache()
         except Exception as exc:  # noqa: BLE001
             strong = {"value": None, "error": f"{type(exc).__name__}: {exc}"[:400]}
+            cls_strong = None
+
+        # ---- verification at N > 1 (outside every timed region): the SAME seeded job through the all-gather route, whose rows on
+        # rank 0 are compared (i) with the m-sharded route's spectra and (ii) with direct sums over the gathered alms ----
+        if not args.no_verify:
+            try:
+                wk = hxd.ShardedTwoPoint(per_set, world, rank, nlm, lmax)
+                v0, v2 = seeded_maps(wk.local_maps)
+                a0, a2 = wk.local_alm_views(dev)
+                if v2.shape[0]:
+                    plan.map2alm(v2.view(-1, npix), 2, pix_weights=pw, out=a2.view(-1, nlm))
+                wk.exchange_begin(2)
+                if v0.shape[0]:
+                    plan.map2alm(v0, 0, pix_weights=pw, out=a0)
+                wk.exchange_begin(0)
+                rows = wk.all_pairs_cl()
+                if rank == 0:
+                    verify_multi = {"routes": None, "cl_vs_direct_sum": None}
+                    if cls_strong is not None:
+                        e = float(np.abs(cls_strong - rows).max() / np.abs(rows).max())
+                        verify_multi["routes"] = {"m_sharded_vs_all_gather_max_err_over_max": e, "spectra": int(rows.shape[0]), "tolerance": 1e-10}
+                    wv = torch.full((nlm,), 2.0, dtype=torch.float64, device=dev)
+                    wv[: lmax + 1] = 1.0
+                    idx_l = torch.cat([torch.arange(m, lmax + 1, device=dev) for m in range(lmax + 1)])
+                    bufv, ecl, nchk = wk.buffer(), 0.0, 0
+                    nm = len(per_set)
+                    for (i, j) in [(0, 0), (0, nm - 1), (nm - 1, nm - 1), (nm // 2, nm // 2 + 1)]:
+                        for ka, ca in enumerate(wk.comps_of_map[i]):
+                            for kb, cb in enumerate(wk.comps_of_map[j]):
+                                a, b_ = bufv[ca], bufv[cb]
+                                ref = torch.zeros(lmax + 1, dtype=torch.float64, device=dev).index_add_(0, idx_l, wv * (a.real * b_.real + a.imag * b_.imag))
+                                ref = (ref / (2.0 * torch.arange(lmax + 1, device=dev) + 1.0)).cpu().numpy()
+                                got = rows[wk.row0[i, j] + ka * len(wk.comps_of_map[j]) + kb]
+                                ecl = max(ecl, float(np.abs(got - ref).max() / np.abs(ref).max()))
+                                nchk += 1
+                    verify_multi["cl_vs_direct_sum"] = {"max_err_over_max": ecl, "spectra_checked": nchk, "tolerance": 1e-11}
+                    verify_multi["ok"] = bool(ecl <= 1e-11 and (verify_multi["routes"] is None or verify_multi["routes"]["m_sharded_vs_all_gather_max_err_over_max"] <= 1e-10))
+                    verify_multi["what"] = ("the fixed job (maps seeded by their global index) through both routes: spectra of the m-sharded route (all-to-all "
+                                            "+ all-reduce) against the rows of the all-gather route on rank 0, and map pairs of the latter against direct sums "
+                                            "over the gathered alms")
+                    del wv, idx_l
+                del v0, v2, wk
+            except Exception as exc:  # noqa: BLE001
+                verify_multi = {"ok": False, "error": f"{type(exc).__name__}: {exc}"[:400]}
+            torch.cuda.empty_cache()
 
     out = None
     if rank == 0:
@@ -456,8 +522,10 @@ def main():
                        "pix_weights": ("synthetic array without symmetry (generic path)" if args.generic_weights else "synthetic weights in healpy's compressed format, expanded to the full sky (symmetric like healpy's)") + ", applied in the timed path",
                        "parallelism": (f"maps dealt to {world} GPUs by cost, RCCL all-gather of alms, tiled pair split"
                                        if world > 1 else "1 GPU")},
-            "verified": (verify or {}).get("ok") if verify is not None else None,
+            "verified": (None if verify is None and verify_multi is None
+                         else bool((verify is None or verify.get("ok")) and (world == 1 or (verify_multi or {}).get("ok")))),
             "verify": verify,
+            "verify_multi": verify_multi,
             "value_strong": strong.get("value") if strong else None,
             "strong_scaling": strong,
             "value_host_to_host": host_leg["value"] if host_leg else None,

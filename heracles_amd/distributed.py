@@ -2,11 +2,18 @@
 (backend "nccl" = RCCL over xGMI on ROCm).
 
 The (field, bin) maps of a job are dealt to the ranks by descending cost (a spin-2 map costs three
-spin-0 transforms).  Every rank transforms its own maps straight into its slice of ONE buffer, the
+spin-0 transforms).  Every rank transforms its own maps straight into its slices of ONE buffer, the
 one exchange step of the path is an in-place all-gather of that buffer (every cross pair needs both
 partners), and the upper triangle of map pairs is cut into tiles that are dealt to the ranks by
 descending size, so that a rank reads ~ nmaps / sqrt(world) distinct alms instead of all of them.
 The small Cl blocks are collected on rank 0.  With world == 1 nothing is copied or communicated.
+
+The buffer is laid out spin by spin -- [spin-2 shards of all ranks | spin-0 shards of all ranks] -- so that
+the exchange can be issued in two parts (round 4): ``exchange_begin(2)`` right after the spin-2 transform
+(asynchronous: the spin-0 transform runs under it), ``exchange_begin(0)`` after the spin-0 transform, and
+``all_pairs_cl`` computes the spin-2 x spin-2 blocks of its tiles as soon as the first part has landed, the
+blocks with a spin-0 partner after the second.  ``exchange()`` (both parts, blocking) is the round-3 behaviour;
+the gathered bytes are the same either way.
 """
 
 from __future__ import annotations
@@ -72,12 +79,22 @@ class ShardedTwoPoint:
                         [g for g in range(nmaps) if self.owner[g] == r and self.spins[g] != 0] for r in range(world)]
         self.ncomp_of = [sum(ncomp(g) for g in ms) for ms in self.maps_of]
         self.ncomp_max = max(self.ncomp_of) if self.ncomp_of else 0
+        self.n0_of = [sum(1 for g in ms if self.spins[g] == 0) for ms in self.maps_of]
+        self.c2_of = [nc - n0 for nc, n0 in zip(self.ncomp_of, self.n0_of)]
+        self.n0_max, self.c2_max = max(self.n0_of, default=0), max(self.c2_of, default=0)
+        # rows of the gather buffer: region of spin 2 = rows [0, world c2_max), rank r's shard at r c2_max; region of spin 0 behind it
+        self.region = {2: (0, self.c2_max), 0: (world * self.c2_max, self.n0_max)}
+        self.nbuf_rows = world * (self.c2_max + self.n0_max)
         self.slot = {}  # map -> first global component index in the gather buffer
         for r, ms in enumerate(self.maps_of):
-            c = r * self.ncomp_max
+            c0, c2 = self.region[0][0] + r * self.n0_max, self.region[2][0] + r * self.c2_max
             for g in ms:
-                self.slot[g] = c
-                c += ncomp(g)
+                if self.spins[g] == 0:
+                    self.slot[g] = c0
+                    c0 += 1
+                else:
+                    self.slot[g] = c2
+                    c2 += 2
         self.comps_of_map = {g: list(range(self.slot[g], self.slot[g] + ncomp(g))) for g in range(nmaps)}
         # global output rows: map pairs in combinations_with_replacement order, component block row-major
         self.pairs = map_pairs(nmaps)
@@ -100,7 +117,12 @@ class ShardedTwoPoint:
         self.rows_of = [[self.row0[p] + k for p in ps for k in range(ncomp(p[0]) * ncomp(p[1]))] for ps in self.pairs_of]
         self.my_pairs = self.pairs_of[rank]
         self.my_cpairs = [(a, b) for (i, j) in self.my_pairs for a in self.comps_of_map[i] for b in self.comps_of_map[j]]
+        # the component pairs of this rank whose partners are both spin-2 (ready after the first part of the exchange), and the rest
+        n2rows = world * self.c2_max
+        self._first = [k for k, (a, b) in enumerate(self.my_cpairs) if a < n2rows and b < n2rows]
+        self._second = [k for k, (a, b) in enumerate(self.my_cpairs) if not (a < n2rows and b < n2rows)]
         self._buf = None
+        self._pending = {}
 
     # -- local transforms write here -------------------------------------------------
     @property
@@ -109,7 +131,8 @@ class ShardedTwoPoint:
         return self.maps_of[self.rank]
 
     def buffer(self, device=None):
-        """(world * ncomp_max, nlm) complex128: slice r * ncomp_max ... holds the alms of rank r's maps."""
+        """(world * (c2_max + n0_max), nlm) complex128: the spin-2 shards of all ranks (rank r at row r c2_max), then the spin-0 shards
+        (rank r at row world c2_max + r n0_max); ``comps_of_map`` gives the rows of a map."""
         import torch
 
         if self._buf is not None and device is not None:
@@ -117,49 +140,76 @@ class ShardedTwoPoint:
             if want.type != self._buf.device.type or (want.index is not None and want.index != self._buf.device.index):
                 self._buf = None  # asked for another device
         if self._buf is None:
-            self._buf = torch.zeros((self.world * self.ncomp_max, self.nlm), dtype=torch.complex128, device=device)
+            self._buf = torch.zeros((self.nbuf_rows, self.nlm), dtype=torch.complex128, device=device)
         return self._buf
 
     def local_alm_views(self, device=None):
         """(alm0, alm2): views into this rank's slice of the gather buffer with shapes (n0, nlm) and (n2, 2, nlm):
         map2alm writes its result straight into the buffer that is then all-gathered."""
         buf = self.buffer(device)
-        n0 = sum(1 for g in self.local_maps if self.spins[g] == 0)
-        n2 = len(self.local_maps) - n0
-        base = self.rank * self.ncomp_max
-        a0 = buf[base : base + n0]
-        a2 = buf[base + n0 : base + n0 + 2 * n2].view(n2, 2, self.nlm)
+        n0, c2 = self.n0_of[self.rank], self.c2_of[self.rank]
+        b0, b2 = self.region[0][0] + self.rank * self.n0_max, self.region[2][0] + self.rank * self.c2_max
+        a0 = buf[b0 : b0 + n0]
+        a2 = buf[b2 : b2 + c2].view(c2 // 2, 2, self.nlm)
         return a0, a2
 
     # -- the exchange step -------------------------------------------------------------
-    def exchange(self):
-        """In-place all-gather of the alm shards (RCCL over xGMI; over gloo -- CPU tests, one-GPU rehearsals --
-        device tensors go through host copies, because gloo gathers host memory only)."""
-        if self.world == 1:
+    def exchange_begin(self, spin):
+        """Start the in-place all-gather of one spin's shards (RCCL over xGMI: asynchronous, on the communicator's stream -- the
+        caller goes on to queue its next transform, which runs under the transfer; over gloo -- CPU tests, one-GPU rehearsals --
+        device tensors go through host copies and the part is complete on return).  Call after that spin's transform was queued."""
+        if self.world == 1 or spin in self._pending:
             return
         import torch
         import torch.distributed as dist
 
+        row0, per = self.region[spin]
+        if per == 0:
+            self._pending[spin] = None
+            return
         buf = self.buffer()
         if buf.is_cuda:
-            # the transforms ran on libhxsht's own stream (possibly asynchronously, hx_set_async): they must have written
-            # this rank's slice before the collective reads it
+            # the transform ran on libhxsht's own stream (possibly asynchronously, hx_set_async): it must have written this rank's
+            # shard before the collective reads it
             from . import _lib
 
             _lib.synchronize()
-        flat = torch.view_as_real(buf)  # complex dtypes are gathered through their real view (same bytes)
-        mine = flat[self.rank * self.ncomp_max : (self.rank + 1) * self.ncomp_max]
+        flat = torch.view_as_real(buf[row0 : row0 + self.world * per])  # complex dtypes are gathered through their real view (same bytes)
+        mine = flat[self.rank * per : (self.rank + 1) * per]
         if dist.get_backend(self.group) == "gloo":
-            host = flat.new_empty(flat.shape, device="cpu")
-            dist.all_gather_into_tensor(host, mine.cpu().contiguous(), group=self.group)
-            flat.copy_(host)
+            if buf.is_cuda:
+                host = flat.new_empty(flat.shape, device="cpu")
+                dist.all_gather_into_tensor(host, mine.cpu().contiguous(), group=self.group)
+                flat.copy_(host)
+                self._pending[spin] = None
+            else:
+                self._pending[spin] = dist.all_gather_into_tensor(flat, mine, group=self.group, async_op=True)
         else:
             if buf.is_cuda:
                 torch.cuda.current_stream(buf.device).synchronize()
-            dist.all_gather_into_tensor(flat, mine, group=self.group)  # in place: mine is flat's own slice
+            self._pending[spin] = dist.all_gather_into_tensor(flat, mine, group=self.group, async_op=True)  # in place: mine is flat's own slice
+
+    def exchange_wait(self, spin):
+        """Block until the part started by ``exchange_begin(spin)`` has landed (starting it now if it was not)."""
+        if self.world == 1:
+            return
+        import torch
+
+        self.exchange_begin(spin)
+        h = self._pending.pop(spin)
+        if h is not None:
+            h.wait()
+        buf = self.buffer()
         if buf.is_cuda:
             # libhxsht launches on its own stream: the gathered shards must have landed first
             torch.cuda.current_stream(buf.device).synchronize()
+
+    def exchange(self):
+        """In-place all-gather of all alm shards, complete on return (both parts of the exchange)."""
+        for spin in (2, 0):
+            self.exchange_begin(spin)
+        for spin in (2, 0):
+            self.exchange_wait(spin)
 
     # -- all pairs -----------------------------------------------------------------------
     def all_pairs_cl(self):
@@ -168,11 +218,21 @@ class ShardedTwoPoint:
         (combinations_with_replacement order) then component block; None elsewhere."""
         import torch
 
-        self.exchange()
         buf = self.buffer()
         comps = [buf[k] for k in range(buf.shape[0])]
-        mine = self.kernel(comps, self.my_cpairs, self.lmax) if self.my_cpairs else np.zeros((0, self.lmax + 1))
-        mine = np.ascontiguousarray(mine, dtype=np.float64)
+        if self.world == 1 or not self._first or not self._second:
+            self.exchange()
+            mine = self.kernel(comps, self.my_cpairs, self.lmax) if self.my_cpairs else np.zeros((0, self.lmax + 1))
+            mine = np.ascontiguousarray(mine, dtype=np.float64)
+        else:
+            # the spin-2 x spin-2 blocks of this rank's tiles as soon as the spin-2 shards are here, the rest after the spin-0 shards
+            self.exchange_begin(2)
+            self.exchange_begin(0)
+            mine = np.empty((len(self.my_cpairs), self.lmax + 1))
+            self.exchange_wait(2)
+            mine[self._first] = self.kernel(comps, [self.my_cpairs[k] for k in self._first], self.lmax)
+            self.exchange_wait(0)
+            mine[self._second] = self.kernel(comps, [self.my_cpairs[k] for k in self._second], self.lmax)
         if self.world == 1:
             out = np.empty((self.nrows, self.lmax + 1))
             out[self.rows_of[0]] = mine
@@ -329,6 +389,12 @@ class MShardedTwoPoint:
         self.sets = order_sets(lmax, world)      # (first, count, step) of every rank: the same for both spins
         self.orders = self.sets[rank]
         self._alm = None
+        import inspect
+
+        try:  # (a kernel without the keyword sums over all orders: the alms are zero outside this rank's)
+            self._kernel_takes_m_range = "m_range" in inspect.signature(self.kernel).parameters
+        except (TypeError, ValueError):
+            self._kernel_takes_m_range = False
 
     @property
     def local_maps(self):
@@ -367,35 +433,62 @@ class MShardedTwoPoint:
             o += sizes_out[s]
         return out
 
-    def run(self, maps0, maps2, pix_weights=None, ring_weights=None):
+    def _agree(self, err, guard):
+        """End of a local phase: with ``guard`` every rank learns whether ANY rank failed in it (one tiny all-reduce) and all raise
+        together -- a rank that raised alone would leave the others blocked in the next collective."""
+        if not guard or self.world == 1:
+            if err is not None:
+                raise err
+            return
+        import torch
+        import torch.distributed as dist
+
+        gloo = dist.get_backend(self.group) == "gloo"
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device="cpu" if gloo else self.stages.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        if int(flag.item()):
+            raise err if err is not None else RuntimeError("MShardedTwoPoint: another rank failed in this phase")
+
+    def run(self, maps0, maps2, pix_weights=None, ring_weights=None, guard=False):
         """maps0 (n0_local, npix), maps2 (n2_local, 2, npix): this rank's maps.  Returns on EVERY rank the array
-        (n_component_pairs_total, lmax + 1) ordered by map pair (combinations_with_replacement order) then component block."""
+        (n_component_pairs_total, lmax + 1) ordered by map pair (combinations_with_replacement order) then component block.
+        ``guard``: agree on success across the ranks before each collective (see ``_agree``)."""
         import torch
 
         n0, n2 = self.n0_of[self.rank], self.n2_of[self.rank]
-        npix = maps0.shape[-1] if n0 else maps2.shape[-1]
-        cat = torch.cat if hasattr(maps0 if n0 else maps2, "data_ptr") else np.concatenate
-        parts = ([maps0.reshape(n0, npix)] if n0 else []) + ([maps2.reshape(2 * n2, npix)] if n2 else [])
-        local = cat(parts) if len(parts) > 1 else parts[0]
-        send = self.stages.ring_modes(local, self.sets, pix_weights=pix_weights, ring_weights=ring_weights)
-        recv = self._all_to_all(send)
-        size = self.stages.modes_size(self.orders[1])
-        blocks0, blocks2 = [], []
-        for s in range(self.world):
-            for c in range(self.ncomp_of[s]):
-                (blocks0 if c < self.n0_of[s] else blocks2).append(recv[s][c * size : (c + 1) * size])
-        alm = self.buffer()
-        self.stages.legendre(0, blocks0, self.orders, alm[: self.nc0])
-        self.stages.legendre(2, blocks2, self.orders, alm[self.nc0 :])
-        self.stages.synchronize()
-        comps = [alm[k] for k in range(alm.shape[0])]
-        # this rank's orders only: the alms are zero elsewhere; a kernel that takes the set does not even read them there
-        first, count, step = self.orders
+        err, send = None, None
         try:
-            part = self.kernel(comps, self.cpairs, self.lmax, m_range=(first, first + max(count - 1, 0) * step + (1 if count else 0), step))
-        except TypeError:
-            part = self.kernel(comps, self.cpairs, self.lmax)
-        part = np.ascontiguousarray(part, dtype=np.float64)
+            npix = maps0.shape[-1] if n0 else maps2.shape[-1]
+            cat = torch.cat if hasattr(maps0 if n0 else maps2, "data_ptr") else np.concatenate
+            parts = ([maps0.reshape(n0, npix)] if n0 else []) + ([maps2.reshape(2 * n2, npix)] if n2 else [])
+            local = cat(parts) if len(parts) > 1 else parts[0]
+            send = self.stages.ring_modes(local, self.sets, pix_weights=pix_weights, ring_weights=ring_weights)
+        except Exception as exc:  # noqa: BLE001
+            err = exc
+        self._agree(err, guard)
+        recv = self._all_to_all(send)
+        err, part = None, None
+        try:
+            size = self.stages.modes_size(self.orders[1])
+            blocks0, blocks2 = [], []
+            for s in range(self.world):
+                for c in range(self.ncomp_of[s]):
+                    (blocks0 if c < self.n0_of[s] else blocks2).append(recv[s][c * size : (c + 1) * size])
+            alm = self.buffer()
+            self.stages.legendre(0, blocks0, self.orders, alm[: self.nc0])
+            self.stages.legendre(2, blocks2, self.orders, alm[self.nc0 :])
+            self.stages.synchronize()
+            comps = [alm[k] for k in range(alm.shape[0])]
+            # this rank's orders only: the alms are zero elsewhere; a kernel that takes the set does not even read them there
+            first, count, step = self.orders
+            if self._kernel_takes_m_range:
+                part = self.kernel(comps, self.cpairs, self.lmax, m_range=(first, first + max(count - 1, 0) * step + (1 if count else 0), step))
+            else:
+                part = self.kernel(comps, self.cpairs, self.lmax)
+            part = np.ascontiguousarray(part, dtype=np.float64)
+        except Exception as exc:  # noqa: BLE001
+            err = exc
+        self._agree(err, guard)
         if self.world > 1:
             import torch.distributed as dist
 

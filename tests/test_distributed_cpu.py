@@ -71,6 +71,59 @@ def _worker(rank, world, port, lmax, outdir):
     dist.destroy_process_group()
 
 
+def _worker_split(rank, world, port, lmax, outdir):
+    """The exchange issued in two parts, as bench.py's step does it: spin-2 shards right after "their transform", the spin-0
+    transform "under" the transfer, spin-0 shards, then the pairs -- against the single blocking exchange on a second object."""
+    import torch
+    import torch.distributed as dist
+
+    from heracles_amd.distributed import ShardedTwoPoint
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nlm = (lmax + 1) * (lmax + 2) // 2
+    split = ShardedTwoPoint(SPINS, world, rank, nlm, lmax, kernel=_kernel)
+    whole = ShardedTwoPoint(SPINS, world, rank, nlm, lmax, kernel=_kernel)
+    for _ in range(2):
+        a0, a2 = split.local_alm_views("cpu")
+        k2 = 0
+        for g in split.local_maps:  # "spin-2 transform"
+            if split.spins[g] == 2:
+                a2[k2] = _alm_of_map(g, 2, lmax)
+                k2 += 1
+        split.exchange_begin(2)
+        k0 = 0
+        for g in split.local_maps:  # "spin-0 transform", while the first part is in flight
+            if split.spins[g] == 0:
+                a0[k0] = _alm_of_map(g, 0, lmax)
+                k0 += 1
+        split.exchange_begin(0)
+        res = split.all_pairs_cl()
+        _fill_local(whole, lmax)
+        whole.exchange()
+        assert not whole._pending
+        ref = whole.all_pairs_cl()
+        assert torch.equal(split.buffer(), whole.buffer())  # the gathered bytes are the same either way
+        if rank == 0:
+            np.testing.assert_array_equal(res, ref)
+    if rank == 0:
+        np.save(os.path.join(outdir, "split.npy"), res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_split_async_exchange_equals_single_exchange(tmp_path, world):
+    """the all-gather issued as two asynchronous parts (spin 2 first, the spin-0 transform under it) gives bitwise
+    the buffer and the spectra of the single blocking gather."""
+    import torch.multiprocessing as mp
+
+    lmax = 12
+    mp.spawn(_worker_split, args=(world, _free_port(), lmax, str(tmp_path)), nprocs=world, join=True)
+    np.testing.assert_array_equal(np.load(tmp_path / "split.npy"), _reference(lmax))
+
+
 def _reference(lmax):
     """All spectra from the definition, map pairs in combinations_with_replacement order."""
     rows = []
@@ -128,7 +181,7 @@ def test_partition_covers_all_pairs():
             assert rows == list(range(ws[0].nrows))
             # every component slot is owned by exactly one map, shards do not overlap
             slots = sorted(c for g in range(len(spins)) for c in ws[0].comps_of_map[g])
-            assert len(slots) == len(set(slots)) and max(slots) < world * ws[0].ncomp_max
+            assert len(slots) == len(set(slots)) and max(slots) < ws[0].nbuf_rows
             if world == 8 and len(spins) == 20:
                 # tiles: a rank reads far fewer than all 30 components
                 touched = [len({c for pr in w.my_cpairs for c in pr}) for w in ws]

@@ -172,3 +172,30 @@ def test_m_sharded_ranks_on_one_gpu_equal_single_process(tmp_path, world):
         got = np.load(tmp_path / f"ms_{r}.npy")
         assert got.shape == ref.shape
         np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
+
+
+def test_bench_rehearsal_two_ranks_verifies_itself(tmp_path):
+    """``bench.py --gpus 2`` launched as the driver launches it, two ranks SHARING the one GPU over gloo (HX_BENCH_SHARE_GPU=1), at a
+    small size: the line must carry ``verify_multi`` -- the m-sharded route's spectra against the all-gather route's rows for the same
+    seeded maps (1e-10) and map pairs against direct sums over the gathered alms -- and ``verified: true`` (the first
+    run on N ranks yields parity evidence, not only a number)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HX_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--nside", "128", "--lmax", "160", "--nbins", "3", "--no-cpu-baseline", "--no-mixmat", "--no-single", "--no-host-leg"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert out["value_strong"] is not None, out["strong_scaling"]
+    vm = out["verify_multi"]
+    assert vm["ok"], vm
+    assert vm["routes"]["m_sharded_vs_all_gather_max_err_over_max"] <= 1e-10
+    assert vm["cl_vs_direct_sum"]["max_err_over_max"] <= 1e-11
+    assert out["verified"] is True

@@ -437,7 +437,7 @@ def test_transform_many_takes_device_maps_and_warns_like_transform(oracle):
     qu = rng.standard_normal((2, 12 * nside**2))
     mp = hx.HipHealpixMapper(nside, lmax, deconvolve=False, niter=0)
     hm._warned_unit_weights = False
-    with pytest.warns(UserWarning, match="unit quadrature"):
+    with pytest.warns(RuntimeWarning, match="unit quadrature"):
         got = mp.transform_many([torch.as_tensor(t).cuda(), torch.as_tensor(qu).cuda()], [0, 2])
     assert all(torch.is_tensor(a) and a.is_cuda for a in got)
     r0 = oracle.map2alm(t[None], nside, lmax, spin=0)[0]
