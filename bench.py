@@ -496,16 +496,28 @@ def main():
             ell = np.arange(L + 1)
             wl = 4 * np.pi * 0.35 * np.exp(-ell * (ell + 1) / 3000.0) + 1e-3 / (1.0 + ell) ** 2
             hx.mixmat_eb(wl[:65], l1max=64, l2max=64)  # warm-up (module load)
-            hx._lib.profile_enable(True)
-            hx._lib.profile_reset()
-            tm = time.perf_counter()
-            mm = hx.mixmat_eb(wl)
-            mix_s = time.perf_counter() - tm
-            hx._lib.profile_enable(False)
+            # median of three builds, host -> host each (a fresh 0.9 GB numpy array per call, as the reference returns one: its first touch
+            # is part of the figure and varies with the state of the host's page cache; all three are listed)
+            mix_all = []
+            for _ in range(3):
+                hx._lib.profile_enable(True)
+                hx._lib.profile_reset()
+                tm = time.perf_counter()
+                mm = hx.mixmat_eb(wl)
+                mix_all.append(time.perf_counter() - tm)
+                hx._lib.profile_enable(False)
+            mix_s = float(np.median(mix_all))
             ng, gms = hx._lib.profile_get("mixmat_gemm")
             N = (3 * L) // 2 + 1
             gflop = 2.0 * (L + 1) ** 2 * N * 2  # two products
-            mix = {"L": L, "seconds": mix_s, "gemm_ms": gms, "gemm_tflops_algorithmic": gflop / (gms * 1e-3) / 1e12 if gms else None,
+            nb_, kpad_ = (L + 1 + 127) // 128, (N + 31) // 32 * 32
+            xflop = 2.0 * 128 * 128 * kpad_ * (nb_ * (nb_ + 1) // 2) * 2  # what k_mixmat_gemm executes: the upper triangle of 128 x 128 tiles, padded nodes
+            mix = {"L": L, "seconds": mix_s, "seconds_all": mix_all, "statistic": "median of 3", "gemm_ms": gms,
+                   "gemm_tflops_executed": xflop / (gms * 1e-3) / 1e12 if gms else None,
+                   "gemm_frac_of_fp64_mfma_peak": xflop / (gms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if gms else None,
+                   "gemm_tflops_algorithmic": gflop / (gms * 1e-3) / 1e12 if gms else None,
+                   "gemm_tflops_algorithmic_is": "SURVEY 8d's 2 (l1max + 1)(l2max + 1) N per product / kernel time: the symmetric product is computed for the "
+                                                 "upper triangle of tiles only, so this exceeds what the matrix pipe executes (gemm_tflops_executed) -- not a utilisation",
                    "checksum": float(np.abs(mm[2] - (mm[0] - mm[1])).max())}
         peaks = hx._lib.measure_peaks()
         out = {

@@ -103,7 +103,7 @@ struct OutView {
 int copy_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t on = nullptr);  // on: another stream than the library's
 void stager_reset_events();  // hx_init on another device: recreate the staging events there
 hipStream_t copy_stream();  // second stream of the library (uploads that overlap its kernels); nullptr if it cannot be created
-int copy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int copy_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t on = nullptr);  // on: another stream than the library's (the caller orders it behind the producer)
 
 int finish_call();  // synchronise unless async
 

@@ -19,7 +19,6 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int GB = 128;   // block tile edge (l, l')
 constexpr int GK = 32;    // nodes per k tile
-constexpr int GLD = GK + 2;
 
 // ---- Gauss-Legendre nodes: Newton on P_n, one thread per node pair ---------------------
 __global__ void k_gauss_legendre(int n, double *__restrict__ x, double *__restrict__ w)
@@ -38,7 +37,9 @@ __global__ void k_gauss_legendre(int n, double *__restrict__ x, double *__restri
         dp = n * (t * p1 - p0) / (t * t - 1.0);
         double dt = p1 / dp;
         t -= dt;
-        if (fabs(dt) <= 2e-16 * fabs(t)) break;
+        // (|t| <= 1: an absolute threshold.  Relative to |t| the nodes next to 0 never met it and every thread ran all ten O(n) sweeps:
+        // 7.7 ms of the L = 6144 build; converged Newton steps do not move the node any more)
+        if (fabs(dt) <= 4e-16) break;
     }
     {
         double p0 = 1.0, p1 = t;
@@ -105,16 +106,28 @@ __global__ void k_weight_xi(int l3max, int n, const double *__restrict__ x, cons
 }
 
 // ---- symmetric GEMM: G[i][j] = colscale[j] * sum_k T[i][k] s[k] T[j][k] -----------------
-// T: [rows_pad][kpad] (zero padded), block tiles (bi <= bj) from `tiles`; writes both halves.
-__global__ __launch_bounds__(256) void k_mixmat_gemm(const double *__restrict__ T, int kpad,
-                                                     const double *__restrict__ s,
-                                                     const int2 *__restrict__ tiles, int n1, int n2,
-                                                     const double *__restrict__ colscale,
-                                                     double *__restrict__ G, long long ldg)
+// T: [rows_pad][kpad] (zero padded), block tiles (bi <= bj) from `tiles` ((-1, -1) = padding entry); writes both halves.
+// Round 4: the round-1 kernel held 350 registers (one work-group per CU) and loaded, stored and multiplied in
+// sequence: 41 TFLOP/s executed.  Now
+//   * two work-groups per CU (<= 256 registers, 72 KiB of LDS each): one group's loads, LDS stores and barrier sit under the other's
+//     matrix instructions, and two waves per SIMD keep the matrix pipe at 97 % of its rate (tools/ubench_mblock.hip);
+//   * the k tiles (16 nodes) are double-buffered in LDS: the global loads of tile t + 1 are requested before the matrix instructions of
+//     tile t and stored behind them -- one barrier per tile;
+//   * every LDS operand read is 128 bits wide: the two nodes of a lane's double2 feed two consecutive matrix instructions (the
+//     contraction over the nodes may take them in any order, as long as A and B agree: instruction h of a pair contracts the nodes
+//     8 q + 2 (lane >> 4) + h); rows are padded to 18 doubles, which spreads the 16 rows of a read over all 64 banks.
+constexpr int GKT = 16;          // nodes per k tile of the GEMM (GK = 32 stays the padding unit of the tables)
+constexpr int GLT = GKT + 2;     // LDS row stride in doubles
+__global__ __launch_bounds__(256, 2) void k_mixmat_gemm(const double *__restrict__ T, int kpad,
+                                                        const double *__restrict__ s,
+                                                        const int2 *__restrict__ tiles, int n1, int n2,
+                                                        const double *__restrict__ colscale,
+                                                        double *__restrict__ G, long long ldg)
 {
-    __shared__ double As[GB][GLD], Bs[GB][GLD];
+    __shared__ double As[2][GB][GLT], Bs[2][GB][GLT];
     const int2 tl = tiles[blockIdx.x];
     const int bi = tl.x, bj = tl.y;
+    if (bi < 0) return;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1;
     double4_t acc[4][4];
@@ -123,34 +136,78 @@ __global__ __launch_bounds__(256) void k_mixmat_gemm(const double *__restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-    const double *Ta = T + (long long)bi * GB * kpad, *Tb = T + (long long)bj * GB * kpad;
-    for (int k0 = 0; k0 < kpad; k0 += GK) {
+    // staging: element pair e = t + 256 u of the 128 x 16 tile: row e >> 3, nodes 2 (e & 7), + 1 (8 threads read 128 contiguous bytes of a row)
+    const int srow = t >> 3, sc2 = (t & 7) * 2;
+    // buffer loads: the row block of a tile is a buffer resource (scalar registers), a thread brings one 32-bit byte offset per row
+    // quarter and the k tile is the scalar offset -- no address arithmetic on the vector unit (as 64-bit per-thread addresses every load
+    // cost a vector instruction in the matrix stream: ~12 cycles of pipe time each)
+    const __amdgpu_buffer_rsrc_t Ra = __builtin_amdgcn_make_buffer_rsrc((void *)(T + (long long)bi * GB * kpad), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Rb = __builtin_amdgcn_make_buffer_rsrc((void *)(T + (long long)bj * GB * kpad), 0, 0x7fffffff, 0x00020000);
+    const int so = (int)(((long long)srow * kpad + sc2) * sizeof(double)), sq = (int)((long long)32 * kpad * sizeof(double));
+    const int so1 = so + sq, so2 = so + 2 * sq, so3 = so + 3 * sq;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    auto bload = [](const __amdgpu_buffer_rsrc_t r, int voff, int soff) __attribute__((always_inline)) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        double2 d;
+        __builtin_memcpy(&d, &v, sizeof(d));
+        return d;
+    };
+    // (no lambdas around the staging registers, no arithmetic on them before the store: either makes hipcc keep them in scratch and wait
+    // for the loads at the top of the loop)
+    double2 va0, va1, va2, va3, vb0, vb1, vb2, vb3, sa;
+#define HX_GLOAD(k0)                                                                      \
+    do {                                                                                  \
+        sa = *reinterpret_cast<const double2 *>(s + (k0) + sc2);                          \
+        va0 = bload(Ra, so, (k0) * 8);                                                    \
+        va1 = bload(Ra, so1, (k0) * 8);                                                   \
+        va2 = bload(Ra, so2, (k0) * 8);                                                   \
+        va3 = bload(Ra, so3, (k0) * 8);                                                   \
+        vb0 = bload(Rb, so, (k0) * 8);                                                    \
+        vb1 = bload(Rb, so1, (k0) * 8);                                                   \
+        vb2 = bload(Rb, so2, (k0) * 8);                                                   \
+        vb3 = bload(Rb, so3, (k0) * 8);                                                   \
+    } while (0)
+#define HX_LSTORE(buf)                                                                                               \
+    do {                                                                                                             \
+        *reinterpret_cast<double2 *>(&As[buf][srow][sc2]) = make_double2(va0.x * sa.x, va0.y * sa.y);                \
+        *reinterpret_cast<double2 *>(&As[buf][srow + 32][sc2]) = make_double2(va1.x * sa.x, va1.y * sa.y);           \
+        *reinterpret_cast<double2 *>(&As[buf][srow + 64][sc2]) = make_double2(va2.x * sa.x, va2.y * sa.y);           \
+        *reinterpret_cast<double2 *>(&As[buf][srow + 96][sc2]) = make_double2(va3.x * sa.x, va3.y * sa.y);           \
+        *reinterpret_cast<double2 *>(&Bs[buf][srow][sc2]) = vb0;                                                     \
+        *reinterpret_cast<double2 *>(&Bs[buf][srow + 32][sc2]) = vb1;                                                \
+        *reinterpret_cast<double2 *>(&Bs[buf][srow + 64][sc2]) = vb2;                                                \
+        *reinterpret_cast<double2 *>(&Bs[buf][srow + 96][sc2]) = vb3;                                                \
+    } while (0)
+    HX_GLOAD(0);
+    HX_LSTORE(0);
+    __syncthreads();
+    const int nk = kpad / GKT;
+    const int arow = wr * 64 + (lane & 15), brow = wc * 64 + (lane & 15), kcol = 2 * (lane >> 4);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const int knext = (kt + 1 < nk ? kt + 1 : kt) * GKT;  // (unconditional: the last iteration re-requests its own tile)
+        HX_GLOAD(knext);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = t + 256 * u, row = e >> 4, c2 = (e & 15) * 2;
-            const double2 sa = *reinterpret_cast<const double2 *>(s + k0 + c2);
-            double2 va = *reinterpret_cast<const double2 *>(Ta + (long long)row * kpad + k0 + c2);
-            const double2 vb = *reinterpret_cast<const double2 *>(Tb + (long long)row * kpad + k0 + c2);
-            As[row][c2] = va.x * sa.x; As[row][c2 + 1] = va.y * sa.y;
-            Bs[row][c2] = vb.x;        Bs[row][c2 + 1] = vb.y;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < GK / 4; ++kk) {
-            double a[4], b[4];
+        for (int q = 0; q < GKT / 8; ++q) {
+            double2 a[4], b[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                a[i] = As[wr * 64 + i * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
-                b[i] = Bs[wc * 64 + i * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+                a[i] = *reinterpret_cast<const double2 *>(&As[buf][arow + 16 * i][8 * q + kcol]);
+                b[i] = *reinterpret_cast<const double2 *>(&Bs[buf][brow + 16 * i][8 * q + kcol]);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(h ? a[i].y : a[i].x, h ? b[j].y : b[j].x, acc[i][j], 0, 0, 0);
         }
+        HX_LSTORE(buf ^ 1);  // (buffer buf ^ 1 was last read in iteration kt - 1, closed by its barrier)
         __syncthreads();
     }
+#undef HX_GLOAD
+#undef HX_LSTORE
     // D layout: row = (lane>>4) + 4*reg, col = lane&15
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -250,10 +307,33 @@ static int mix_ctx_init(MixCtx &c, int l1max, int l2max, int l3max)
     c.rows_pad = (c.L + 1 + GB - 1) / GB * GB;
     HX_TRY(gl_nodes_device(c.n, c.gl));
     HX_TRY(c.s.alloc(sizeof(double) * c.kpad));
-    std::vector<int2> tiles;
+    // Tile order: work-groups go to the 8 XCDs round-robin (blockIdx % 8), and an XCD runs 64 of them at a time (32 CUs x 2).  The
+    // upper triangle is cut into super-tiles of 8 x 4 block tiles (12 row blocks of T for 32 tiles), the super-tiles are dealt to the
+    // XCDs (largest first, to the least loaded) and every XCD walks its own list: the tiles that run side by side on an XCD share their
+    // rows of T through its L2 instead of each streaming 2 x 9.5 MB from memory.  (-1, -1) pads the shorter lists.
     const int nb = c.rows_pad / GB;
-    for (int i = 0; i < nb; ++i)
-        for (int j = i; j < nb; ++j) tiles.push_back(make_int2(i, j));
+    constexpr int SR = 8, SC = 4, NX = 8;
+    std::vector<std::vector<int2>> supers;
+    for (int I = 0; I < nb; I += SR)
+        for (int J = I / SC * SC; J < nb; J += SC) {
+            std::vector<int2> m;
+            for (int i = I; i < std::min(I + SR, nb); ++i)
+                for (int j = std::max(J, i); j < std::min(J + SC, nb); ++j) m.push_back(make_int2(i, j));
+            if (!m.empty()) supers.push_back(m);
+        }
+    std::stable_sort(supers.begin(), supers.end(), [](const std::vector<int2> &a, const std::vector<int2> &b) { return a.size() > b.size(); });
+    std::vector<std::vector<int2>> per(NX);
+    for (const auto &m : supers) {
+        int x = 0;
+        for (int q = 1; q < NX; ++q)
+            if (per[q].size() < per[x].size()) x = q;
+        per[x].insert(per[x].end(), m.begin(), m.end());
+    }
+    size_t longest = 0;
+    for (const auto &l : per) longest = std::max(longest, l.size());
+    std::vector<int2> tiles(longest * NX, make_int2(-1, -1));
+    for (int x = 0; x < NX; ++x)
+        for (size_t k = 0; k < per[x].size(); ++k) tiles[k * NX + x] = per[x][k];
     c.ntiles = tiles.size();
     HX_TRY(upload_vec(c.d_tiles, tiles));
     std::vector<double> cs(c.rows_pad, 0.0);
@@ -421,14 +501,32 @@ extern "C" int hx_mixmat_eb(const double *cl, int ncl, int l1max, int l2max, int
     HX_TRY(stage_cl(cl, ncl, l3max, d_cl));
     OutView vo;
     HX_TRY(vo.bind(out, sizeof(double) * 3 * sz));
-    int ab[2][2] = {{2, 2}, {2, -2}};
-    double *outs[2] = {vo.as<double>(), vo.as<double>() + 2 * sz};
-    HX_TRY(mixmat_core(d_cl.as<double>(), l1max, l2max, l3max, 2, ab, outs));
-    hipLaunchKernelGGL(k_eb_combine, dim3(1024), dim3(256), 0, rt().stream, (long long)sz, vo.as<double>(),
-                       vo.as<double>() + sz, vo.as<double>() + 2 * sz);
+    double *o0 = vo.as<double>(), *o1 = o0 + sz, *o2 = o0 + 2 * sz;
+    hipStream_t st = rt().stream;
+    MixCtx c;
+    HX_TRY(mix_ctx_init(c, l1max, l2max, l3max));
+    HX_TRY(mix_ctx_mask(c, d_cl.as<double>()));
+    // b = G^{(2,-2)} first: it IS the third matrix, so a host destination receives it (second stream, ~5 ms at L = 6144) while the
+    // product a = G^{(2,2)} is computed; then [0] = (a + b) / 2, [1] = (a - b) / 2
+    HX_TRY(mix_ctx_product(c, 3, o2));
+    HX_TRY(mix_ctx_table(c, 2));
+    hipStream_t cs = vo.host ? copy_stream() : nullptr;
+    if (cs) {
+        static hipEvent_t ev = nullptr;
+        if (!ev) HX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HX_HIP(hipEventRecord(ev, st));
+        HX_HIP(hipStreamWaitEvent(cs, ev, 0));
+    }
+    HX_TRY(mix_ctx_product(c, 2, o0));
+    if (cs) HX_TRY(copy_d2h((double *)vo.host + 2 * sz, o2, sizeof(double) * sz, cs));  // (complete on return; the product above runs meanwhile)
+    hipLaunchKernelGGL(k_eb_combine, dim3(1024), dim3(256), 0, st, (long long)sz, o0, o1, o2);
     HX_HIP(hipGetLastError());
-    HX_TRY(vo.finish());
-    HX_HIP(hipStreamSynchronize(rt().stream));
+    if (cs) {
+        HX_TRY(copy_d2h(vo.host, o0, sizeof(double) * 2 * sz));
+    } else {
+        HX_TRY(vo.finish());
+    }
+    HX_HIP(hipStreamSynchronize(st));  // the context (tables, weights) dies with this scope
     return HX_OK;
 }
 
