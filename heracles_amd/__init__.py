@@ -14,11 +14,13 @@ from .mapper import HipHealpixMapper
 from .mapping import transform
 from .sht import Plan, get_plan
 from .transforms import cl2corr, corr2cl, gauss_legendre, wigner_d_table
+from .fits import read_vmap
 from .twopoint import (
     alm2cl,
     alm2cl_pairs,
     alm2lmax,
     angular_power_spectra,
+    apply_mixing_matrix,
     debias_cls,
     mixing_matrices,
     mixmat,
@@ -31,5 +33,5 @@ __all__ = [
     "alm2cl", "alm2cl_pairs", "alm2lmax", "angular_power_spectra", "debias_cls",
     "mixing_matrices", "mixmat", "mixmat_eb", "cl2corr", "corr2cl", "gauss_legendre",
     "wigner_d_table", "naturalspice", "Result", "TocDict", "toc_match", "update_metadata", "DeviceArray",
-    "jackknife_cls", "region_alms", "RegionAlms", "transform",
+    "jackknife_cls", "region_alms", "RegionAlms", "transform", "read_vmap", "apply_mixing_matrix",
 ]

@@ -401,6 +401,36 @@ extern "C" int hx_ud_grade(int nside_in, int nside_out, int nmaps, const double 
     return finish_call();
 }
 
+// NESTED <-> RING reordering of full-sky maps (healpy.read_map converts a NESTED file to RING: heracles/io.py:365 reads visibility maps
+// through it).  One thread per output pixel: out[p] = in[other index of p].
+__global__ __launch_bounds__(256) void k_reorder(int order, int to_ring, const double *__restrict__ in, double *__restrict__ out)
+{
+    const long long npix = 12ll << (2 * order);
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const long long q = to_ring ? ring2nest_dev(order, p) : nest2ring_dev(order, p);
+    out[(long long)blockIdx.y * npix + p] = in[(long long)blockIdx.y * npix + q];
+}
+
+extern "C" int hx_reorder(int nside, int to_ring, int nmaps, const double *in, double *out)
+{
+    HX_TRY(ensure_ready());
+    if (!nside_pow2(nside)) return fail(HX_ERR_ARG, "hx_reorder: nside %d must be a power of 2 (<= 8192)", nside);
+    if (nmaps < 0 || (nmaps > 0 && (!in || !out)) || in == out) return fail(HX_ERR_ARG, "hx_reorder: bad arguments (in place is not supported)");
+    if (nmaps == 0) return HX_OK;
+    const long long npix = 12ll * nside * nside;
+    InView vin;
+    OutView vout;
+    HX_TRY(vin.bind(in, sizeof(double) * npix * nmaps));
+    HX_TRY(vout.bind(out, sizeof(double) * npix * nmaps));
+    int o = 0;
+    while ((1 << o) < nside) ++o;
+    hipLaunchKernelGGL(k_reorder, dim3((unsigned)((npix + 255) / 256), nmaps), dim3(256), 0, rt().stream, o, to_ring ? 1 : 0, vin.as<double>(), vout.as<double>());
+    HX_HIP(hipGetLastError());
+    HX_TRY(vout.finish());
+    return finish_call();
+}
+
 // =====================================================================================
 // healpy pixel weights: compressed octant -> full-sky array (heracles/healpy.py:183-189, use_pixel_weights=True)
 // =====================================================================================

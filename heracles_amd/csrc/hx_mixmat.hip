@@ -530,6 +530,49 @@ extern "C" int hx_mixmat_eb(const double *cl, int ncl, int l1max, int l2max, int
     return HX_OK;
 }
 
+// y[v][i] = sum_j M[i][j] x[v][j]: the products of heracles.twopoint.apply_mixing_matrix (heracles/twopoint.py:497-524: `_M @ cl` per
+// component spectrum).  One wave per row, the row read once for all nvec <= 4 vectors (HBM-bound: 8 B per matrix element).
+__global__ __launch_bounds__(256) void k_matvec(int n, int m, long long ld, const double *__restrict__ M, int nvec, const double *__restrict__ x,
+                                                double *__restrict__ y)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const double *r = M + (long long)row * ld;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j = lane; j < m; j += 64) {
+        const double a = r[j];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (v < nvec) acc[v] = fma(a, x[(long long)v * m + j], acc[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        double t = acc[v];
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);  // fixed order: bitwise repeatable
+        if (lane == 0 && v < nvec) y[(long long)v * n + row] = t;
+    }
+}
+
+extern "C" int hx_matvec(int n, int m, const double *M, int nvec, const double *x, double *y)
+{
+    HX_TRY(ensure_ready());
+    if (n < 0 || m < 0 || nvec < 0 || ((n > 0 && m > 0 && nvec > 0) && (!M || !x || !y))) return fail(HX_ERR_ARG, "hx_matvec: bad arguments");
+    if (n == 0 || nvec == 0) return HX_OK;
+    InView vm, vx;
+    OutView vy;
+    HX_TRY(vm.bind(M, sizeof(double) * (size_t)n * std::max(m, 1)));
+    HX_TRY(vx.bind(x, sizeof(double) * (size_t)nvec * std::max(m, 1)));
+    HX_TRY(vy.bind(y, sizeof(double) * (size_t)nvec * n));
+    for (int v0 = 0; v0 < nvec; v0 += 4) {
+        const int nv = std::min(4, nvec - v0);
+        hipLaunchKernelGGL(k_matvec, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, rt().stream, n, m, (long long)m, vm.as<double>(), nv,
+                           vx.as<double>() + (size_t)v0 * m, vy.as<double>() + (size_t)v0 * n);
+        HX_HIP(hipGetLastError());
+    }
+    HX_TRY(vy.finish());
+    return finish_call();
+}
+
 // Mixing matrices of nmask mask spectra for one (l1max, l2max, l3max): nodes, Wigner-d tables and tile list are built once,
 // then every mask costs its node weights and one GEMM per product.  Replaces the serial loop of convolvecl calls in
 // heracles.twopoint.mixing_matrices (heracles/twopoint.py:354-397).

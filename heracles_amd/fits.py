@@ -408,3 +408,60 @@ class MapFits(_FitsDict):
 
 class AlmFits(_FitsDict):
     _reader, _writer = staticmethod(_read_complex), staticmethod(_write_complex)
+
+
+# ---- visibility maps (heracles/io.py:360-381) ------------------------------------------------------------------------------------
+UNSEEN = -1.6375e30  # healpy.UNSEEN
+
+
+def read_vmap(filename, nside=None, field=0, *, transform=False, lmax=None, pixwin=None, datapath=None, niter=3):
+    """``heracles.io.read_vmap`` (heracles/io.py:360-381): column ``field`` of the first HEALPix table of the file as a RING map
+    (a NESTED file is reordered, as ``hp.read_map`` does), unseen pixels set to zero, changed to ``nside`` with a warning if the file has
+    another resolution (``hx_ud_grade``); ``transform=True``: its alms up to ``lmax`` (healpy's default: 3 nside - 1) with pixel weights,
+    divided by the pixel window (``hx_map2alm`` with ``fl = 1 / pw``).
+
+    Not in the reference's signature, because healpy's data files are not available here: ``pixwin=(pw_T, pw_P)`` (the window table; else
+    healpy's, if installed), ``datapath`` (directory of healpy's weight files; without one the quadrature uses unit weights and
+    ``niter`` Jacobi iterations -- healpy's ``map2alm`` default is three)."""
+    from warnings import warn
+
+    from .mapper import pixel_window, ud_grade
+
+    hdus = [(h, off) for h, off in _scan(filename) if str(h.get("XTENSION", "")).strip() == "BINTABLE"]
+    if not hdus:
+        raise ValueError(f"{filename}: no binary table extension")
+    h, off = hdus[0]
+    cols = _read_map(filename, h, off)
+    cols = np.atleast_2d(np.asarray(cols))
+    if not 0 <= field < cols.shape[0]:
+        raise IndexError(f"{filename}: field {field} of {cols.shape[0]}")
+    vmap = np.array(cols[field], dtype=np.float64)
+    npix = vmap.shape[0]
+    nside_in = int(round((npix / 12) ** 0.5))
+    if 12 * nside_in * nside_in != npix:
+        raise ValueError(f"{filename}: {npix} pixels are not a full-sky HEALPix map")
+    if str(h.get("ORDERING", "RING")).strip().upper().startswith("NEST"):
+        ring = np.empty_like(vmap)
+        _lib.ensure_init()
+        _lib.check(_lib.load().hx_reorder(nside_in, 1, 1, _lib.ptr(vmap), _lib.ptr(ring)))
+        vmap = ring
+    # set unseen pixels to zero.  hp.read_map has already replaced everything its mask_bad accepts (|v - UNSEEN| <= 1e-15 + 1e-5 |UNSEEN|:
+    # the float32 image of UNSEEN in the files healpy writes by default) with the exact UNSEEN the reference compares to -- healpy's
+    # source is not available here: restated from its published behaviour, unpinned
+    vmap[np.abs(vmap - UNSEEN) <= 1e-15 + 1e-5 * abs(UNSEEN)] = 0.0
+    if nside is not None and nside != nside_in:
+        warn(f"{filename}: changing NSIDE to {nside}")  # vmap is provided at a different resolution
+        vmap = ud_grade(vmap, nside)
+    if transform:
+        from . import sht
+        from .weights import load_pixel_weights
+
+        nside_t = int(round((vmap.shape[0] / 12) ** 0.5))
+        lmax_t = 3 * nside_t - 1 if lmax is None else int(lmax)
+        pw = pixel_window(nside_t, lmax_t, pixwin)[0]
+        weights = load_pixel_weights(datapath, nside_t) if datapath is not None else None
+        if datapath is not None and weights is None:
+            raise FileNotFoundError(f"no pixel-weight file for NSIDE={nside_t} under datapath {datapath!r}")
+        plan = sht.get_plan(nside_t, lmax_t)
+        vmap = plan.map2alm(vmap[None], 0, pix_weights=weights, fl=1.0 / pw, niter=0 if weights is not None else niter)[0]
+    return vmap

@@ -426,3 +426,66 @@ def mixing_matrices(fields, cls, *, l1max=None, l2max=None, l3max=None, bins=Non
         for ctx in contexts.values():
             ctx.close()
     return out
+
+
+# ---- heracles.twopoint.apply_mixing_matrix (heracles/twopoint.py:497-524) ---------------------------------------------
+def _result_axis_array(result, name):
+    """``get_result_array(result, name)[0]`` of heracles/result.py:53-72: the named angular array of the first ell axis, with the
+    reference's defaults (ell = arange, lower = ell, upper = lower shifted by one, weight = ones)."""
+    arr = getattr(result, name, None)
+    n = result.shape[result.axis[0]]
+    if arr is None:
+        if name in ("ell", "lower"):
+            src = getattr(result, "ell", None) if name == "lower" else None
+            arr = np.arange(n) if src is None else src
+        elif name == "upper":
+            lo = _result_axis_array(result, "lower")
+            arr = np.append(lo[1:], lo[-1] + 1)
+        elif name == "weight":
+            arr = np.ones(n)
+        else:
+            raise ValueError(f"cannot make default for array {name!r}")
+    return arr[0] if isinstance(arr, tuple) else arr
+
+
+def _matvec(M, xs):
+    """rows of ``M @ x`` for every spectrum x of ``xs`` (hx_matvec: the matrix -- numpy array or device tensor / DeviceArray -- is
+    read once for up to four spectra)."""
+    M = getattr(M, "tensor", M)
+    xs = np.ascontiguousarray(np.atleast_2d(xs), dtype=np.float64)
+    n, m = M.shape
+    if xs.shape[-1] != m:
+        raise ValueError(f"matrix of shape {(n, m)} applied to spectra of length {xs.shape[-1]}")
+    M = M.contiguous() if hasattr(M, "data_ptr") else np.ascontiguousarray(M, dtype=np.float64)
+    out = np.empty((xs.shape[0], n))
+    _lib.ensure_init()
+    _lib.check(_lib.load().hx_matvec(n, m, _lib.ptr(M), xs.shape[0], _lib.ptr(xs), _lib.ptr(out)))
+    return out
+
+
+def apply_mixing_matrix(d, M):
+    """Apply (inverse) mixing matrices to data spectra, key by key: ``heracles.twopoint.apply_mixing_matrix``
+    (heracles/twopoint.py:497-524).  Spin-2 x spin-2 blocks use the three matrices of ``mixmat_eb`` as the reference does --
+    EE' = M0 EE + M1 BB, BB' = M1 EE + M0 BB, EB' = M2 EB, BE' = M2 BE --, every other block is ``M @ cl`` per component
+    spectrum; the angular arrays of the result follow the matrix' output axis.  The products run on the GPU (hx_matvec); matrices
+    may be numpy arrays or device-resident (``DeviceArray`` / torch tensors)."""
+    from dataclasses import replace
+
+    out = {}
+    for key, res in d.items():
+        dtype = np.asarray(res.array).dtype
+        s1, s2 = res.spin
+        cl = np.atleast_2d(np.asarray(res.array))
+        mm = M[key]
+        mat = getattr(mm.array, "tensor", mm.array)  # (a DeviceArray's tensor: indexable per matrix)
+        if s1 != 0 and s2 != 0:
+            a = _matvec(mat[0], np.stack([cl[0, 0], cl[1, 1]]))   # M0 EE, M0 BB
+            b = _matvec(mat[1], np.stack([cl[0, 0], cl[1, 1]]))   # M1 EE, M1 BB
+            c = _matvec(mat[2], np.stack([cl[0, 1], cl[1, 0]]))   # M2 EB, M2 BE
+            new = np.array([[a[0] + b[1], c[0]], [c[1], b[0] + a[1]]])
+        else:
+            new = np.squeeze(_matvec(mat, cl.reshape(-1, cl.shape[-1])))
+        new = np.array(list(new), dtype=dtype)
+        out[key] = replace(res, array=new, ell=_result_axis_array(mm, "ell"), lower=_result_axis_array(mm, "lower"),
+                           upper=_result_axis_array(mm, "upper"), weight=_result_axis_array(mm, "weight"))
+    return out

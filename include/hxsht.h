@@ -180,6 +180,11 @@ int hx_alm_subtract(int64_t n, const double *full, int nsub, const double *const
  * Gauss-Legendre nodes, Wigner-d tables and the GEMM tile list are built ONCE per (l1max, l2max, l3max); every mask streamed
  * through then costs its node weights and one GEMM per product (for jobs whose matrices do not fit in memory together).
  * kind 1: spin (0,0), 2: spin (0,2)/(2,0) -> out (l1max+1, l2max+1); 4: spin (2,2) -> out (3, l1max+1, l2max+1). */
+/* The products of heracles.twopoint.apply_mixing_matrix (heracles/twopoint.py:497-524, `_M @ cl`): y[v] = M x[v] for nvec spectra
+ * x [nvec][m] -> y [nvec][n], M row-major (n, m); every pointer host or device (a device-resident matrix is read once per four
+ * spectra: HBM-bound).  Rows are summed in a fixed order (bitwise repeatable).                                        */
+int hx_matvec(int n, int m, const double *M, int nvec, const double *x, double *y);
+
 typedef struct hx_mixctx hx_mixctx;
 hx_mixctx *hx_mixctx_create(int l1max, int l2max, int l3max);
 int hx_mixctx_apply(hx_mixctx *ctx, const double *cl, int ncl, int kind, double *out);
@@ -234,6 +239,11 @@ int hx_map_values(int nside, int64_t n, const double *lon, const double *lat, in
  * children; upgrade = replication.  in: [nmaps][12 nside_in^2], out: [nmaps][12 nside_out^2].
  * Both nside must be powers of two (healpy raises ValueError otherwise; here HX_ERR_ARG).   */
 int hx_ud_grade(int nside_in, int nside_out, int nmaps, const double *in, double *out);
+
+/* NESTED <-> RING reordering of full-sky maps: what hp.read_map does to a NESTED file before heracles.io.read_vmap sees it
+ * (heracles/io.py:360-365).  to_ring != 0: in is NESTED, out RING; 0: the reverse.  in / out [nmaps][12 nside^2], host or device,
+ * not in place.  nside a power of two.                                                                              */
+int hx_reorder(int nside, int to_ring, int nmaps, const double *in, double *out);
 
 /* healpy's pixel-weight files (`healpix_full_weights_nside_NNNN.fits`, the data hp.map2alm(use_pixel_weights=True, datapath=...)
  * of heracles/healpy.py:183-189 reads): expansion of the compressed half-quadrant weights -- hx_pixel_weights_size(nside) =

@@ -1,0 +1,142 @@
+"""Round-4 widening: ``heracles.io.read_vmap`` (heracles/io.py:360-381) and ``heracles.twopoint.apply_mixing_matrix``
+(heracles/twopoint.py:497-524) on the GPU path, against the composition of their parts evaluated by the oracle / by the reference's own
+arithmetic in numpy.  healpy files (weights, pixel window) are not available: the window table is synthetic, the files are written with
+this package's FITS writer in the layouts healpy produces (float64 / float32 columns, RING / NESTED) -- file-level parity with
+healpy-written files is unpinned, as for the other FITS tables."""
+
+import types
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_healpix_table(path, columns, nside, ordering="RING", repeat=1024, width=8):
+    """A HEALPix map file in the layout healpy.write_map produces: one table, vector columns of `repeat` pixels per row."""
+    from heracles_amd import fits as hf
+
+    cols = np.atleast_2d(np.asarray(columns, dtype=np.float64))
+    ncols, npix = cols.shape
+    rep = min(repeat, npix)
+    nrows = npix // rep
+    table = np.empty((nrows, ncols, rep), dtype=">f8" if width == 8 else ">f4")
+    for c in range(ncols):
+        table[:, c, :] = cols[c].reshape(nrows, rep)
+    hf._new_file(path, True)
+    extra = [hf._card("PIXTYPE", "HEALPIX"), hf._card("ORDERING", ordering), hf._card("NSIDE", nside), hf._card("FIRSTPIX", 0),
+             hf._card("LASTPIX", npix - 1), hf._card("INDXSCHM", "IMPLICIT"), hf._card("OBJECT", "FULLSKY")]
+    cards = [hf._card("XTENSION", "BINTABLE", "binary table extension"), hf._card("BITPIX", 8), hf._card("NAXIS", 2),
+             hf._card("NAXIS1", ncols * rep * width), hf._card("NAXIS2", nrows), hf._card("PCOUNT", 0), hf._card("GCOUNT", 1),
+             hf._card("TFIELDS", ncols)]
+    for c in range(ncols):
+        cards += [hf._card(f"TTYPE{c + 1}", f"COL{c + 1}"), hf._card(f"TFORM{c + 1}", f"{rep}{'D' if width == 8 else 'E'}")]
+    cards += extra
+    payload = table.tobytes()
+    with open(path, "ab") as f:
+        f.write(hf._header_bytes(cards))
+        f.write(payload)
+        f.write(b"\0" * (-len(payload) % hf.BLOCK))
+
+
+@pytest.mark.parametrize("ordering,width", [("RING", 8), ("NESTED", 4)])
+def test_read_vmap_resolution_unseen_and_transform(oracle, tmp_path, ordering, width):
+    import heracles_amd as hx
+    from heracles_amd.fits import UNSEEN
+
+    nside_file, nside, lmax = 32, 16, 30
+    rng = np.random.default_rng(3)
+    npix = 12 * nside_file**2
+    ring = rng.uniform(0.0, 1.0, npix)
+    if width == 4:
+        ring = ring.astype(np.float32).astype(np.float64)  # what a float32 file can hold
+    ring[rng.choice(npix, 200, replace=False)] = UNSEEN
+    other = rng.standard_normal(npix)
+    stored = ring if ordering == "RING" else ring[oracle.nest2ring(nside_file, np.arange(npix))]
+    stored_other = other if ordering == "RING" else other[oracle.nest2ring(nside_file, np.arange(npix))]
+    path = tmp_path / "vmap.fits"
+    _write_healpix_table(path, [stored_other, stored], nside_file, ordering=ordering, width=width)
+    # as stored, at the file's resolution: unseen pixels are zero, NESTED files come back in RING order
+    same = hx.read_vmap(path, field=1)
+    want = ring.copy()
+    want[want == UNSEEN] = 0.0
+    np.testing.assert_array_equal(same, want)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        np.testing.assert_array_equal(hx.read_vmap(path, nside=nside_file, field=1), want)  # same nside: no warning, no regrade
+    # another resolution: the reference's warning, hp.ud_grade of the zero-filled map
+    with pytest.warns(UserWarning, match="changing NSIDE to 16"):
+        low = hx.read_vmap(path, nside=nside, field=1)
+    np.testing.assert_array_equal(low, oracle.ud_grade(want, nside))
+    # transform: map2alm with (here: unit) weights and three iterations, then almxfl(1 / pw)
+    pw = (np.linspace(1.0, 0.8, lmax + 1), np.linspace(1.0, 0.7, lmax + 1))
+    with pytest.warns(UserWarning, match="changing NSIDE"):
+        alm = hx.read_vmap(path, nside=nside, field=1, transform=True, lmax=lmax, pixwin=pw)
+    ref = oracle.map2alm(low[None], nside, lmax, spin=0, niter=3)[0]
+    ref = ref * np.concatenate([1.0 / pw[0][m:] for m in range(lmax + 1)])
+    np.testing.assert_allclose(alm, ref, atol=1e-11 * np.abs(ref).max())
+    with pytest.raises(IndexError):
+        hx.read_vmap(path, field=2)
+
+
+def test_reorder_round_trip_and_against_oracle(oracle):
+    import torch
+
+    import heracles_amd as hx
+
+    L = hx._lib.load()
+    for nside in (1, 2, 8, 64):
+        npix = 12 * nside**2
+        m = np.random.default_rng(nside).standard_normal((2, npix))
+        nest = np.empty_like(m)
+        hx._lib.check(L.hx_reorder(nside, 0, 2, hx._lib.ptr(m), hx._lib.ptr(nest)))
+        np.testing.assert_array_equal(nest, m[:, oracle.nest2ring(nside, np.arange(npix))])
+        back = torch.empty((2, npix), dtype=torch.float64, device="cuda")
+        dn = torch.as_tensor(nest).cuda()
+        hx._lib.check(L.hx_reorder(nside, 1, 2, hx._lib.ptr(dn), hx._lib.ptr(back)))
+        np.testing.assert_array_equal(back.cpu().numpy(), m)
+    with pytest.raises(hx.HxError):
+        hx._lib.check(L.hx_reorder(12, 1, 1, hx._lib.ptr(m), hx._lib.ptr(nest)))
+
+
+def test_apply_mixing_matrix_follows_the_reference(oracle):
+    """The arithmetic of heracles/twopoint.py:497-524 restated with numpy on the same inputs (its four cases: scalar x scalar,
+    scalar x spin-2, spin-2 x spin-2, rectangular matrices whose output axis sets the angular arrays); host and device matrices."""
+    import torch
+
+    import heracles_amd as hx
+
+    rng = np.random.default_rng(17)
+    n, m = 37, 53
+    ell_out = np.arange(n) + 0.5
+    M = {
+        ("P", "P", 0, 0): hx.Result(rng.standard_normal((n, m)), spin=(0, 0), axis=-2, ell=ell_out),
+        ("P", "G", 0, 1): hx.Result(rng.standard_normal((n, m)), spin=(0, 2), axis=-2),
+        ("G", "G", 1, 1): hx.Result(rng.standard_normal((3, n, m)), spin=(2, 2), axis=-2),
+    }
+    d = {
+        ("P", "P", 0, 0): hx.Result(rng.standard_normal(m), spin=(0, 0), axis=-1),
+        ("P", "G", 0, 1): hx.Result(rng.standard_normal((2, m)), spin=(0, 2), axis=-1),
+        ("G", "G", 1, 1): hx.Result(rng.standard_normal((2, 2, m)).astype(np.float64), spin=(2, 2), axis=-1),
+    }
+    for device in (False, True):
+        Mx = M
+        if device:
+            Mx = {k: hx.Result(hx.DeviceArray(torch.as_tensor(v.array).cuda(), {}), spin=v.spin, axis=v.axis, ell=v.ell) for k, v in M.items()}
+        got = hx.apply_mixing_matrix(d, Mx)
+        assert list(got) == list(d)
+        k = ("P", "P", 0, 0)
+        np.testing.assert_allclose(got[k].array, M[k].array @ d[k].array, rtol=1e-13, atol=1e-13)
+        assert got[k].array.shape == (n,)
+        np.testing.assert_array_equal(got[k].ell, ell_out)
+        k = ("P", "G", 0, 1)
+        np.testing.assert_allclose(got[k].array, np.array([M[k].array @ c for c in d[k].array]), rtol=1e-13, atol=1e-13)
+        np.testing.assert_array_equal(got[k].ell, np.arange(n))
+        np.testing.assert_array_equal(got[k].upper, np.arange(1, n + 1))
+        np.testing.assert_array_equal(got[k].weight, np.ones(n))
+        k = ("G", "G", 1, 1)
+        A, x = M[k].array, d[k].array
+        ref = np.array([[A[0] @ x[0, 0] + A[1] @ x[1, 1], A[2] @ x[0, 1]], [A[2] @ x[1, 0], A[1] @ x[0, 0] + A[0] @ x[1, 1]]])
+        np.testing.assert_allclose(got[k].array, ref, rtol=1e-13, atol=1e-13)
+        assert got[k].spin == (2, 2)
