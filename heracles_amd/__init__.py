@@ -22,6 +22,7 @@ from .twopoint import (
     angular_power_spectra,
     apply_mixing_matrix,
     debias_cls,
+    invert_mixing_matrix,
     mixing_matrices,
     mixmat,
     mixmat_eb,
@@ -33,5 +34,5 @@ __all__ = [
     "alm2cl", "alm2cl_pairs", "alm2lmax", "angular_power_spectra", "debias_cls",
     "mixing_matrices", "mixmat", "mixmat_eb", "cl2corr", "corr2cl", "gauss_legendre",
     "wigner_d_table", "naturalspice", "Result", "TocDict", "toc_match", "update_metadata", "DeviceArray",
-    "jackknife_cls", "region_alms", "RegionAlms", "transform", "read_vmap", "apply_mixing_matrix",
+    "jackknife_cls", "region_alms", "RegionAlms", "transform", "read_vmap", "apply_mixing_matrix", "invert_mixing_matrix",
 ]

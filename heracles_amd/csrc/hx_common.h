@@ -110,6 +110,9 @@ int finish_call();  // synchronise unless async
 // Scratch budget of one analysis m-chunk in bytes (hx_set_scratch_budget, else HX_SCRATCH_GB); 0 = automatic
 double scratch_budget_bytes();
 
+// G = T diag(s) T2^T on the FP64 matrix unit (hx_mixmat.hip; used by hx_svd.hip)
+int launch_gemm_tst(const double *T, int rows1_pad, const double *T2, int rows2_pad, int kpad, const double *s, int n1, int n2, double *G, long long ldg);
+
 // Gauss-Legendre nodes/weights into device arrays (hx_mixmat.hip)
 int launch_gauss_legendre(int n, double *d_x, double *d_w);
 

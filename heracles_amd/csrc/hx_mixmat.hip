@@ -118,7 +118,10 @@ __global__ void k_weight_xi(int l3max, int n, const double *__restrict__ x, cons
 //     8 q + 2 (lane >> 4) + h); rows are padded to 18 doubles, which spreads the 16 rows of a read over all 64 banks.
 constexpr int GKT = 16;          // nodes per k tile of the GEMM (GK = 32 stays the padding unit of the tables)
 constexpr int GLT = GKT + 2;     // LDS row stride in doubles
-__global__ __launch_bounds__(256, 2) void k_mixmat_gemm(const double *__restrict__ T, int kpad,
+// SYM: T2 == T, only tiles bi <= bj are listed and both halves are written (the mixing matrices); !SYM: G[i][j] = sum_k T[i][k] s[k] T2[j][k]
+// for every listed tile, colscale may be null (the last product of hx_pinv: V diag(1 / sigma^2) W^T).
+template <bool SYM>
+__global__ __launch_bounds__(256, 2) void k_mixmat_gemm(const double *__restrict__ T, const double *__restrict__ T2, int kpad,
                                                         const double *__restrict__ s,
                                                         const int2 *__restrict__ tiles, int n1, int n2,
                                                         const double *__restrict__ colscale,
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void k_mixmat_gemm(const double *__restrict
     // quarter and the k tile is the scalar offset -- no address arithmetic on the vector unit (as 64-bit per-thread addresses every load
     // cost a vector instruction in the matrix stream: ~12 cycles of pipe time each)
     const __amdgpu_buffer_rsrc_t Ra = __builtin_amdgcn_make_buffer_rsrc((void *)(T + (long long)bi * GB * kpad), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Rb = __builtin_amdgcn_make_buffer_rsrc((void *)(T + (long long)bj * GB * kpad), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Rb = __builtin_amdgcn_make_buffer_rsrc((void *)((SYM ? T : T2) + (long long)bj * GB * kpad), 0, 0x7fffffff, 0x00020000);
     const int so = (int)(((long long)srow * kpad + sc2) * sizeof(double)), sq = (int)((long long)32 * kpad * sizeof(double));
     const int so1 = so + sq, so2 = so + 2 * sq, so3 = so + 3 * sq;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -218,9 +221,26 @@ __global__ __launch_bounds__(256, 2) void k_mixmat_gemm(const double *__restrict
                 const int gi = bi * GB + wr * 64 + i * 16 + (lane >> 4) + 4 * r;
                 const int gj = bj * GB + wc * 64 + j * 16 + (lane & 15);
                 const double v = acc[i][j][r];
-                if (gi < n1 && gj < n2) G[(long long)gi * ldg + gj] = v * colscale[gj];
-                if (bi != bj && gj < n1 && gi < n2) G[(long long)gj * ldg + gi] = v * colscale[gi];
+                if (gi < n1 && gj < n2) G[(long long)gi * ldg + gj] = colscale ? v * colscale[gj] : v;
+                if (SYM && bi != bj && gj < n1 && gi < n2) G[(long long)gj * ldg + gi] = v * colscale[gi];
             }
+}
+
+// G (n1 x n2, leading dimension ldg) = T diag(s) T2^T for two zero-padded tables T [rows1_pad][kpad], T2 [rows2_pad][kpad] (rows padded to
+// multiples of 128, kpad to a multiple of 32) on the stream of the library (hx_svd.hip)
+int launch_gemm_tst(const double *T, int rows1_pad, const double *T2, int rows2_pad, int kpad, const double *s, int n1, int n2, double *G, long long ldg)
+{
+    std::vector<int2> tiles;
+    for (int i = 0; i < rows1_pad / GB; ++i)
+        for (int j = 0; j < rows2_pad / GB; ++j) tiles.push_back(make_int2(i, j));
+    DevBuf d_tiles;
+    HX_TRY(d_tiles.alloc(sizeof(int2) * tiles.size()));
+    HX_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice, rt().stream));
+    hipLaunchKernelGGL(k_mixmat_gemm<false>, dim3((unsigned)tiles.size()), dim3(256), 0, rt().stream, T, T2, kpad, s, d_tiles.as<int2>(), n1, n2,
+                       (const double *)nullptr, G, ldg);
+    HX_HIP(hipGetLastError());
+    HX_HIP(hipStreamSynchronize(rt().stream));  // the tile list dies with this scope
+    return HX_OK;
 }
 
 // out0 = (a + b)/2, out1 = (a - b)/2, out2 = b   (a = G22 in out0, b = G2-2 in out2)
@@ -379,7 +399,7 @@ static int mix_ctx_product(MixCtx &c, int t, double *d_out)
 {
     HX_TRY(mix_ctx_table(c, t));
     ProfScope ps("mixmat_gemm");
-    hipLaunchKernelGGL(k_mixmat_gemm, dim3((unsigned)c.ntiles), dim3(256), 0, rt().stream, c.T[t].as<double>(), c.kpad,
+    hipLaunchKernelGGL(k_mixmat_gemm<true>, dim3((unsigned)c.ntiles), dim3(256), 0, rt().stream, c.T[t].as<double>(), c.T[t].as<double>(), c.kpad,
                        c.s.as<double>(), c.d_tiles.as<int2>(), c.l1max + 1, c.l2max + 1, c.d_cs.as<double>(), d_out,
                        (long long)(c.l2max + 1));
     HX_HIP(hipGetLastError());

@@ -489,3 +489,61 @@ def apply_mixing_matrix(d, M):
         out[key] = replace(res, array=new, ell=_result_axis_array(mm, "ell"), lower=_result_axis_array(mm, "lower"),
                            upper=_result_axis_array(mm, "upper"), weight=_result_axis_array(mm, "weight"))
     return out
+
+
+# ---- heracles.twopoint.invert_mixing_matrix (heracles/twopoint.py:404-494) ---------------------------------------------
+def pinv(M, rcond=1e-5, *, device=None, info=False):
+    """``np.linalg.pinv(M, rcond=rcond)`` on the GPU (``hx_pinv``: blocked one-sided Jacobi SVD, singular values <= rcond * the largest
+    dropped).  ``M``: numpy array or device tensor (n, m); returns a numpy array (m, n), or a device tensor with ``device=``."""
+    import ctypes as C_
+
+    M = getattr(M, "tensor", M)
+    n, m = M.shape
+    M = M.contiguous() if hasattr(M, "data_ptr") else np.ascontiguousarray(M, dtype=np.float64)
+    if device is None:
+        out = np.empty((m, n))
+    else:
+        import torch
+
+        out = torch.empty((m, n), dtype=torch.float64, device=device)
+    inf = (C_.c_double * 4)()
+    _lib.ensure_init()
+    _lib.check(_lib.load().hx_pinv(int(n), int(m), _lib.ptr(M), float(rcond), _lib.ptr(out), inf))
+    return (out, {"sweeps": int(inf[0]), "kept": int(inf[1]), "largest": inf[2], "smallest_kept": inf[3]}) if info else out
+
+
+def invert_mixing_matrix(M, rcond=1e-5, progress=None):
+    """Pseudo-inverses of mixing matrices, key by key: ``heracles.twopoint.invert_mixing_matrix`` (heracles/twopoint.py:404-494).  Spin-2 x
+    spin-2 keys hold the three matrices of ``mixmat_eb``: M0 +- M1 are inverted separately (the transformation to Cl^EE +- Cl^BB makes
+    the E/B system block diagonal), [0] = (P + Q) / 2, [1] = (P - Q) / 2 of their inverses P, Q, [2] = pinv(M2); every other key is
+    ``pinv(M)``.  ``rcond``: a number or a mapping key -> number (a key missing from it is a ``KeyError``, as in the reference).  A
+    non-square matrix swaps its ell axes: the angular arrays of the result are then those of the inverse's output axis (0 .. size).
+    Every ``pinv`` runs on the GPU (``hx_pinv``)."""
+    from collections.abc import Mapping
+    from dataclasses import replace
+
+    prog = progress if progress is not None else _NoProgress()
+    out = {}
+    for count, (key, value) in enumerate(M.items(), 1):
+        prog.update(count, len(M))
+        mat = getattr(value.array, "tensor", value.array)
+        s1, s2 = value.spin
+        n, m = mat.shape[-2], mat.shape[-1]
+        if isinstance(rcond, Mapping):
+            if key not in rcond:
+                raise KeyError(f"Missing rcond value for wm key: {key}")
+            rc = rcond[key]
+        else:
+            rc = rcond
+        with prog.task(f"invert {key}"):
+            if s1 != 0 and s2 != 0:
+                plus, minus = pinv(mat[0] + mat[1], rc), pinv(mat[0] - mat[1], rc)
+                inv = np.array([(plus + minus) / 2, (plus - minus) / 2, pinv(mat[2], rc)])
+            else:
+                inv = pinv(mat, rc)
+        if n != m:
+            size = inv.shape[value.axis[0]]
+            out[key] = replace(value, array=inv, ell=np.arange(size), lower=np.arange(size), upper=np.arange(1, size + 1), weight=np.ones(size))
+        else:
+            out[key] = replace(value, array=inv)
+    return out

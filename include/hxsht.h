@@ -185,6 +185,12 @@ int hx_alm_subtract(int64_t n, const double *full, int nsub, const double *const
  * spectra: HBM-bound).  Rows are summed in a fixed order (bitwise repeatable).                                        */
 int hx_matvec(int n, int m, const double *M, int nvec, const double *x, double *y);
 
+/* np.linalg.pinv(M, rcond) as heracles.twopoint.invert_mixing_matrix calls it (heracles/twopoint.py:447-460): out (m x n) = pseudo-inverse
+ * of M (n x m, row-major), singular values <= rcond * the largest are dropped.  Blocked one-sided Jacobi SVD on the GPU (Gram matrices of
+ * column-block pairs, their 64 x 64 eigenproblems in LDS, rotations), the final product on the FP64 matrix unit.  M / out host or device;
+ * info (nullable, 4 doubles on the host): sweeps, singular values kept, largest, smallest kept.                               */
+int hx_pinv(int n, int m, const double *M, double rcond, double *out, double *info);
+
 typedef struct hx_mixctx hx_mixctx;
 hx_mixctx *hx_mixctx_create(int l1max, int l2max, int l3max);
 int hx_mixctx_apply(hx_mixctx *ctx, const double *cl, int ncl, int kind, double *out);

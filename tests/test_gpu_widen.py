@@ -140,3 +140,94 @@ def test_apply_mixing_matrix_follows_the_reference(oracle):
         ref = np.array([[A[0] @ x[0, 0] + A[1] @ x[1, 1], A[2] @ x[0, 1]], [A[2] @ x[1, 0], A[1] @ x[0, 0] + A[0] @ x[1, 1]]])
         np.testing.assert_allclose(got[k].array, ref, rtol=1e-13, atol=1e-13)
         assert got[k].spin == (2, 2)
+
+
+# ---- hx_pinv / invert_mixing_matrix (heracles/twopoint.py:404-494) -------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(5, 4), (4, 5), (40, 40), (97, 33), (33, 97), (200, 130), (301, 301)])
+def test_pinv_matches_numpy(shape):
+    """``hx_pinv`` (blocked one-sided Jacobi SVD) against ``np.linalg.pinv`` with the same ``rcond``: well conditioned, graded singular
+    values with a cut in the middle, and exactly rank-deficient input; numpy on the host is the checker here, not a fallback."""
+    import heracles_amd as hx
+    from heracles_amd.twopoint import pinv
+
+    n, m = shape
+    rng = np.random.default_rng(n * 1000 + m)
+    a = rng.standard_normal((n, m))
+    got, info = pinv(a, 1e-10, info=True)
+    ref = np.linalg.pinv(a, rcond=1e-10)
+    assert got.shape == (m, n) and info["kept"] == min(n, m)
+    np.testing.assert_allclose(got, ref, atol=1e-11 * np.abs(ref).max())
+    # graded spectrum 1 ... 1e-8, rcond in a gap: the same singular values are kept
+    k = min(n, m)
+    u, _, vt = np.linalg.svd(a, full_matrices=False)
+    sv = np.logspace(0, -8, k)
+    b = (u * sv) @ vt
+    for rc in (3e-3, 3e-6):
+        got, info = pinv(b, rc, info=True)
+        ref = np.linalg.pinv(b, rcond=rc)
+        assert info["kept"] == int(np.sum(sv > rc * sv[0]))
+        np.testing.assert_allclose(got, ref, atol=1e-9 * np.abs(ref).max())
+    # rank one (the reference's own test matrices are all ones: tests/test_twopoint.py:425-447)
+    ones = np.ones((n, m))
+    got, info = pinv(ones, 1e-4, info=True)
+    assert info["kept"] == 1
+    np.testing.assert_allclose(got, np.linalg.pinv(ones, rcond=1e-4), atol=1e-13)
+    np.testing.assert_allclose(got.sum(), 1.0, rtol=1e-12)
+    assert hx is not None
+
+
+def test_pinv_device_in_out_and_larger_size():
+    import torch
+
+    from heracles_amd.twopoint import pinv
+
+    rng = np.random.default_rng(9)
+    n = 700
+    i, j = np.arange(n)[:, None], np.arange(n)[None, :]
+    a = np.exp(-0.5 * ((i - j) / 3.0) ** 2) + 1e-3 * rng.standard_normal((n, n))  # a mixing-matrix-like band
+    dev = pinv(torch.as_tensor(a).cuda(), 1e-5, device="cuda")
+    assert dev.is_cuda
+    ref = np.linalg.pinv(a, rcond=1e-5)
+    np.testing.assert_allclose(dev.cpu().numpy(), ref, atol=1e-8 * np.abs(ref).max())
+
+
+def test_invert_and_apply_mixing_matrix_against_reference_golden():
+    """Vectors generated by the reference's own ``invert_mixing_matrix`` / ``apply_mixing_matrix`` (tests/golden/make_golden_mixing.py:
+    ``heracles.twopoint`` is importable) on seeded band matrices: square, tall and wide keys of all three spin classes, per-key ``rcond``,
+    and matrices of ones."""
+    import os
+
+    import heracles_amd as hx
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_mixing.npz"))
+    spins = {"POS|POS|0|0": (0, 0), "POS|SHE|0|1": (0, 2), "SHE|SHE|1|1": (2, 2)}
+    for name in ("square", "tall", "wide"):
+        mats, rconds, cls = {}, {}, {}
+        for ks, sp in spins.items():
+            key = tuple(int(x) if x.isdigit() else x for x in ks.split("|"))
+            M = g[f"{name}/M/{ks}"]
+            mats[key] = hx.Result(M, spin=sp, axis=-2, ell=np.arange(M.shape[-2]))
+            rconds[key] = float(g[f"{name}/rcond/{ks}"])
+            cls[key] = hx.Result(g[f"{name}/cl/{ks}"], spin=sp, axis=-1)
+        inv = hx.invert_mixing_matrix(mats, rcond=rconds)
+        assert list(inv) == list(mats)
+        for ks in spins:
+            key = tuple(int(x) if x.isdigit() else x for x in ks.split("|"))
+            ref = g[f"{name}/inv/{ks}"]
+            assert inv[key].array.shape == ref.shape and inv[key].spin == mats[key].spin
+            np.testing.assert_allclose(inv[key].array, ref, atol=1e-9 * np.abs(ref).max())
+            np.testing.assert_array_equal(inv[key].ell, g[f"{name}/inv_ell/{ks}"])
+        applied = hx.apply_mixing_matrix(cls, inv)
+        for ks in spins:
+            key = tuple(int(x) if x.isdigit() else x for x in ks.split("|"))
+            ref = g[f"{name}/applied/{ks}"]
+            np.testing.assert_allclose(applied[key].array, ref, atol=1e-8 * np.abs(ref).max())
+        with pytest.raises(KeyError, match="Missing rcond value"):
+            hx.invert_mixing_matrix(mats, rcond={})
+    ones = {("A", "A", 0, 0): hx.Result(np.ones((11, 21)), spin=(0, 0), axis=-2, ell=np.arange(11)),
+            ("B", "B", 0, 0): hx.Result(np.ones((3, 11, 21)), spin=(2, 2), axis=-2, ell=np.arange(11))}
+    inv = hx.invert_mixing_matrix(ones, rcond=1e-4)
+    np.testing.assert_allclose(inv["A", "A", 0, 0].array, g["ones/inv/A|A|0|0"], atol=1e-13)
+    np.testing.assert_allclose(inv["B", "B", 0, 0].array, g["ones/inv/B|B|0|0"], atol=1e-13)
+    np.testing.assert_allclose(inv["A", "A", 0, 0].array.sum(), 1.0)   # the reference's assertions (tests/test_twopoint.py:439-447)
+    np.testing.assert_allclose(inv["B", "B", 0, 0].array.sum(), 1.5)
