@@ -836,9 +836,12 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
     constexpr int DQ0 = NG * 512, DSZ = NG * 512 + NBX * 128;
     constexpr bool HALFB = SPIN == 2;
     constexpr int NPB = HALFB ? 1 : 2;  // operand positions kept in registers
-    static_assert(NG >= 1 && NG <= 2 && NSUB * DSZ <= 2048, "the D tiles of a wave fit its tile");
+    // doubles per wave of its tile: the 16 x 64 lambda tile (2048), or the D tiles of a flush if they need more (two blocks of 36 / 40
+    // columns: 2304 / 2560 -- 80 KiB per work-group, still two per CU)
+    constexpr int TW = NSUB * DSZ > 2048 ? NSUB * DSZ : 2048;
+    static_assert(NG >= 1 && NG <= 2 && TW * NW * 8 <= 81920, "two work-groups per CU");
     static_assert(SPIN == 0 || HX_HALF_F, "spin 2: the lambda- chain carries (-1)^(l + m) lambda- (one operand row, wave-uniform coefficients)");
-    __shared__ double tile[NW][2048];          // 64 KiB; doubles as the D staging area of the flush
+    __shared__ double tile[NW][TW];            // 64 KiB (80 at most); doubles as the D staging area of the flush
 #if HX_DUO_ABL & 64  // diagnostic: ONE work-group per CU (the phase durations of a wave that is alone on its SIMD)
     __shared__ double lds_hog[3072];
     if (A.ncol < 0) lds_hog[threadIdx.x] = 1.0;
@@ -1111,14 +1114,14 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
                     const double *src = &tile[0][0] + sub * DSZ + (g * 2 + fpos) * 256 + fcol * 16 + ((fch ^ (fcol & 7)) * 2);
                     double2 s4[NW];
 #pragma unroll
-                    for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(src + ww * 2048);
+                    for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(src + ww * TW);
                     put(pgrp + rsub + g * NCOL, (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x));
                     put(pgrp + rsub + g * NCOL + 8 * (long long)A.pcol, (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y));
                 }
                 if (NBX > 0 && tid < 64 * NBX) {
                     double2 s4[NW];
 #pragma unroll
-                    for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(&tile[0][0] + ww * 2048 + sub * DSZ + DQ0 + tid * 2);
+                    for (int ww = 0; ww < NW; ++ww) s4[ww] = *reinterpret_cast<const double2 *>(&tile[0][0] + ww * TW + sub * DSZ + DQ0 + tid * 2);
                     put(pquad + rsub, (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x));
                     put(pquad + rsub + A.pcol, (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y));
                 }
@@ -1307,7 +1310,7 @@ static double sweep_cost(int spin, int units)
 {
     if (leg_duo()) {  // k_legendre_duo, round 4 (gpurun_out/r4_t6_shapes.log)
         if (spin == 0) return units <= 4 ? 21.6 * units : (units <= 8 ? 84.5 : (units <= 10 ? 100.7 : 147.0));
-        return units <= 2 ? 61.0 * units : (units <= 4 ? 166.0 : (units == 5 ? 198.0 : (units == 6 ? 221.0 : (units <= 8 ? 276.0 : (units == 9 ? 317.0 : 345.0)))));
+        return units <= 2 ? 61.0 * units : (units <= 4 ? 166.0 : (units == 5 ? 198.0 : (units == 6 ? 221.0 : (units <= 8 ? 276.0 : (units == 9 ? 304.0 : 345.0)))));
     }
     if (spin == 0) return units <= 4 ? 21.6 * units : (units <= 8 ? 100.0 : (units <= 10 ? 115.0 : 162.0));
     return units <= 2 ? 61.0 * units : (units <= 4 ? 196.0 : (units == 5 ? 224.0 : (units <= 8 ? 316.0 : (units == 9 ? 360.0 : 400.0))));
@@ -1457,13 +1460,15 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
             const dim3 db(256);
             const int key = sh.ng * 10 + sh.nbx;
             // two l-blocks per flush wherever the second accumulator set fits the 256 registers (ten spin-0 maps 105 -> 101 ms, five spin-2 fields
-            // 206 -> 198, eight 289 -> 276; sixteen spin-0 maps spill: 147 -> 157); HX_DUO_NSUB=1 keeps one block per flush (bit-identical results)
+            // 206 -> 198, eight 289 -> 276, nine 320 -> 304; sixteen spin-0 maps spill: 147 -> 157; ten fields spill 43 registers: 345 -> 423);
+            // HX_DUO_NSUB=1 keeps one block per flush (bit-identical results)
             static int nsub1 = -1;
             if (nsub1 < 0) { const char *e = getenv("HX_DUO_NSUB"); nsub1 = (e && atoi(e) == 1) ? 1 : 0; }
             if (key == 10 && !nsub1) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 0, 2>), pgrid, db, 0, st, A, cn);
             else if (key == 11 && !nsub1) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 1, 2>), pgrid, db, 0, st, A, cn);
             else if (key == 20 && !nsub1 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 2, 0, 2>), pgrid, db, 0, st, A, cn);
             else if (key == 12 && !nsub1 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 1, 2, 2>), pgrid, db, 0, st, A, cn);
+            else if (key == 21 && !nsub1 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 2, 1, 2>), pgrid, db, 0, st, A, cn);  // (its D tiles need 72 KiB of LDS)
             else if (key == 10) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 0>), pgrid, db, 0, st, A, cn);
             else if (key == 11) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 1>), pgrid, db, 0, st, A, cn);
             else if (key == 20) hipLaunchKernelGGL((k_legendre_duo<SPIN, 2, 0>), pgrid, db, 0, st, A, cn);
