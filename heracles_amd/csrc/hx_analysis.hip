@@ -860,11 +860,15 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
     // LDS hand-over, no LDS read per step (32 of the 48 LDS instructions of a block's recursion: 1760 -> cycles per block for a lone
     // wave), no scalar load (their latency cannot be covered: out-of-order return allows no load in flight across a wait: 5000 cycles)
     const double2 *__restrict__ cfm = coefn + almidx(lmax, 0, m) + l0 + (SPIN == 0 ? 0 : 1) + (threadIdx.x & 15);
-    auto put = [](double *p, double v) __attribute__((always_inline)) {
+    // the FIRST ring group of an m stores its rows, the others add to them: the rows need not be zeroed before the launch (3 GB per sweep of
+    // ten fields) and a fortieth of the atomics is plain stores
+    bool first_group = true;
+    auto put = [&](double *p, double v) __attribute__((always_inline)) {
 #if HX_DUO_ABL & 8
         *p = v;
 #else
-        __builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)p, v);
+        if (first_group) *p = v;
+        else __builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)p, v);
 #endif
     };
     auto lds_barrier = []() __attribute__((always_inline)) {
@@ -883,6 +887,7 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
 #endif
     for (int ti = 0; ti < mt.count; ++ti) {
         const LegTask task = A.tasks[mt.first + ti];
+        first_group = ti == 0;
         int tid = threadIdx.x;
         asm volatile("; ring group" : "+v"(tid));
         const int w = tid >> 6, lane = tid & 63;
@@ -1447,7 +1452,8 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         A.counters = nullptr;
         A.of_m = ts.d_of_m.as<MTasks>(); A.arow = ts.d_arow.as<long long>(); A.arow0 = ts.arow[m0];
         A.tasks = ts.d_tasks.as<LegTask>();  // the pipelined kernel indexes the whole list through of_m
-        HX_HIP(hipMemsetAsync(pl->partial.p, 0, (size_t)(ts.arow[m1] - ts.arow[m0]) * pcol * sizeof(double), st));
+        if (!duo_shape(sh))  // (k_legendre_duo's first ring group of an m stores its rows)
+            HX_HIP(hipMemsetAsync(pl->partial.p, 0, (size_t)(ts.arow[m1] - ts.arow[m0]) * pcol * sizeof(double), st));
 #if defined(HX_DIAG) && ((HX_PIPE_ABL & 8) || (HX_DUO_ABL & 32))
         HX_TRY(pl->d_dbg.alloc(144));
         HX_HIP(hipMemsetAsync(pl->d_dbg.p, 0, 144, st));
