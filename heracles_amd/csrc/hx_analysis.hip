@@ -842,6 +842,7 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
     static_assert(NG >= 1 && NG <= 2 && TW * NW * 8 <= 81920, "two work-groups per CU");
     static_assert(SPIN == 0 || HX_HALF_F, "spin 2: the lambda- chain carries (-1)^(l + m) lambda- (one operand row, wave-uniform coefficients)");
     __shared__ double tile[NW][TW];            // 64 KiB (80 at most); doubles as the D staging area of the flush
+    __shared__ int lead_in[2][NW];             // while no wave of the ring group has issued a matrix instruction yet: did wave w, in flush (slot) b?
 #if HX_DUO_ABL & 64  // diagnostic: ONE work-group per CU (the phase durations of a wave that is alone on its SIMD)
     __shared__ double lds_hog[3072];
     if (A.ncol < 0) lds_hog[threadIdx.x] = 1.0;
@@ -1021,10 +1022,17 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
         double *pgrp = A.partial + (orow + 2 * frow + fpos) * A.pcol + fcol;
         double *pquad = A.partial + (orow + 2 * qrow) * A.pcol + NG * NCOL + qcol;
         double2 cnext[2] = {cfm[0], cfm[16]};
+        // Lead-in of a ring group: the blocks in which every ring of all four waves is still below 2^-300 (~ 8 % of the blocks) have
+        // nothing to flush.  Until the first wave issues matrix instructions the waves exchange one flag per flush through LDS (one barrier,
+        // one 16-byte read) and skip staging, reduction, atomics and the second barrier; from then on no flag is read or written any more
+        // (read in EVERY flush the flags cost more than they saved: 357 vs 345 ms).  The first ring group of an m writes all its rows.
+        bool started = first_group;
+        int nflush = 0;
         DUO_STAMP(0);
         for (int b0 = 0; b0 < nblk; b0 += NSUB) {
             double4_t acc[NSUB][NG][2];
             double accx[NSUB][NXA][2];
+            bool mine = false;
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
                 const int b = b0 + sub;
@@ -1045,6 +1053,7 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
                 cnext[1] = cfm[(b + 1) * LBLK + 16];
                 n_rec = __builtin_amdgcn_readfirstlane(n_rec + 1);
                 if (rm >= 2) DUO_STAMP(1); else DUO_STAMP(2);
+                mine = mine || rm >= 2;
                 if (rm >= 2 && !(HX_DUO_ABL & 1)) {
                     n_mf = __builtin_amdgcn_readfirstlane(n_mf + 1);
                     constexpr int PF = 3;
@@ -1094,6 +1103,18 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
             // (g 2 + p) 256 + col 16 + (c ^ (col & 7)) 2;  4-column blocks: lane (i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3) = row 4 blk + i,
             // column j, both positions in one 16-byte store at DQ0 + ((row 4 NBX + 4 x + j) 2); sub-block sub at + sub DSZ
             const bool two = NSUB > 1 && b0 + 1 < nblk;
+            if (!started) {
+                if (lane == 0) lead_in[nflush & 1][w] = mine ? 1 : 0;
+                lds_barrier();
+                const int4 fl = *reinterpret_cast<const int4 *>(&lead_in[nflush & 1][0]);
+                ++nflush;
+                started = __builtin_amdgcn_readfirstlane(fl.x | fl.y | fl.z | fl.w) != 0;
+                if (!started) {  // nothing to add to the rows of these blocks
+                    pgrp += (long long)NSUB * LBLK * A.pcol;
+                    pquad += (long long)NSUB * LBLK * A.pcol;
+                    continue;
+                }
+            }
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
                 double *dt = tw + sub * DSZ;
