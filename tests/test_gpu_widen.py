@@ -231,3 +231,24 @@ def test_invert_and_apply_mixing_matrix_against_reference_golden():
     np.testing.assert_allclose(inv["B", "B", 0, 0].array, g["ones/inv/B|B|0|0"], atol=1e-13)
     np.testing.assert_allclose(inv["A", "A", 0, 0].array.sum(), 1.0)   # the reference's assertions (tests/test_twopoint.py:439-447)
     np.testing.assert_allclose(inv["B", "B", 0, 0].array.sum(), 1.5)
+
+
+def test_pinv_edge_cases():
+    """1 x 1, single rows / columns, an all-zero matrix (numpy returns zeros), rcond >= 1 (only the largest singular value survives...
+    numpy keeps s > rcond * max(s): none at rcond = 1), bad arguments."""
+    import heracles_amd as hx
+    from heracles_amd.twopoint import pinv
+
+    rng = np.random.default_rng(0)
+    for shape in ((1, 1), (1, 5), (5, 1), (2, 3)):
+        a = rng.standard_normal(shape)
+        np.testing.assert_allclose(pinv(a, 1e-12), np.linalg.pinv(a, rcond=1e-12), atol=1e-13)
+    z = np.zeros((7, 4))
+    got, info = pinv(z, 1e-5, info=True)
+    np.testing.assert_array_equal(got, np.zeros((4, 7)))
+    assert info["kept"] == 0
+    a = rng.standard_normal((9, 6))
+    np.testing.assert_allclose(pinv(a, 1.0), np.linalg.pinv(a, rcond=1.0), atol=1e-13)   # nothing is strictly above the largest
+    np.testing.assert_allclose(pinv(a, 0.5), np.linalg.pinv(a, rcond=0.5), atol=1e-12)
+    with pytest.raises(hx.HxError):
+        hx._lib.check(hx._lib.load().hx_pinv(3, 3, hx._lib.ptr(np.eye(3)), -1.0, hx._lib.ptr(np.eye(3)), None))
