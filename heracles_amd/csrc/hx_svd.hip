@@ -6,7 +6,7 @@
 //   per pair (I, J):  G = [W_I W_J]^T [W_I W_J]  (64 x 64, k_svd_gram: row chunks, partial sums added with f64 atomics)
 //                     G = Q diag Q^T              (k_svd_eig: parallel-order cyclic Jacobi of the 64 x 64 matrix in LDS, one work-group per pair)
 //                     [W_I W_J] <- [W_I W_J] Q,  [V_I V_J] <- [V_I V_J] Q   (k_svd_rotate, row chunks)
-//   until no pair had an off-diagonal Gram element above 1e-14 sqrt(G_ii G_jj).  Then the columns of W are u_j sigma_j, those of V are v_j:
+//   (one sweep of it per visit: see hx_pinv) until no pair had an off-diagonal Gram element above 1e-14 sqrt(G_ii G_jj).  Then the columns of W are u_j sigma_j, those of V are v_j:
 //       pinv(M) = sum_j v_j w_j^T / sigma_j^2  (kept j)  =  V diag(mask / sigma^2) W^T     -- one GEMM on the matrix unit (launch_gemm_tst).
 // One-sided Jacobi computes small singular values to high RELATIVE accuracy, which is what a relative cut-off (rcond) asks for.
 // Everything runs on the GPU; the host drives the tournament and reads one convergence word per sweep and the m singular values once.
@@ -24,7 +24,7 @@ namespace hx {
 constexpr int SB = 32;        // columns per block
 constexpr int SP = 2 * SB;    // columns of a block pair
 constexpr int SR = 64;        // rows per LDS tile of the Gram / rotation kernels
-constexpr int SLD = SP + 1;   // LDS row stride of the 64 x 64 matrices of k_svd_eig
+constexpr int SLD = SP + 2;   // LDS row stride of the 64 x 64 matrices of k_svd_eig (even: rows stay 16-byte aligned)
 
 // W: [rows_pad][ld] row-major (ld = nb SB columns).  G[pair] += P^T P over the rows of this chunk, P = the 64 columns of the pair.
 __global__ __launch_bounds__(256) void k_svd_gram(const double *__restrict__ W, long long ld, int nrows, const int2 *__restrict__ pairs,
@@ -75,20 +75,26 @@ __global__ __launch_bounds__(256) void k_svd_gram(const double *__restrict__ W, 
 }
 
 // Symmetric eigen-decomposition of every pair's 64 x 64 Gram matrix: G = Q diag Q^T, Q written over G's slot in Qout ([pair][64][64],
-// Qout[c][j] = component c of eigenvector j).  Parallel-order cyclic Jacobi: 63 rounds of 32 disjoint rotations per sweep.
+// Qout[c][j] = component c of eigenvector j).  Parallel-order cyclic Jacobi: 63 rounds of 32 disjoint rotations per sweep.  A round is
+// A <- J^T A J with J = the 32 rotations together, applied 2 x 2 block by 2 x 2 block: block (a, b) = rows (p_a, q_a) x columns (p_b, q_b)
+// becomes J_a^T [block] J_b, 1024 blocks over 256 threads, one pass and one barrier (separate column and row passes were two, with twice
+// the LDS traffic); the eigenvectors are kept as ROWS (QT <- J^T QT), whose update runs over neighbouring columns in 128-bit accesses.
+// (1.42 -> 1.2 ms per call of 8-9 sweeps at n = 4097: a round is latency, not traffic -- three dependent trips to LDS and the
+// square roots of the rotation between two barriers, one wave per SIMD.)
 // offmax (one double, as ordered integer bits): max over all pairs of |G_ij| / sqrt(G_ii G_jj) BEFORE the diagonalisation -- the
 // convergence measure of the outer (one-sided) iteration.
-__global__ __launch_bounds__(256) void k_svd_eig(const double *__restrict__ G, double *__restrict__ Qout, unsigned long long *__restrict__ offmax)
+__global__ __launch_bounds__(256) void k_svd_eig(const double *__restrict__ G, double *__restrict__ Qout, unsigned long long *__restrict__ offmax,
+                                                 int max_sweeps, double stop_below)
 {
-    __shared__ double A[SP][SLD], Q[SP][SLD];
-    __shared__ double cs[SB], sn[SB];
-    __shared__ int pp[SB], qq[SB];
+    __shared__ __attribute__((aligned(16))) double A[SP][SLD], QT[SP][SLD];
+    __shared__ double2 rot[SB];   // (c, s) of the round's rotations
+    __shared__ int2 pq[SB];       // their (p, q), p < q
     __shared__ unsigned long long lmax_bits;
     const int t = threadIdx.x;
     const double *g = G + (long long)blockIdx.x * SP * SP;
     for (int e = t; e < SP * SP; e += 256) {
         A[e >> 6][e & 63] = g[e];
-        Q[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
+        QT[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
     }
     if (t == 0) lmax_bits = 0ull;
     __syncthreads();
@@ -107,7 +113,8 @@ __global__ __launch_bounds__(256) void k_svd_eig(const double *__restrict__ G, d
     if (t == 0) atomicMax(offmax, lmax_bits);
     const double first = __longlong_as_double((long long)lmax_bits);
     if (first > 1e-15) {
-        for (int sweep = 0; sweep < 12; ++sweep) {
+        const int a = t >> 3, b0 = t & 7;  // this thread's row pair; its column pairs are b0 + 8 u
+        for (int sweep = 0; sweep < max_sweeps; ++sweep) {
             __syncthreads();
             if (t == 0) lmax_bits = 0ull;
             for (int round = 0; round < SP - 1; ++round) {
@@ -129,42 +136,46 @@ __global__ __launch_bounds__(256) void k_svd_eig(const double *__restrict__ G, d
                         s = tt * c;
                     }
                     atomicMax(&lmax_bits, (unsigned long long)__double_as_longlong(rel));
-                    pp[t] = p; qq[t] = q; cs[t] = c; sn[t] = s;
+                    pq[t] = make_int2(p, q);
+                    rot[t] = make_double2(c, s);
                 }
                 __syncthreads();
-                // columns of A and of Q: X <- X J   (work items (k, pair): 64 x 32)
+                const int2 ra = pq[a];
+                const double2 ja = rot[a];
+                // eigenvector rows p_a, q_a: columns 2 (b0 + 8 u), + 1
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int pr = t & 31, k = (t >> 5) + 8 * u;
-                    const int p = pp[pr], q = qq[pr];
-                    const double c = cs[pr], s = sn[pr];
-                    const double ap = A[k][p], aq = A[k][q];
-                    A[k][p] = c * ap - s * aq;
-                    A[k][q] = s * ap + c * aq;
-                    const double qp = Q[k][p], qv = Q[k][q];
-                    Q[k][p] = c * qp - s * qv;
-                    Q[k][q] = s * qp + c * qv;
+                for (int u = 0; u < 4; ++u) {
+                    const int k = 2 * (b0 + 8 * u);
+                    double2 *xp = reinterpret_cast<double2 *>(&QT[ra.x][k]), *xq = reinterpret_cast<double2 *>(&QT[ra.y][k]);
+                    const double2 vp = *xp, vq = *xq;
+                    *xp = make_double2(ja.x * vp.x - ja.y * vq.x, ja.x * vp.y - ja.y * vq.y);
+                    *xq = make_double2(ja.y * vp.x + ja.x * vq.x, ja.y * vp.y + ja.x * vq.y);
                 }
-                __syncthreads();
-                // rows of A: A <- J^T A   (work items (pair, k): 32 x 64)
+                // blocks (a, b) of A
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int k = t & 63, pr = (t >> 6) + 4 * u;
-                    const int p = pp[pr], q = qq[pr];
-                    const double c = cs[pr], s = sn[pr];
-                    const double ap = A[p][k], aq = A[q][k];
-                    A[p][k] = c * ap - s * aq;
-                    A[q][k] = s * ap + c * aq;
+                for (int u = 0; u < 4; ++u) {
+                    const int2 rb = pq[b0 + 8 * u];
+                    const double2 jb = rot[b0 + 8 * u];
+                    const double app = A[ra.x][rb.x], apq = A[ra.x][rb.y], aqp = A[ra.y][rb.x], aqq = A[ra.y][rb.y];
+                    // rows: J_a^T
+                    const double r0p = ja.x * app - ja.y * aqp, r0q = ja.x * apq - ja.y * aqq;
+                    const double r1p = ja.y * app + ja.x * aqp, r1q = ja.y * apq + ja.x * aqq;
+                    // columns: J_b
+                    A[ra.x][rb.x] = jb.x * r0p - jb.y * r0q;
+                    A[ra.x][rb.y] = jb.y * r0p + jb.x * r0q;
+                    A[ra.y][rb.x] = jb.x * r1p - jb.y * r1q;
+                    A[ra.y][rb.y] = jb.y * r1p + jb.x * r1q;
                 }
             }
             __syncthreads();
-            if (__longlong_as_double((long long)lmax_bits) < 1e-16) break;
+            if (__longlong_as_double((long long)lmax_bits) < stop_below) break;
         }
     }
     __syncthreads();
     // eigenvectors in descending order of their eigenvalue = squared norm of the rotated column: the larger columns of a pair move to its
     // first block (de Rijk's ordering, block-wise).  Without it the one-sided iteration idled for ~16 sweeps at an off-diagonal measure of
     // 0.2-0.7 before its quadratic phase (21 sweeps at n = 2049)
+    int *rank_of = reinterpret_cast<int *>(rot);  // (32 double2 = 128 ints, free after the last round)
     if (t < SP) {
         const double lam = A[t][t];
         int rank = 0;
@@ -172,13 +183,13 @@ __global__ __launch_bounds__(256) void k_svd_eig(const double *__restrict__ G, d
             const double li = A[i][i];
             rank += (li > lam || (li == lam && i < t)) ? 1 : 0;
         }
-        reinterpret_cast<int *>(cs)[t] = rank;  // (cs: 32 doubles = 64 ints, free after the last round)
+        rank_of[t] = rank;
     }
     __syncthreads();
     double *qo = Qout + (long long)blockIdx.x * SP * SP;
     for (int e = t; e < SP * SP; e += 256) {
-        const int c = e >> 6, j = e & 63;
-        qo[c * SP + reinterpret_cast<const int *>(cs)[j]] = Q[c][j];
+        const int j = e >> 6, c = e & 63;   // eigenvector j, component c
+        qo[c * SP + rank_of[j]] = QT[j][c];
     }
 }
 
@@ -325,14 +336,20 @@ extern "C" int hx_pinv(int n, int m, const double *M, double rcond, double *out,
     const int wchunks = (nw + rpc - 1) / rpc, vchunks = (int)((ld + rpc - 1) / rpc);
     // converged when no Gram element is above the rounding noise of its own sum (nw terms added in an unordered way)
     const double tol = std::max(1e-14, 16.0 * 1.1e-16 * std::sqrt((double)nw));
+    // ONE Jacobi sweep per Gram matrix: diagonalising every 64 x 64 problem to rounding (8-9 sweeps on the first visits) bought nothing --
+    // n = 4097: 18 outer sweeps / 3.49 s with up to 12 inner sweeps, 18 / 1.59 s with 2, 19 / 1.29 s with 1 (tools/pinv_grid.sh);
+    // HX_SVD_INNER overrides (experiments)
+    const char *e_in = getenv("HX_SVD_INNER");
+    const int inner_sweeps = e_in ? std::max(1, atoi(e_in)) : 1;
+    const double inner_stop = 1e-8;   // (a sweep that met nothing above 1e-8 leaves nothing above 1e-16: quadratic convergence)
     int sweeps = 0;
-    for (; sweeps < 30; ++sweeps) {
+    for (; sweeps < 60; ++sweeps) {
         HX_HIP(hipMemsetAsync(d_off.p, 0, sizeof(unsigned long long), st));
         for (int r = 0; r < nsteps; ++r) {
             const int2 *pr = d_pairs.as<int2>() + (size_t)r * npair;
             HX_HIP(hipMemsetAsync(G.p, 0, sizeof(double) * (size_t)npair * SP * SP, st));
             hipLaunchKernelGGL(k_svd_gram, dim3(npair, wchunks), dim3(256), 0, st, W.as<double>(), ld, nw, pr, rpc, G.as<double>());
-            hipLaunchKernelGGL(k_svd_eig, dim3(npair), dim3(256), 0, st, G.as<double>(), Q.as<double>(), d_off.as<unsigned long long>());
+            hipLaunchKernelGGL(k_svd_eig, dim3(npair), dim3(256), 0, st, G.as<double>(), Q.as<double>(), d_off.as<unsigned long long>(), inner_sweeps, inner_stop);
             hipLaunchKernelGGL(k_svd_rotate, dim3(npair, std::max(wchunks, vchunks), 2), dim3(256), 0, st, W.as<double>(), nw, V.as<double>(), (int)ld, ld, pr, rpc,
                                Q.as<double>());
         }
