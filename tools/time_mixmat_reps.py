@@ -1,0 +1,12 @@
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import numpy as np, heracles_amd as hx
+hx.init(0)
+L = 6144
+ell = np.arange(L + 1)
+wl = 4 * np.pi * 0.35 * np.exp(-ell * (ell + 1) / 3000.0) + 1e-3 / (1.0 + ell) ** 2
+hx.mixmat_eb(wl[:65], l1max=64, l2max=64)
+ts = []
+for rep in range(8):
+    t = time.perf_counter(); mm = hx.mixmat_eb(wl); ts.append(time.perf_counter() - t)
+print("mixmat_eb host->host ms:", [round(x * 1e3, 1) for x in ts], "checksum", float(np.abs(mm[2] - (mm[0] - mm[1])).max()))
