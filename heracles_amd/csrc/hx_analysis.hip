@@ -69,6 +69,7 @@ struct LegParams {
     const MTasks *__restrict__ of_m;
     const long long *__restrict__ arow;
     long long arow0;
+    int add_all;                       // k_legendre_duo: every ring group ADDS to its (zeroed) rows -- a launch that holds only some ring groups of an m (StreamSweep)
 };
 
 // =====================================================================================
@@ -80,18 +81,19 @@ template <int SPIN>
 __global__ __launch_bounds__(256) void k_fourier_combine(PlanDev P, const double2 *__restrict__ Y, int ncomp, int ng,
                                                          int ncol, int m0, int ms, const double *__restrict__ rw,
                                                          const LegTask *__restrict__ tasks, const MTasks *__restrict__ of_m,
-                                                         double *__restrict__ F)
+                                                         double *__restrict__ F, int tile0)
 {
     constexpr int NOP = LegCfg<SPIN>::NOP;
     __shared__ RingAtM ring_at_m[32];
     const int m = m0 + blockIdx.x * ms;
+    const int ty = (int)blockIdx.y + tile0;  // tile of 32 ring pairs (tile0: first tile of the slab of a StreamSweep)
     // ring blocks in front of the first task of this m are pruned (m beyond what their rings resolve): their rows of F are
     // never read
     const MTasks mt = of_m[m];
-    if (mt.count == 0 || (int)blockIdx.y < tasks[mt.first].rb0) return;
-    if (threadIdx.x < 32) ring_at_m[threadIdx.x] = ring_at_m_of(P, blockIdx.y * 32 + threadIdx.x, m, rw);
+    if (mt.count == 0 || ty < tasks[mt.first].rb0) return;
+    if (threadIdx.x < 32) ring_at_m[threadIdx.x] = ring_at_m_of(P, ty * 32 + threadIdx.x, m, rw);
     __syncthreads();
-    const int rp = blockIdx.y * 32 + (threadIdx.x >> 3);
+    const int rp = ty * 32 + (threadIdx.x >> 3);
     const int slot = threadIdx.x & 7;
     const bool live = rp < P.nrp;
     const RingAtM ram = ring_at_m[threadIdx.x >> 3];
@@ -888,7 +890,7 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
 #endif
     for (int ti = 0; ti < mt.count; ++ti) {
         const LegTask task = A.tasks[mt.first + ti];
-        first_group = ti == 0;
+        first_group = ti == 0 && !A.add_all;
         int tid = threadIdx.x;
         asm volatile("; ring group" : "+v"(tid));
         const int w = tid >> 6, lane = tid & 63;
@@ -1446,6 +1448,32 @@ static int sweep_pcol(const SweepShape &sh)
     return sh.ncol;
 }
 
+// k_legendre_duo for a sweep shape (one work-group per order of the grid)
+template <int SPIN>
+static int launch_duo(const SweepShape &sh, dim3 pgrid, hipStream_t st, const LegParams &A, const double2 *cn)
+{
+    const dim3 db(256);
+    const int key = sh.ng * 10 + sh.nbx;
+    // two l-blocks per flush wherever the second accumulator set fits the 256 registers (ten spin-0 maps 105 -> 101 ms, five spin-2 fields
+    // 206 -> 198, eight 289 -> 276, nine 320 -> 304; sixteen spin-0 maps spill: 147 -> 157; ten fields spill 43 registers: 345 -> 423);
+    // HX_DUO_NSUB=1 keeps one block per flush (bit-identical results)
+    static int nsub1 = -1;
+    if (nsub1 < 0) { const char *e = getenv("HX_DUO_NSUB"); nsub1 = (e && atoi(e) == 1) ? 1 : 0; }
+    if (key == 10 && !nsub1) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 0, 2>), pgrid, db, 0, st, A, cn);
+    else if (key == 11 && !nsub1) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 1, 2>), pgrid, db, 0, st, A, cn);
+    else if (key == 20 && !nsub1 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 2, 0, 2>), pgrid, db, 0, st, A, cn);
+    else if (key == 12 && !nsub1 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 1, 2, 2>), pgrid, db, 0, st, A, cn);
+    else if (key == 21 && !nsub1 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 2, 1, 2>), pgrid, db, 0, st, A, cn);  // (its D tiles need 72 KiB of LDS)
+    else if (key == 10) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 0>), pgrid, db, 0, st, A, cn);
+    else if (key == 11) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 1>), pgrid, db, 0, st, A, cn);
+    else if (key == 20) hipLaunchKernelGGL((k_legendre_duo<SPIN, 2, 0>), pgrid, db, 0, st, A, cn);
+    else if (key == 12 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 1, 2>), pgrid, db, 0, st, A, cn);
+    else if (key == 21 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 2, 1>), pgrid, db, 0, st, A, cn);
+    else if (key == 22 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 2, 2>), pgrid, db, 0, st, A, cn);
+    else return fail(HX_ERR_ARG, "legendre analysis: no two-group kernel for %d groups + %d blocks", sh.ng, sh.nbx);
+    return HX_OK;
+}
+
 template <int SPIN>
 static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int nb, const SweepShape &sh, const double *d_rw,
                         const double *d_fl, int add, double2 *d_alms)
@@ -1462,7 +1490,7 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         ProfScope ps("fourier_combine");
         dim3 grid(nm, pl->nrp_pad / 32);
         hipLaunchKernelGGL(k_fourier_combine<SPIN>, grid, dim3(256), 0, st, P, pl->Y.as<double2>(), nb, ng, ncol, m0, ms, d_rw,
-                           ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(), pl->F.as<double>());
+                           ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(), pl->F.as<double>(), 0);
     }
     if (t1 > t0) {
         ProfScope ps("legendre_analysis");
@@ -1471,7 +1499,7 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         A.P = P; A.tasks = ts.d_tasks.as<LegTask>() + t0; A.F = pl->F.as<double>(); A.partial = pl->partial.as<double>();
         A.m0 = m0; A.ms = ms; A.row0 = ts.rows_before_m[m0]; A.ng = ng; A.ncol = ncol; A.pcol = pcol;
         A.counters = nullptr;
-        A.of_m = ts.d_of_m.as<MTasks>(); A.arow = ts.d_arow.as<long long>(); A.arow0 = ts.arow[m0];
+        A.of_m = ts.d_of_m.as<MTasks>(); A.arow = ts.d_arow.as<long long>(); A.arow0 = ts.arow[m0]; A.add_all = 0;
         A.tasks = ts.d_tasks.as<LegTask>();  // the pipelined kernel indexes the whole list through of_m
         if (!duo_shape(sh))  // (k_legendre_duo's first ring group of an m stores its rows)
             HX_HIP(hipMemsetAsync(pl->partial.p, 0, (size_t)(ts.arow[m1] - ts.arow[m0]) * pcol * sizeof(double), st));
@@ -1484,25 +1512,7 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
         const double *al = SPIN == 0 ? pl->al0.as<double>() : pl->al2.as<double>();
         dim3 pblock(PipeCfg<SPIN>::NW * 64), pgrid((unsigned)nm);
         if (duo_shape(sh)) {
-            const dim3 db(256);
-            const int key = sh.ng * 10 + sh.nbx;
-            // two l-blocks per flush wherever the second accumulator set fits the 256 registers (ten spin-0 maps 105 -> 101 ms, five spin-2 fields
-            // 206 -> 198, eight 289 -> 276, nine 320 -> 304; sixteen spin-0 maps spill: 147 -> 157; ten fields spill 43 registers: 345 -> 423);
-            // HX_DUO_NSUB=1 keeps one block per flush (bit-identical results)
-            static int nsub1 = -1;
-            if (nsub1 < 0) { const char *e = getenv("HX_DUO_NSUB"); nsub1 = (e && atoi(e) == 1) ? 1 : 0; }
-            if (key == 10 && !nsub1) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 0, 2>), pgrid, db, 0, st, A, cn);
-            else if (key == 11 && !nsub1) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 1, 2>), pgrid, db, 0, st, A, cn);
-            else if (key == 20 && !nsub1 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 2, 0, 2>), pgrid, db, 0, st, A, cn);
-            else if (key == 12 && !nsub1 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 1, 2, 2>), pgrid, db, 0, st, A, cn);
-            else if (key == 21 && !nsub1 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 2, 1, 2>), pgrid, db, 0, st, A, cn);  // (its D tiles need 72 KiB of LDS)
-            else if (key == 10) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 0>), pgrid, db, 0, st, A, cn);
-            else if (key == 11) hipLaunchKernelGGL((k_legendre_duo<SPIN, 1, 1>), pgrid, db, 0, st, A, cn);
-            else if (key == 20) hipLaunchKernelGGL((k_legendre_duo<SPIN, 2, 0>), pgrid, db, 0, st, A, cn);
-            else if (key == 12 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 1, 2>), pgrid, db, 0, st, A, cn);
-            else if (key == 21 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 2, 1>), pgrid, db, 0, st, A, cn);
-            else if (key == 22 && SPIN == 2) hipLaunchKernelGGL((k_legendre_duo<2, 2, 2>), pgrid, db, 0, st, A, cn);
-            else return fail(HX_ERR_ARG, "legendre analysis: no two-group kernel for %d groups + %d blocks", sh.ng, sh.nbx);
+            HX_TRY(launch_duo<SPIN>(sh, pgrid, st, A, cn));
         }
         else if (sh.ng == 1 && sh.nbx == 0 && pipe_nsub(SPIN) == 2)
             hipLaunchKernelGGL((k_legendre_pipe<SPIN, 1, 0, 2>), pgrid, pblock, 0, st, A, cn, al);
@@ -1694,6 +1704,142 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
         else
             HX_TRY(launch_chunk<2>(pl, ts, ch.first, ch.second, nb, sh, d_rw, d_fl, add, d_alms));
     }
+    return HX_OK;
+}
+
+// ---- a sweep whose rings arrive in slabs (StreamSweep, hx_sht_common.h) --------------------------------------------------------------
+// hx_map2alm_multi on host maps used to cut a job into sweeps of 5 fields / 8 maps so that a transform could start before the job's last
+// byte had arrived: smaller sweeps cost more (2 x 198 ms instead of 340 for ten fields) and the last of them is exposed behind the upload.
+// A ring group of the Legendre kernel needs the rings of that group only -- of ALL maps of the sweep -- so the upload goes slab of rings
+// by slab of rings (ascending, poles first: the ring groups of an order then run in the order they always run in) and slab k's ring FFTs,
+// operand rows and the ring groups it completes are queued behind it.  What is left behind the last byte is 1 / nslab of one sweep.
+static hx_plan::TaskSet &stream_tasks(hx_plan *pl, int spin) { return spin ? pl->ts[3] : pl->ts[2]; }
+
+bool analysis_can_stream(hx_plan *pl, int spin, int nb)
+{
+    if (!pl || pl->nside < 1 || pl->hsrc || pl->nssrc || pl->m_lo != 0 || pl->m_hi >= 0 || pl->m_step > 1) return false;
+    if (nb < 1 || nb > analysis_max_comp(spin)) return false;
+    const SweepShape sh = sweep_shape(spin, nb);
+    if (!duo_shape(sh) || sh.valu) return false;
+    // F and the accumulation rows of ALL orders at once
+    const double f_bytes = (double)pl->nrp_pad * analysis_f_rows(spin) * sh.ncol * sizeof(double) * (pl->lmax + 1.0);
+    const double p_bytes = 0.5 * (pl->lmax + 1.0) * (pl->lmax + 2.0 + LBLK) * sweep_pcol(sh) * sizeof(double);
+    double budget = 80e9;
+    if (scratch_budget_bytes() > 0.0) budget = scratch_budget_bytes();
+    return f_bytes + p_bytes <= budget;
+}
+
+int analysis_stream_plan(hx_plan *pl, int spin, int nb, int nslab, StreamSweep &s)
+{
+    if (!analysis_can_stream(pl, spin, nb)) return fail(HX_ERR_ARG, "analysis_stream_plan: not a streamable sweep");
+    if (spin) HX_TRY(ensure_rec2(pl));
+    HX_TRY(build_task_set(pl, spin, PipeCfg<2>::NW * (spin ? PipeCfg<2>::RBS : PipeCfg<0>::RBS), stream_tasks(pl, spin)));
+    hx_plan::TaskSet &ts = stream_tasks(pl, spin);
+    const SweepShape sh = sweep_shape(spin, nb);
+    s.pl = pl; s.spin = spin; s.nb = nb;
+    // slab edges: whole 32-ring-pair blocks, about equal numbers of pixels (a ring pair is 8 nsub pixels, the equator ring 4)
+    const int nrb = (pl->nrp + RBLK - 1) / RBLK;
+    std::vector<double> cum(nrb + 1, 0.0);
+    for (int rb = 0; rb < nrb; ++rb) {
+        double px = 0.0;
+        for (int rp = rb * RBLK; rp < std::min((rb + 1) * RBLK, pl->nrp); ++rp) px += (rp == pl->nrp - 1 ? 4.0 : 8.0) * pl->h_nsub[rp];
+        cum[rb + 1] = cum[rb] + px;
+    }
+    nslab = std::max(1, std::min(nslab, nrb));
+    s.rp_edge.assign(1, 0);
+    for (int k = 1; k < nslab; ++k) {
+        const int rb = (int)(std::lower_bound(cum.begin(), cum.end(), cum[nrb] * k / nslab) - cum.begin());
+        if (rb * RBLK > s.rp_edge.back() && rb < nrb) s.rp_edge.push_back(rb * RBLK);
+    }
+    s.rp_edge.push_back(nrb * RBLK);
+    s.nslab = (int)s.rp_edge.size() - 1;
+    // the ring groups of order m that slab k completes: those whose LAST ring block lies in it (the ring groups of an m are in ascending order)
+    const int lmax = pl->lmax;
+    std::vector<MTasks> tab((size_t)s.nslab * (lmax + 1), MTasks{0, 0});
+    for (int m = 0; m <= lmax; ++m) {
+        const MTasks mt = ts.of_m[m];
+        int t = mt.first;
+        for (int k = 0; k < s.nslab; ++k) {
+            const int rb_hi = s.rp_edge[k + 1] / RBLK;
+            MTasks &o = tab[(size_t)k * (lmax + 1) + m];
+            o.first = t;
+            while (t < mt.first + mt.count && ts.tasks[t].rb0 + ts.tasks[t].nrb <= rb_hi) ++t;
+            o.count = t - o.first;
+        }
+        if (t != mt.first + mt.count) return fail(HX_ERR_ARG, "analysis_stream_plan: ring groups of m = %d left over", m);
+    }
+    HX_TRY(upload(s.d_of_m, tab));
+    // scratch for all orders at once (DevBuf::alloc keeps what is large enough: planning every sweep of a call first means no buffer is
+    // re-allocated -- a device-wide synchronisation -- between its sweeps)
+    HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nb));
+    HX_TRY(pl->F.alloc((size_t)pl->nrp_pad * analysis_f_rows(spin) * sh.ncol * sizeof(double) * (size_t)(lmax + 1)));
+    HX_TRY(pl->partial.alloc((size_t)ts.arow[lmax + 1] * sweep_pcol(sh) * sizeof(double)));
+    return HX_OK;
+}
+
+int analysis_stream_start(StreamSweep &s)
+{
+    hx_plan *pl = s.pl;
+    const SweepShape sh = sweep_shape(s.spin, s.nb);
+    // the accumulation rows start at zero: every ring group adds
+    HX_HIP(hipMemsetAsync(pl->partial.p, 0, (size_t)stream_tasks(pl, s.spin).arow[pl->lmax + 1] * sweep_pcol(sh) * sizeof(double), rt().stream));
+    pl->last_chunks = 1;
+    return HX_OK;
+}
+
+template <int SPIN>
+static int stream_slab(StreamSweep &s, int k)
+{
+    hx_plan *pl = s.pl;
+    hx_plan::TaskSet &ts = stream_tasks(pl, SPIN);
+    const SweepShape sh = sweep_shape(SPIN, s.nb);
+    const int ng = sh.ng + (sh.nbx > 0 ? 1 : 0), lmax = pl->lmax, nm = lmax + 1;
+    const int rp_lo = s.rp_edge[k], rp_hi = s.rp_edge[k + 1];
+    hipStream_t st = rt().stream;
+    PlanDev P = pl->dev();
+    HX_TRY(launch_ring_subdft_maps(pl, s.nb, s.d_maps, s.d_pw, pl->Y.as<double2>(), rp_lo, std::min(rp_hi, pl->nrp)));
+    {
+        ProfScope ps("fourier_combine");
+        const int tile_hi = k + 1 == s.nslab ? pl->nrp_pad / 32 : rp_hi / 32;  // (the padding rows behind the last ring pair are zeroed with the last slab)
+        dim3 grid(nm, tile_hi - rp_lo / 32);
+        hipLaunchKernelGGL(k_fourier_combine<SPIN>, grid, dim3(256), 0, st, P, pl->Y.as<double2>(), s.nb, ng, sh.ncol, 0, 1, s.d_rw,
+                           ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(), pl->F.as<double>(), rp_lo / 32);
+    }
+    {
+        ProfScope ps("legendre_analysis");
+        ProfScope ps2(SPIN == 0 ? "legendre_analysis_s0" : "legendre_analysis_s2");
+        LegParams A;
+        A.P = P; A.tasks = ts.d_tasks.as<LegTask>(); A.F = pl->F.as<double>(); A.partial = pl->partial.as<double>();
+        A.m0 = 0; A.ms = 1; A.row0 = 0; A.ng = ng; A.ncol = sh.ncol; A.pcol = sweep_pcol(sh);
+        A.counters = nullptr;
+        A.of_m = s.d_of_m.as<MTasks>() + (size_t)k * (lmax + 1); A.arow = ts.d_arow.as<long long>(); A.arow0 = 0; A.add_all = 1;
+        HX_TRY(launch_duo<SPIN>(sh, dim3((unsigned)nm), st, A, SPIN == 0 ? pl->cn0.as<double2>() : pl->cn2.as<double2>()));
+    }
+    HX_HIP(hipGetLastError());
+    return HX_OK;
+}
+
+int analysis_stream_slab(StreamSweep &s, int k)
+{
+    if (k < 0 || k >= s.nslab) return fail(HX_ERR_ARG, "analysis_stream_slab: slab %d of %d", k, s.nslab);
+    return s.spin == 0 ? stream_slab<0>(s, k) : stream_slab<2>(s, k);
+}
+
+int analysis_stream_end(StreamSweep &s)
+{
+    hx_plan *pl = s.pl;
+    hx_plan::TaskSet &ts = stream_tasks(pl, s.spin);
+    const SweepShape sh = sweep_shape(s.spin, s.nb);
+    const int ng = sh.ng + (sh.nbx > 0 ? 1 : 0), nm = pl->lmax + 1, pcol = sweep_pcol(sh);
+    PlanDev P = pl->dev();
+    ProfScope ps("alm_reduce");
+    if (s.spin == 0)
+        hipLaunchKernelGGL(k_alm_reduce<0>, dim3(nm), dim3(256), 0, rt().stream, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(), pl->partial.as<double>(),
+                           0LL, 0, 1, s.nb, ng, pcol, s.d_fl, 0, s.d_alms, pl->nlm, ts.d_arow.as<long long>(), pl->al0.as<double>());
+    else
+        hipLaunchKernelGGL(k_alm_reduce<2>, dim3(nm), dim3(256), 0, rt().stream, P, ts.d_tasks.as<LegTask>(), ts.d_of_m.as<MTasks>(), pl->partial.as<double>(),
+                           0LL, 0, 1, s.nb, ng, pcol, s.d_fl, 0, s.d_alms, pl->nlm, ts.d_arow.as<long long>(), pl->al2.as<double>());
+    HX_HIP(hipGetLastError());
     return HX_OK;
 }
 

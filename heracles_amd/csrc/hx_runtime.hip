@@ -209,8 +209,9 @@ struct CopyPool {
 };
 
 struct Stager {
-    void *pin[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    static constexpr int NPIN = 4;  // uploads rotate through all four (three DMAs queued while the host fills the fourth); downloads use the first two
+    void *pin[NPIN] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[NPIN] = {nullptr, nullptr, nullptr, nullptr};
     int nthreads = 1;
     bool ok = false, tried = false;
     CopyPool *pool = nullptr;  // leaked on purpose: its detached workers may outlive static destruction
@@ -223,7 +224,7 @@ struct Stager {
         cpu_set_t old;
         const bool have_old = sched_getaffinity(0, sizeof(old), &old) == 0;
         pin_thread_to(cpus);
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NPIN; ++i) {
             if (hipHostMalloc(&pin[i], STAGE_CHUNK, hipHostMallocDefault) != hipSuccess ||
                 hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
                 (void)hipGetLastError();
@@ -252,7 +253,7 @@ struct Stager {
     // hx_init on another device: the events belong to the old device's context
     void reset_events()
     {
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NPIN; ++i)
             if (ev[i]) {
                 (void)hipEventDestroy(ev[i]);
                 ev[i] = nullptr;
@@ -322,9 +323,16 @@ int copy_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t on)
         HX_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
         return HX_OK;
     }
-    int i = 0;
-    for (size_t off = 0; off < bytes; off += STAGE_CHUNK, i ^= 1) {
-        const size_t len = std::min(STAGE_CHUNK, bytes - off);
+    // equal chunks (a 67 MB copy as 64 + 3 MB has nothing to overlap its large DMA with), and the buffers alternate ACROSS calls: a
+    // caller that uploads many pieces in a row (the ring slabs of hx_map2alm_multi: 40 pieces of 67 MB each) keeps the host copy of one
+    // piece under the DMA of the piece before it -- starting every call on buffer 0 halved its rate (27 instead of 56 GB/s; two buffers in turn: 51)
+    static int next_buf = 0;
+    const size_t nchunk = (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK;
+    const size_t chunk = ((bytes + nchunk - 1) / nchunk + 4095) & ~(size_t)4095;
+    for (size_t off = 0; off < bytes; off += chunk) {
+        const int i = next_buf;
+        next_buf = (next_buf + 1) % Stager::NPIN;
+        const size_t len = std::min(chunk, bytes - off);
         HX_HIP(hipEventSynchronize(s.ev[i]));  // the DMA that last read this buffer has finished
         parallel_memcpy(s.pin[i], (const char *)src_host + off, len, s.nthreads);
         HX_HIP(hipMemcpyAsync((char *)dst_dev + off, s.pin[i], len, hipMemcpyHostToDevice, st));
@@ -351,6 +359,9 @@ int copy_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t on)
         const uintptr_t a1 = ((uintptr_t)dst_host + bytes) & ~(((uintptr_t)2 << 20) - 1);
         if (a1 > a0) (void)madvise((void *)a0, (size_t)(a1 - a0), MADV_HUGEPAGE);
     }
+    // (an upload on another stream may still be reading the two buffers used here)
+    HX_HIP(hipEventSynchronize(s.ev[0]));
+    HX_HIP(hipEventSynchronize(s.ev[1]));
     const size_t nchunk = (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK;
     auto issue = [&](size_t c) -> int {
         const size_t off = c * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - off);

@@ -823,10 +823,11 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
             pl->fft_classes.push_back(c);
         }
         if (upload(pl->fft_rp_list, list) != HX_OK) { delete pl; return nullptr; }
+        pl->h_fft_rp_list = list;
     }
     pl->twN = std::max(maxM, 2);
     pl->lds_fft = (size_t)lds_fft_slots(std::min(maxM, cap)) * sizeof(double2);
-    pl->h_sth = sth; pl->h_z = z; pl->h_nsub = nsub;
+    pl->h_sth = sth; pl->h_z = z; pl->h_nsub = nsub; pl->h_startN = sN; pl->h_startS = sS;
     // Bluestein tables: one spectrum per distinct non-power-of-two sub-length
     std::vector<int> blu_list, blu_split;
     long long btot = 0;
@@ -911,9 +912,10 @@ extern "C" void hx_plan_destroy(hx_plan *plan)
     if (!plan) return;
     if (rt().ready) (void)hipStreamSynchronize(rt().stream);
     for (int i = 0; i < hx_plan::NSTAGE; ++i) {
-        if (plan->stage_up[i]) (void)hipEventDestroy(plan->stage_up[i]);
         if (plan->stage_done[i]) (void)hipEventDestroy(plan->stage_done[i]);
     }
+    for (int i = 0; i < hx_plan::NUNIT_EV; ++i)
+        if (plan->unit_up[i]) (void)hipEventDestroy(plan->unit_up[i]);
     delete plan;
 }
 
@@ -942,9 +944,20 @@ int ensure_rec2(hx_plan *pl)
 // One launch per FFT-size class, so that every class gets the LDS it needs and no more
 // (a 4096-point ring must not reserve the 128 KiB of an 8192-point Bluestein ring).
 template <int MODE>
-static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, const double2 *zin, double2 *Y)
+static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, const double2 *zin, double2 *Y, int rp_lo = 0,
+                                 int rp_hi = 0x7fffffff)
 {
-    for (const auto &c : pl->fft_classes) {
+    for (const auto &cls : pl->fft_classes) {
+        // the ring pairs of the class that lie in [rp_lo, rp_hi): its list is in descending order, so they are one run of it
+        hx_plan::FftClass c = cls;
+        if (rp_lo > 0 || rp_hi < pl->nrp) {
+            const int *b = pl->h_fft_rp_list.data() + cls.first, *e = b + cls.count;
+            const int *x = std::lower_bound(b, e, rp_hi, [](int rp, int lim) { return rp >= lim; });  // first rp < rp_hi
+            const int *y = std::lower_bound(b, e, rp_lo, [](int rp, int lim) { return rp >= lim; });  // first rp < rp_lo
+            c.first = cls.first + (int)(x - b);
+            c.count = (int)(y - x);
+            if (c.count <= 0) continue;
+        }
         if (c.big < 0) {  // plain 2^k rings: two sub-DFTs per work item (k_ring_pairfft)
             const int threads = 2 * std::max(64, c.M / 16);
             const size_t lds = (size_t)(2 * lds_fft_slots(c.M) + ring_ph_hi(c.M) + 64) * sizeof(double2);
@@ -1026,11 +1039,11 @@ __global__ __launch_bounds__(256) void k_pixw_symmetry(PlanDev P, const double *
     if (!ok) *flag = 0;
 }
 
-int launch_ring_subdft_maps(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, double2 *Y)
+int launch_ring_subdft_maps(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, double2 *Y, int rp_lo, int rp_hi)
 {
     ProfScope ps("ring_fft");
     if (d_pw && pl->pw_checked != d_pw) HX_TRY(classify_pixel_weights(pl, d_pw));  // (entry points that did not do it themselves)
-    return launch_subdft_classes<0>(pl, nb, d_maps, d_pw, nullptr, Y);
+    return launch_subdft_classes<0>(pl, nb, d_maps, d_pw, nullptr, Y, rp_lo, rp_hi);
 }
 
 // Called by the entry points of the C ABI right after they have bound their pixel-weight array, before they queue anything else:
@@ -1183,8 +1196,11 @@ static int map2alm_multi_impl(hx_plan *pl, int njobs, const int *spins, const in
     HX_TRY(classify_pixel_weights(pl, vpw.as<double>()));
     std::vector<InView> vfl(njobs);
     std::vector<OutView> valm(njobs);
-    struct Sweep { int job, c0, nb; };
+    struct Sweep { int job, c0, nb; bool stream; };
     std::vector<Sweep> sweeps;
+    // HX_STREAM_SLABS: slabs of rings per streamed sweep (default 12; 0 or 1: the sweeps of round 3 -- whole maps, 5 fields / 8 maps at most)
+    static int want_slabs = -1;
+    if (want_slabs < 0) { const char *e = getenv("HX_STREAM_SLABS"); want_slabs = e ? atoi(e) : 12; }
     bool any_host = false;
     for (int j = 0; j < njobs; ++j) {
         HX_TRY(vfl[j].bind(fls ? fls[j] : nullptr, sizeof(double) * (pl->lmax + 1)));
@@ -1193,99 +1209,156 @@ static int map2alm_multi_impl(hx_plan *pl, int njobs, const int *spins, const in
         any_host = any_host || host;
         const int unit = spins[j] ? 2 : 1, cap = spins[j] ? 10 : 8;  // 5 spin-2 fields / 8 spin-0 maps: one full column group each
         for (int c0 = 0; c0 < ncomps[j];) {
-            int nb = host ? std::min(cap, ncomps[j] - c0) : analysis_next_batch(spins[j], ncomps[j] - c0);
-            // spin 2: two even sweeps rather than a full and a small one (a sweep costs ~76 ms before its first column);
-            // spin 0: a full group, then the rest -- small spin-0 sweeps run on the vector-unit kernel at 23 ms per map
-            if (host && spins[j] && ncomps[j] - c0 > cap && ncomps[j] - c0 < 2 * cap) nb = ((ncomps[j] - c0) / unit + 1) / 2 * unit;
-            sweeps.push_back({j, c0, nb});
+            // host maps: the sweep that costs least per map, its rings uploaded and transformed slab by slab (StreamSweep) ...
+            int nb = analysis_next_batch(spins[j], ncomps[j] - c0);
+            const bool stream = host && want_slabs > 1 && copy_stream() != nullptr && analysis_can_stream(pl, spins[j], nb);
+            if (host && !stream) {
+                // ... or, where that is not possible (the small batches of the vector-unit kernels), whole maps in small sweeps
+                nb = std::min(cap, ncomps[j] - c0);
+                // spin 2: two even sweeps rather than a full and a small one (a sweep costs ~76 ms before its first column);
+                // spin 0: a full group, then the rest -- small spin-0 sweeps run on the vector-unit kernel at 23 ms per map
+                if (spins[j] && ncomps[j] - c0 > cap && ncomps[j] - c0 < 2 * cap) nb = ((ncomps[j] - c0) / unit + 1) / 2 * unit;
+            }
+            sweeps.push_back({j, c0, nb, stream});
             c0 += nb;
         }
     }
-    if (any_host && staged(sweeps.back().job)) {
+    if (any_host && staged(sweeps.back().job) && !sweeps.back().stream) {
         for (;;) {  // halve the last sweep until it holds at most two units
             Sweep &l = sweeps.back();
             const int unit = spins[l.job] ? 2 : 1, units = l.nb / unit;
             if (units <= 2) break;
             const int first = (units + 1) / 2 * unit;
-            const Sweep tail = {l.job, l.c0 + first, l.nb - first};
+            const Sweep tail = {l.job, l.c0 + first, l.nb - first, false};
             l.nb = first;
             sweeps.push_back(tail);
         }
     }
     hipStream_t cs = any_host ? copy_stream() : nullptr;
-    constexpr int NST = hx_plan::NSTAGE;
     size_t stage_bytes = 0;
     for (const Sweep &w : sweeps)
         if (staged(w.job)) stage_bytes = std::max(stage_bytes, (size_t)(sizeof(double) * (size_t)w.nb * (size_t)pl->npix));
+    // host sweeps are numbered in upload order; buffer h % NST holds host sweep h.  THREE buffers: the upload of sweep h + 1 waits
+    // for the transform of sweep h - 2, not h - 1 -- with two, a 4.8 GB upload sat 130 ms behind the 240 ms transform of the
+    // spin-2 sweep before it (tools/time_host_multi.py).  Streamed sweeps are up to 32 GB each and end right behind their upload: two.
+    const int NST = 3 * (double)stage_bytes > 64e9 ? 2 : hx_plan::NSTAGE;
+    constexpr int NEV = hx_plan::NUNIT_EV;
+    hipEvent_t *unit_up = pl->unit_up;
     if (any_host) {
         if (!cs) return fail(HX_ERR_HIP, "hx_map2alm_multi: no copy stream");
         for (int i = 0; i < NST; ++i) {
             HX_TRY(pl->stage[i].alloc(stage_bytes));
-            if (!pl->stage_up[i]) HX_HIP(hipEventCreateWithFlags(&pl->stage_up[i], hipEventDisableTiming));
             if (!pl->stage_done[i]) HX_HIP(hipEventCreateWithFlags(&pl->stage_done[i], hipEventDisableTiming));
         }
+        for (int i = 0; i < NEV; ++i)
+            if (!unit_up[i]) HX_HIP(hipEventCreateWithFlags(&unit_up[i], hipEventDisableTiming));
     }
-    // host sweeps are numbered in upload order; buffer h % NST holds host sweep h.  THREE buffers: the upload of sweep h + 1 waits
-    // for the transform of sweep h - 2, not h - 1 -- with two, a 4.8 GB upload sat 130 ms behind the 240 ms transform of the
-    // spin-2 sweep before it (tools/time_host_multi.py)
     std::vector<int> hidx(sweeps.size(), -1);
     int nh = 0;
     for (size_t k = 0; k < sweeps.size(); ++k)
         if (staged(sweeps[k].job)) hidx[k] = nh++;
-    auto upload = [&](size_t k) -> int {
+    // streamed sweeps: slab edges, task tables and scratch of ALL of them before anything is queued
+    std::vector<StreamSweep> ss(sweeps.size());
+    for (size_t k = 0; k < sweeps.size(); ++k) {
         const Sweep &w = sweeps[k];
-        const int b = hidx[k] % NST;
-        if (hidx[k] >= NST) HX_HIP(hipEventSynchronize(pl->stage_done[b]));  // host sweep h - NST has read this buffer
-        if (comp_maps && comp_maps[w.job]) {
-            const double *const *cm = comp_maps[w.job] + w.c0;
+        if (!w.stream) continue;
+        HX_TRY(analysis_stream_plan(pl, spins[w.job], w.nb, want_slabs, ss[k]));
+        ss[k].d_maps = pl->stage[hidx[k] % NST].as<double>();
+        ss[k].d_alms = valm[w.job].as<double2>() + (size_t)w.c0 * pl->nlm;
+        ss[k].d_rw = vrw.as<double>(); ss[k].d_pw = vpw.as<double>(); ss[k].d_fl = vfl[w.job].as<double>();
+    }
+    // units of work in order: a whole sweep, or one slab of a streamed sweep; units of host sweeps have an upload in front of them
+    struct Unit { size_t k; int slab; };
+    std::vector<Unit> units;
+    for (size_t k = 0; k < sweeps.size(); ++k) {
+        if (sweeps[k].stream)
+            for (int q = 0; q < ss[k].nslab; ++q) units.push_back({k, q});
+        else
+            units.push_back({k, -1});
+    }
+    std::vector<int> uidx(units.size(), -1);  // number of the unit among those with an upload
+    int nu = 0;
+    for (size_t u = 0; u < units.size(); ++u)
+        if (hidx[units[u].k] >= 0) uidx[u] = nu++;
+    // component c of a sweep: its source array and its place in the staging buffer
+    auto comp_src = [&](const Sweep &w, int c) -> const double * {
+        return (comp_maps && comp_maps[w.job]) ? comp_maps[w.job][w.c0 + c] : maps[w.job] + (size_t)(w.c0 + c) * pl->npix;
+    };
+    auto push = [&](void *dst, const double *src, size_t bytes) -> int {
+        if (is_device_ptr(src)) HX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, cs));
+        else HX_TRY(copy_h2d(dst, src, bytes, cs));
+        return HX_OK;
+    };
+    auto upload = [&](size_t u) -> int {
+        const Sweep &w = sweeps[units[u].k];
+        const int b = hidx[units[u].k] % NST, slab = units[u].slab;
+        if (slab <= 0 && hidx[units[u].k] >= NST) HX_HIP(hipEventSynchronize(pl->stage_done[b]));  // host sweep h - NST has read this buffer
+        double *stage = pl->stage[b].as<double>();
+        if (slab < 0) {
             for (int c = 0; c < w.nb;) {  // runs of components that lie behind one another in memory: one transfer each
                 int e = c + 1;
-                while (e < w.nb && cm[e] == cm[e - 1] + pl->npix) ++e;
-                char *dst = (char *)pl->stage[b].p + sizeof(double) * (size_t)c * pl->npix;
-                const size_t bytes = sizeof(double) * (size_t)(e - c) * pl->npix;
-                if (is_device_ptr(cm[c])) HX_HIP(hipMemcpyAsync(dst, cm[c], bytes, hipMemcpyDeviceToDevice, cs));
-                else HX_TRY(copy_h2d(dst, cm[c], bytes, cs));
+                while (e < w.nb && comp_src(w, e) == comp_src(w, e - 1) + pl->npix) ++e;
+                HX_TRY(push(stage + (size_t)c * pl->npix, comp_src(w, c), sizeof(double) * (size_t)(e - c) * pl->npix));
                 c = e;
             }
         } else {
-            HX_TRY(copy_h2d(pl->stage[b].p, maps[w.job] + (size_t)w.c0 * pl->npix, sizeof(double) * (size_t)w.nb * pl->npix, cs));
+            // the rings of the slab: a block of northern rings and the block of their southern partners, per component
+            const StreamSweep &sw = ss[units[u].k];
+            const int r0 = sw.rp_edge[slab], r1 = std::min(sw.rp_edge[slab + 1], pl->nrp) - 1;  // first and last ring pair
+            const long long n0 = pl->h_startN[r0], n1 = pl->h_startN[r1] + 4LL * pl->h_nsub[r1];
+            const int rs = pl->h_startS[r1] >= 0 ? r1 : r1 - 1;                                  // (the equator has no southern ring)
+            const long long s0 = rs >= r0 ? pl->h_startS[rs] : 0, s1 = rs >= r0 ? pl->h_startS[r0] + 4LL * pl->h_nsub[r0] : 0;
+            for (int c = 0; c < w.nb; ++c) {
+                const double *src = comp_src(w, c);
+                double *dst = stage + (size_t)c * pl->npix;
+                HX_TRY(push(dst + n0, src + n0, sizeof(double) * (size_t)(n1 - n0)));
+                if (s1 > s0) HX_TRY(push(dst + s0, src + s0, sizeof(double) * (size_t)(s1 - s0)));
+            }
         }
-        HX_HIP(hipEventRecord(pl->stage_up[b], cs));
+        HX_HIP(hipEventRecord(unit_up[uidx[u] % NEV], cs));
         return HX_OK;
     };
-    auto next_host = [&](size_t k) -> size_t {  // first host sweep after k
-        for (size_t q = k + 1; q < sweeps.size(); ++q)
-            if (hidx[q] >= 0) return q;
-        return sweeps.size();
+    auto next_upload = [&](size_t u) -> size_t {  // first unit after u with an upload
+        for (size_t q = u + 1; q < units.size(); ++q)
+            if (uidx[q] >= 0) return q;
+        return units.size();
     };
-    // HX_TRACE=1: host-side timeline of the call on stderr (ms since entry): when each sweep's upload was staged and issued
+    // HX_TRACE=1: host-side timeline of the call on stderr (ms since entry): when each unit's upload was staged and issued
     const bool trace = getenv("HX_TRACE") != nullptr;
     const auto t_entry = std::chrono::steady_clock::now();
     auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count(); };
-    auto traced_upload = [&](size_t k) -> int {
+    auto traced_upload = [&](size_t u) -> int {
         const double t0 = now_ms();
-        const int rc = upload(k);
-        if (trace)
-            fprintf(stderr, "[hx] multi: sweep %zu (job %d, spin %d, %d comps, %.1f GB) staged %.0f -> %.0f ms\n", k, sweeps[k].job, spins[sweeps[k].job],
-                    sweeps[k].nb, sizeof(double) * (double)sweeps[k].nb * pl->npix / 1e9, t0, now_ms());
+        const int rc = upload(u);
+        if (trace) {
+            const Sweep &w = sweeps[units[u].k];
+            fprintf(stderr, "[hx] multi: sweep %zu (job %d, spin %d, %d comps) slab %d staged %.0f -> %.0f ms\n", units[u].k, w.job, spins[w.job], w.nb, units[u].slab, t0, now_ms());
+        }
         return rc;
     };
-    const size_t first_host = next_host((size_t)-1);
-    if (first_host < sweeps.size()) HX_TRY(traced_upload(first_host));
-    for (size_t k = 0; k < sweeps.size(); ++k) {
+    const size_t first_up = next_upload((size_t)-1);
+    if (first_up < units.size()) HX_TRY(traced_upload(first_up));
+    for (size_t u = 0; u < units.size(); ++u) {
+        const size_t k = units[u].k;
         const Sweep &w = sweeps[k];
-        const double *src = maps[w.job] + (size_t)w.c0 * pl->npix;
-        if (hidx[k] >= 0) {
-            HX_HIP(hipStreamWaitEvent(rt().stream, pl->stage_up[hidx[k] % NST], 0));
-            src = pl->stage[hidx[k] % NST].as<double>();
+        const int slab = units[u].slab;
+        if (uidx[u] >= 0) HX_HIP(hipStreamWaitEvent(rt().stream, unit_up[uidx[u] % NEV], 0));
+        bool done = true;
+        if (slab < 0) {
+            const double *src = hidx[k] >= 0 ? pl->stage[hidx[k] % NST].as<double>() : maps[w.job] + (size_t)w.c0 * pl->npix;
+            HX_TRY(analysis_batch(pl, spins[w.job], w.nb, src, valm[w.job].as<double2>() + (size_t)w.c0 * pl->nlm, vrw.as<double>(), vpw.as<double>(),
+                                  vfl[w.job].as<double>(), 0));
+        } else {
+            if (slab == 0) HX_TRY(analysis_stream_start(ss[k]));
+            HX_TRY(analysis_stream_slab(ss[k], slab));
+            done = slab + 1 == ss[k].nslab;
+            if (done) HX_TRY(analysis_stream_end(ss[k]));
         }
-        HX_TRY(analysis_batch(pl, spins[w.job], w.nb, src, valm[w.job].as<double2>() + (size_t)w.c0 * pl->nlm, vrw.as<double>(), vpw.as<double>(),
-                              vfl[w.job].as<double>(), 0));
-        if (hidx[k] >= 0) {
-            HX_HIP(hipEventRecord(pl->stage_done[hidx[k] % NST], rt().stream));
-            const size_t q = next_host(k);
-            if (trace) fprintf(stderr, "[hx] multi: sweep %zu transform queued at %.0f ms\n", k, now_ms());
-            if (q < sweeps.size()) HX_TRY(traced_upload(q));  // the host thread stages the next sweep while this one is transformed
+        if (done && hidx[k] >= 0) HX_HIP(hipEventRecord(pl->stage_done[hidx[k] % NST], rt().stream));
+        if (trace) fprintf(stderr, "[hx] multi: sweep %zu slab %d queued at %.0f ms\n", k, slab, now_ms());
+        if (uidx[u] >= 0) {
+            const size_t q = next_upload(u);
+            if (q < units.size()) HX_TRY(traced_upload(q));  // the host thread stages the next unit while this one is transformed
         }
     }
     for (int j = 0; j < njobs; ++j) HX_TRY(valm[j].finish());

@@ -300,6 +300,7 @@ struct hx_plan {
     hx::DevBuf z, omz, sth, rwdef, nsub, shifted, startN, startS, bhat_off, tw, bhat, mfac, kfac2, rec0, rec2, cn0, al0, cn2, al2;
     std::vector<double> h_sth, h_z;
     std::vector<int> h_nsub;
+    std::vector<long long> h_startN, h_startS;   // first pixel of the northern / southern ring of a pair (-1: the equator has no southern ring)
     struct TaskSet {
         bool built = false;
         std::vector<hx::LegTask> tasks;       // ordered by m; tasks of one m contiguous
@@ -313,12 +314,15 @@ struct hx_plan {
     struct FftClass { int M, first, count, big; };
     std::vector<FftClass> fft_classes;   // ring pairs grouped by in-LDS FFT length
     hx::DevBuf fft_rp_list;
+    std::vector<int> h_fft_rp_list;      // (host copy: ring pairs in DESCENDING order within a class)
     hx::DevBuf Y, F, partial, d_dbg, resid, resid_maps, Fsyn, pw_sym;
     const double *pw_checked = nullptr;       // the pixel-weight array of the current call that pw_mode describes
     int pw_mode = 0;                          // 1: one weight per pixel; 2: the array repeats over the quadrants of every ring and from north to south (healpy's weights)
     static constexpr int NSTAGE = 3;          // staging buffers of the upload pipeline (hx_map2alm_multi / _list; hx_map2alm of host maps is one job of it)
     hx::DevBuf stage[NSTAGE];                 // maps of one sweep each: host input uploaded sweep by sweep
-    hipEvent_t stage_up[NSTAGE] = {nullptr, nullptr, nullptr}, stage_done[NSTAGE] = {nullptr, nullptr, nullptr};
+    hipEvent_t stage_done[NSTAGE] = {nullptr, nullptr, nullptr};   // the transform of the sweep in buffer i has been queued behind this
+    static constexpr int NUNIT_EV = 4;        // upload events in flight: a unit (a sweep, or a slab of rings of a streamed sweep) waits for its own before the next but one is recorded
+    hipEvent_t unit_up[NUNIT_EV] = {nullptr, nullptr, nullptr, nullptr};
     hx::PlanDev dev() const;
 };
 
@@ -326,7 +330,7 @@ namespace hx {
 // hx_sht.hip
 hx_plan *plan_create_equiangular(int N, int lmax);
 int ensure_rec2(hx_plan *pl);
-int launch_ring_subdft_maps(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, double2 *Y);
+int launch_ring_subdft_maps(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, double2 *Y, int rp_lo = 0, int rp_hi = 0x7fffffff);  // ring pairs [rp_lo, rp_hi) only
 int classify_pixel_weights(hx_plan *pl, const double *d_pw);
 // hx_analysis.hip
 int build_tasks(hx_plan *pl, int spin);
@@ -335,6 +339,22 @@ int analysis_batch(hx_plan *pl, int spin, int nb, const double *d_maps, double2 
 int analysis_max_comp(int spin);
 int analysis_next_batch(int spin, int remaining);
 int analysis_max_batch(int spin, int ncomp);
+// One analysis sweep whose rings ARRIVE IN SLABS (hx_map2alm_multi on host maps): the ring FFT, the operand pass and the ring groups of the
+// Legendre kernel run slab by slab behind the upload, the change of layout once at the end -- the same sums in the same order as the sweep
+// over resident maps (bit-identical alms)
+struct StreamSweep {
+    hx_plan *pl = nullptr;
+    int spin = 0, nb = 0, nslab = 0;
+    const double *d_maps = nullptr, *d_rw = nullptr, *d_pw = nullptr, *d_fl = nullptr;
+    double2 *d_alms = nullptr;
+    std::vector<int> rp_edge;   // slab k = ring pairs [rp_edge[k], rp_edge[k + 1]): whole 32-ring-pair blocks, about equal numbers of pixels
+    DevBuf d_of_m;              // [nslab][lmax + 1]: the ring groups of order m that are complete with slab k
+};
+bool analysis_can_stream(hx_plan *pl, int spin, int nb);
+int analysis_stream_plan(hx_plan *pl, int spin, int nb, int nslab, StreamSweep &s);   // slab edges, task tables, scratch (grown, never shrunk): before anything of the call is queued
+int analysis_stream_start(StreamSweep &s);  // zeroes the accumulation rows (queued on the library stream, in front of slab 0)
+int analysis_stream_slab(StreamSweep &s, int k);
+int analysis_stream_end(StreamSweep &s);
 // hx_legendre_valu.hip: one map (spin 0) / one field (spin 2) per sweep on the FP64 vector unit
 int launch_valu_chunk(hx_plan *pl, int spin, hx_plan::TaskSet &ts, int m0, int m1, int c0, const double *d_rw);
 int valu_task_blocks(int spin);      // 32-ring-pair blocks per task
