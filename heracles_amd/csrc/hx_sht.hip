@@ -1172,13 +1172,14 @@ extern "C" int hx_map2alm(hx_plan *pl, int spin, int ncomp, const double *maps, 
 }
 
 // Several transforms as ONE call (the loop of heracles/mapping.py:151-172 over the (field, bin) maps of a job): host maps of ALL
-// jobs go through one upload pipeline -- sweep k + 1 is staged (pageable -> pinned -> HBM, second stream) while the GPU transforms
-// sweep k, across job boundaries -- so that the call costs its PCIe time plus the transform of the LAST sweep.  Jobs are cut into
-// sweeps of at most 5 spin-2 fields / 8 spin-0 maps (the first transform starts after a third of the upload at the bench size;
-// smaller sweeps cost more matrix-pipe time than they hide), and the last sweep of the call is halved until it holds at most two units: what is left exposed behind the last byte
-// of the upload is a small transform.  Callers put their large jobs first.  niter = 0 only (iterations need their maps resident).
-// (At the bench size -- 32 GB of spin-2 and 16 GB of spin-0 maps at 55 GB/s -- the sweeps are 5 + 5 fields and 8 + 2 maps: their
-// transforms, 240 + 240 + 100 + 50 ms, ride under the 880 ms of uploads except the last.)
+// jobs go through one upload pipeline (pageable -> pinned -> HBM, second stream) that the transforms follow, across job boundaries, so
+// that the call costs its PCIe time plus very little.  A host job is cut into the sweeps that cost least per map (ten fields / ten maps
+// at the bench size) and every such sweep runs as a StreamSweep (hx_sht_common.h): its rings are uploaded slab by slab -- for every
+// component the block of northern rings of the slab and the block of their southern partners -- and the slab's ring FFTs, operand rows
+// and completed ring groups are queued behind it; what is left behind the last byte is a twelfth of a sweep (21 ms at the bench size:
+// 48 GB in 882 ms).  Sweeps that cannot be streamed (the small batches of the vector-unit kernels, HX_STREAM_SLABS=0) are uploaded whole,
+// at most 5 spin-2 fields / 8 spin-0 maps at a time with the last one halved until it holds at most two units (round 3's pipeline: 960 ms).
+// Callers put their large jobs first.  niter = 0 only (iterations need their maps resident).
 // comp_maps (hx_map2alm_list): job j's components are SEPARATE arrays comp_maps[j][c] (maps[j] = the first of them); they are
 // gathered into the staging buffer of their sweep -- host arrays through the pinned pipeline, device arrays by copies on the
 // upload stream; neighbours in memory go as one transfer.

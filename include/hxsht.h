@@ -109,8 +109,8 @@ int hx_map2alm(hx_plan *plan, int spin, int ncomp, const double *maps, double *a
 int hx_alm2map(hx_plan *plan, int spin, int ncomp, const double *alms, double *maps);
 /* The loop of heracles/mapping.py:151-172 (one transform per (field, bin) map) as ONE call over njobs transforms
  * (spins[j], ncomps[j], maps[j], alms[j], fls[j] as in hx_map2alm; fls may be NULL; niter = 0): host maps of all jobs share one
- * upload pipeline, so that the uploads of job j + 1 overlap the transforms of job j and the call costs its PCIe time plus one small
- * transform.  Put large jobs first.  Results are those of njobs hx_map2alm calls up to the rounding of different sweep sizes. */
+ * upload pipeline that the transforms follow slab of rings by slab of rings, so that the call costs its PCIe time plus a twelfth of one
+ * sweep.  Put large jobs first.  Results are bit-identical to those of njobs hx_map2alm calls on the same (host or device) maps. */
 int hx_map2alm_multi(hx_plan *plan, int njobs, const int *spins, const int *ncomps, const double *const *maps, double *const *alms,
                      const double *ring_weights, const double *pix_weights, const double *const *fls);
 /* The same for SEPARATE arrays, as heracles holds them (heracles/mapping.py:151-172: one array per (field, bin)): map i is
