@@ -808,6 +808,20 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
 #ifndef HX_DUO_FMACDPP
 #define HX_DUO_FMACDPP 1  // p' x + q' as (row broadcast, multiply-add with a broadcast source) instead of (two row broadcasts, multiply-add)
 #endif
+// Gaps in the matrix stream (round 4, second session; tools/ubench_duo.hip, profiles/r04_ubench_duo_gaps.txt).  A wave that streams FP64
+// matrix instructions back to back starves the FP64 vector work of the other wave on its SIMD completely; with `s_nop 3` behind every
+// (16 x 16 x 4, 4 x 4 x 4) pair and s_setprio 3 on the other wave, exactly two of its FMAs get through per gap, at 7.8 cycles of
+// matrix-pipe time each (s_nop 7: 2.8 per gap at 11.8).  In the kernel the other group's recursion and reduction then advance under this
+// group's matrix block (cycle accounting per wave-block, ten fields: recursion 4180 -> 3260, reduction 1965 -> 740, second barrier 547 ->
+// 208) -- and the matrix block pays for every instruction let in (5390 -> 7850 with s_nop 7): 344 -> 337 ms for ten fields, a wash or a
+// loss elsewhere (five fields 196 -> 203, ten spin-0 maps 100 -> 102); s_nop 3 is a gain of ~1 % everywhere.  HX_DUO_GAP = n: s_nop n - 1
+// behind every such pair (0: none; -1: 8 for the 40-column shape, none for the 24- and 36-column ones -- six fields 222 -> 225 ms, nine 303 -> 310 with s_nop 3 --, 4 otherwise: five fields 196 -> 194, eight 275 -> 272, ten spin-0 maps 100.2 -> 99.2, sixteen 147.6 -> 139.7); HX_DUO_PRIO: s_setprio 3 outside the matrix block.
+#ifndef HX_DUO_GAP
+#define HX_DUO_GAP -1
+#endif
+#ifndef HX_DUO_PRIO
+#define HX_DUO_PRIO 1
+#endif
 #ifndef HX_DUO_ABL
 #define HX_DUO_ABL 0  // timing experiments only: 1 no matrix instructions, 2 no recursion, 4 no flush, 8 plain stores instead of atomics, 32 cycle accounting
 #endif
@@ -828,6 +842,9 @@ __device__ __forceinline__ double row_bcast_fmac(double t, double p, double x)
     return t;
 }
 
+#if HX_DUO_ABL & 128  // diagnostic build: when and where the work-group of every m ran (100 MHz wall clock, XCC, HW_ID)
+__device__ unsigned long long g_duo_stamp[8192 * 3];
+#endif
 // NSUB: 32-l blocks per flush (their D tiles stay in registers; one staging round and one pair of barriers per NSUB blocks)
 template <int SPIN, int NG, int NBX, int NSUB = 1>
 __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const double2 *__restrict__ coefn)
@@ -837,6 +854,7 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
     constexpr int NXA = NBX > 0 ? NBX : 1;
     constexpr int DQ0 = NG * 512, DSZ = NG * 512 + NBX * 128;
     constexpr bool HALFB = SPIN == 2;
+    constexpr int GAPN = HX_DUO_GAP >= 0 ? HX_DUO_GAP : ((SPIN == 2 && NG == 2 && NBX == 2) ? 8 : (SPIN == 2 && NG + NBX == 3) ? 0 : 4);
     constexpr int NPB = HALFB ? 1 : 2;  // operand positions kept in registers
     // doubles per wave of its tile: the 16 x 64 lambda tile (2048), or the D tiles of a flush if they need more (two blocks of 36 / 40
     // columns: 2304 / 2560 -- 80 KiB per work-group, still two per CU)
@@ -852,6 +870,9 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
 #endif
     const PlanDev &P = A.P;
     const int m = A.m0 + blockIdx.x * A.ms, lmax = P.lmax;
+#if HX_DUO_ABL & 128
+    const unsigned long long stamp_begin = wall_clock64();
+#endif
     const MTasks mt = A.of_m[m];
     const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
     const int off = (l0 + m) & 1;
@@ -879,6 +900,7 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
         __builtin_amdgcn_s_barrier();
     };
     int n_mf = 0, n_rec = 0;
+    if (HX_DUO_PRIO) __builtin_amdgcn_s_setprio(3);
 #if HX_DUO_ABL & 32
     // cycle accounting (diagnostic build): [0] task prologue, [1] recursion (live / mixed), [2] recursion (dead), [3] matrix block, [4] staging + wait at the
     // first barrier, [5] reduction, [6] wait at the second barrier
@@ -1058,6 +1080,7 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
                 mine = mine || rm >= 2;
                 if (rm >= 2 && !(HX_DUO_ABL & 1)) {
                     n_mf = __builtin_amdgcn_readfirstlane(n_mf + 1);
+                    if (HX_DUO_PRIO) __builtin_amdgcn_s_setprio(0);
                     constexpr int PF = 3;
                     auto a_fetch = [&](int sp) __attribute__((always_inline)) {
                         const int op = SPIN == 0 ? 0 : sp & 1, q = SPIN == 0 ? sp : sp >> 1;
@@ -1075,13 +1098,26 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
 #pragma unroll
                         for (int pos = 0; pos < 2; ++pos) {
                             const double a = pos ? a1 : a0;
+                            if (GAPN > 0) {
+                                // one 16 x 16 x 4 (+ one 4 x 4 x 4) instruction, then a gap of a few cycles: see HX_DUO_GAP
 #pragma unroll
-                            for (int g = 0; g < NG; ++g) acc[sub][g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[sp][HALFB ? 0 : pos][g], acc[sub][g][pos], 0, 0, 0);
+                                for (int g = 0; g < (NG > NBX ? NG : NBX); ++g) {
+                                    if (g < NG) acc[sub][g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[sp][HALFB ? 0 : pos][g], acc[sub][g][pos], 0, 0, 0);
+                                    if (g < NBX) accx[sub][g][pos] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[sp][HALFB ? 0 : pos][g], accx[sub][g][pos], 0, 0, 0);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    asm volatile("s_nop %0" ::"n"(GAPN > 0 ? GAPN - 1 : 0));
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            } else {
 #pragma unroll
-                            for (int g = 0; g < NBX; ++g) accx[sub][g][pos] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[sp][HALFB ? 0 : pos][g], accx[sub][g][pos], 0, 0, 0);
+                                for (int g = 0; g < NG; ++g) acc[sub][g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[sp][HALFB ? 0 : pos][g], acc[sub][g][pos], 0, 0, 0);
+#pragma unroll
+                                for (int g = 0; g < NBX; ++g) accx[sub][g][pos] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[sp][HALFB ? 0 : pos][g], accx[sub][g][pos], 0, 0, 0);
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    if (HX_DUO_PRIO) __builtin_amdgcn_s_setprio(3);
                 }
                 DUO_STAMP(3);
             }
@@ -1170,6 +1206,16 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
         atomicAdd(&g_exec_flops[0], (unsigned long long)n_mf * (32ull * (NG * 2048ull + NBX * 512ull)));
         atomicAdd(&g_exec_flops[1], (unsigned long long)n_rec * (64ull * LBLK * 4ull));
     }
+#if HX_DUO_ABL & 128
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_duo_stamp[blockIdx.x * 3 + 0] = stamp_begin;
+        g_duo_stamp[blockIdx.x * 3 + 1] = wall_clock64();
+        g_duo_stamp[blockIdx.x * 3 + 2] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
 }
 
 // =====================================================================================
@@ -1530,6 +1576,20 @@ static int launch_chunk(hx_plan *pl, hx_plan::TaskSet &ts, int m0, int m1, int n
             hipLaunchKernelGGL((k_legendre_pipe<SPIN, 2, 0, 1>), pgrid, pblock, 0, st, A, cn, al);  // a second accumulator set spills 20-76 registers
         else
             return fail(HX_ERR_ARG, "legendre analysis: no kernel for %d groups + %d blocks", sh.ng, sh.nbx);
+#if defined(HX_DIAG) && (HX_DUO_ABL & 128)
+        if (const char *fn = duo_shape(sh) ? getenv("HX_DUO_STAMP_FILE") : nullptr) {
+            HX_HIP(hipStreamSynchronize(st));
+            std::vector<unsigned long long> h(8192 * 3);
+            HX_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_duo_stamp), sizeof(unsigned long long) * h.size()));
+            char name[512];
+            snprintf(name, sizeof name, "%s.spin%d", fn, SPIN);
+            if (FILE *f = fopen(name, "w")) {
+                for (int k = 0; k < std::min(nm, 8192); ++k)
+                    fprintf(f, "%d %llu %llu %llu %llu %d\n", m0 + k * ms, h[3 * k], h[3 * k + 1], h[3 * k + 2] >> 32, h[3 * k + 2] & 0xffffffffull, ts.of_m[m0 + k * ms].count);
+                fclose(f);
+            }
+        }
+#endif
 #if defined(HX_DIAG) && (HX_DUO_ABL & 32)
         if (duo_shape(sh)) {
             unsigned long long hc[18];

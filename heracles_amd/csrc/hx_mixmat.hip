@@ -118,8 +118,21 @@ __global__ void k_weight_xi(int l3max, int n, const double *__restrict__ x, cons
 //     8 q + 2 (lane >> 4) + h); rows are padded to 18 doubles, which spreads the 16 rows of a read over all 64 banks.
 constexpr int GKT = 16;          // nodes per k tile of the GEMM (GK = 32 stays the padding unit of the tables)
 constexpr int GLT = GKT + 2;     // LDS row stride in doubles
+// Where the kernel stands (round 4, work-group timelines of the HX_GEMM_STAMP build, L = 6144: 1225 tiles on 512 resident groups): a tile
+// takes 2.41 ms when two groups share a CU (1.9-2.9; 2.20 would be the matrix pipe's rate at the 2.15 GHz the part holds here: 0.92) and
+// 2.0 ms alone on a CU (HX_GEMM_HOG build: 0.55 of the pipe -- its loads run ONE k tile = 4096 cycles ahead, less than a trip to memory
+// under load, and with 243 registers a second tile in flight has no room); the launch is two full rounds to 4.3-4.8 ms and a last round
+// of 20-28 tiles per XCD, most of them alone on their CU, to 6.75 ms: matrix pipe busy 0.78.  Measured and not kept: the tiles of that
+// last round as two 128 x 64 halves (same k tiles with half the instructions each cover even less latency: 6.8 ms) and as two halves of
+// the NODES added into a zeroed G (two addends commute: still repeatable bit for bit; parts 1.37 ms each, 6.55 ms -- 3 % for a memset,
+// atomics and a second code path).  Ranges of k tiles dealt evenly to persistent groups (stream-K) would end every group together, but
+// groups that are at different nodes of their tiles no longer share the rows of T through their XCD's L2, which is what the tile order
+// of mix_ctx_init is for.
 // SYM: T2 == T, only tiles bi <= bj are listed and both halves are written (the mixing matrices); !SYM: G[i][j] = sum_k T[i][k] s[k] T2[j][k]
 // for every listed tile, colscale may be null (the last product of hx_pinv: V diag(1 / sigma^2) W^T).
+#ifdef HX_GEMM_STAMP  // diagnostic build: when and where every work-group ran
+__device__ unsigned long long g_gemm_stamp[4096 * 4];
+#endif
 template <bool SYM>
 __global__ __launch_bounds__(256, 2) void k_mixmat_gemm(const double *__restrict__ T, const double *__restrict__ T2, int kpad,
                                                         const double *__restrict__ s,
@@ -128,9 +141,17 @@ __global__ __launch_bounds__(256, 2) void k_mixmat_gemm(const double *__restrict
                                                         double *__restrict__ G, long long ldg)
 {
     __shared__ double As[2][GB][GLT], Bs[2][GB][GLT];
+#ifdef HX_GEMM_HOG  // diagnostic build (tools/build_variant.sh): ONE work-group per CU
+    __shared__ double hog[2048];
+    if (kpad < 0) { hog[threadIdx.x] = 1.0; G[0] = hog[threadIdx.x ^ 1]; }
+#endif
     const int2 tl = tiles[blockIdx.x];
     const int bi = tl.x, bj = tl.y;
     if (bi < 0) return;
+#ifdef HX_GEMM_STAMP
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+    const unsigned long long r_begin = wall_clock64();
+#endif
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1;
     double4_t acc[4][4];
@@ -224,6 +245,17 @@ __global__ __launch_bounds__(256, 2) void k_mixmat_gemm(const double *__restrict
                 if (gi < n1 && gj < n2) G[(long long)gi * ldg + gj] = colscale ? v * colscale[gj] : v;
                 if (SYM && bi != bj && gj < n1 && gi < n2) G[(long long)gj * ldg + gi] = v * colscale[gi];
             }
+#ifdef HX_GEMM_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_gemm_stamp[blockIdx.x * 4 + 0] = r_begin;
+        g_gemm_stamp[blockIdx.x * 4 + 1] = wall_clock64();
+        g_gemm_stamp[blockIdx.x * 4 + 2] = ((unsigned long long)xcc << 32) | hwid;
+        g_gemm_stamp[blockIdx.x * 4 + 3] = ((unsigned long long)(__builtin_readcyclecounter() - t_begin) << 24) | (bi << 10) | bj;
+    }
+#endif
 }
 
 // G (n1 x n2, leading dimension ldg) = T diag(s) T2^T for two zero-padded tables T [rows1_pad][kpad], T2 [rows2_pad][kpad] (rows padded to
@@ -403,6 +435,18 @@ static int mix_ctx_product(MixCtx &c, int t, double *d_out)
                        c.s.as<double>(), c.d_tiles.as<int2>(), c.l1max + 1, c.l2max + 1, c.d_cs.as<double>(), d_out,
                        (long long)(c.l2max + 1));
     HX_HIP(hipGetLastError());
+#ifdef HX_GEMM_STAMP
+    if (const char *fn = getenv("HX_GEMM_STAMP_FILE")) {
+        HX_HIP(hipStreamSynchronize(rt().stream));
+        std::vector<unsigned long long> h(4096 * 4);
+        HX_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_gemm_stamp), sizeof(unsigned long long) * h.size()));
+        if (FILE *f = fopen(fn, "w")) {
+            for (size_t k = 0; k < std::min<size_t>(c.ntiles, 4096); ++k)
+                fprintf(f, "%zu %llu %llu %llu %llu %llu\n", k, h[4 * k], h[4 * k + 1], h[4 * k + 2] >> 32, h[4 * k + 2] & 0xffffffffull, h[4 * k + 3]);
+            fclose(f);
+        }
+    }
+#endif
     return HX_OK;
 }
 

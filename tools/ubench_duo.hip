@@ -14,7 +14,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // MODE: 0 dependent pairs (t = fma(c, x, d); v = fma(t, v, -p)), 1 bursts: 8 independent t's, then the 8 chain steps, 2 all independent,
 //       3 two-step form (chain depth 1 per 2 steps)
 // SMALL: consumer alternates 16x16x4 and 4x4x4 (the 20-column shape).  PRIO: producer s_setprio 3.  NOCONS: consumer idle.
-template <int MODE, int SMALL, int PRIO, int NOCONS, int LDSOPS>
+template <int MODE, int SMALL, int PRIO, int NOCONS, int LDSOPS, int GAP = 0>
 __global__ __launch_bounds__(512, 1) void k_duo(double *out, unsigned long long *cyc, int iters, const double *__restrict__ src)
 {
     __shared__ double tile[8][2048];
@@ -40,6 +40,11 @@ __global__ __launch_bounds__(512, 1) void k_duo(double *out, unsigned long long 
                 acc[i & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[i], acc[i & 1], 0, 0, 0);
                 if (SMALL) accx[i & 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bx[i], accx[i & 1], 0, 0, 0);
                 if (LDSOPS & 1) a += tile[w][(lane * 2 + i * 128 + it) & 2047] * 1e-30;
+                // GAP: the consumer leaves the issue port alone for a moment after every matrix instruction (pair): does the producer
+                // of the other wave get an FP64 vector instruction through?  (1..15: s_nop n - 1; 16: s_sleep 1; 17: s_setprio 0 / 3 toggling)
+                if (GAP >= 1 && GAP <= 15) asm volatile("s_nop %0" ::"n"(GAP >= 1 && GAP <= 15 ? GAP - 1 : 0));
+                if (GAP == 16) __builtin_amdgcn_s_sleep(1);
+                if (GAP >= 20 && (i & 1)) asm volatile("s_nop %0" ::"n"(GAP >= 20 ? GAP - 20 : 0));   // after every second pair
             }
             n += 8;
         }
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(512, 1) void k_duo(double *out, unsigned long long 
     if (lane == 0) { cyc[(blockIdx.x * 8 + w) * 2] = t1 - t0; cyc[(blockIdx.x * 8 + w) * 2 + 1] = n; }
 }
 
-template <int MODE, int SMALL, int PRIO, int NOCONS, int LDSOPS>
+template <int MODE, int SMALL, int PRIO, int NOCONS, int LDSOPS, int GAP = 0>
 int run(const char *name, int iters)
 {
     const int nb = 256;
@@ -118,7 +123,7 @@ int run(const char *name, int iters)
     std::vector<double> h(4096);
     for (int i = 0; i < 4096; ++i) h[i] = (double)rand() / RAND_MAX;
     CK(hipMemcpy(src, h.data(), 4096 * 8, hipMemcpyHostToDevice));
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k_duo<MODE, SMALL, PRIO, NOCONS, LDSOPS>), dim3(nb), dim3(512), 0, 0, out, cyc, iters, src);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k_duo<MODE, SMALL, PRIO, NOCONS, LDSOPS, GAP>), dim3(nb), dim3(512), 0, 0, out, cyc, iters, src);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> c(nb * 16);
     CK(hipMemcpy(c.data(), cyc, nb * 16 * 8, hipMemcpyDeviceToHost));
@@ -158,5 +163,18 @@ int main()
     run<1, 1, 0, 0, 3>("16x16x4 + 4x4x4 stream + A reads | bursts + tile stores", it);
     run<1, 1, 1, 0, 3>("16x16x4 + 4x4x4 stream + A reads | bursts + tile stores, prio", it);
     run<3, 1, 1, 0, 3>("16x16x4 + 4x4x4 stream + A reads | two-step + tile stores, prio", it);
+    // round 4, second session: gaps in the consumer's stream
+    run<1, 1, 0, 0, 0, 1>("16x16x4 + 4x4x4 stream, s_nop 0 per pair | bursts", it);
+    run<1, 1, 0, 0, 0, 2>("16x16x4 + 4x4x4 stream, s_nop 1 per pair | bursts", it);
+    run<1, 1, 0, 0, 0, 4>("16x16x4 + 4x4x4 stream, s_nop 3 per pair | bursts", it);
+    run<1, 1, 0, 0, 0, 8>("16x16x4 + 4x4x4 stream, s_nop 7 per pair | bursts", it);
+    run<1, 1, 0, 0, 0, 15>("16x16x4 + 4x4x4 stream, s_nop 14 per pair | bursts", it);
+    run<1, 1, 0, 0, 0, 16>("16x16x4 + 4x4x4 stream, s_sleep 1 per pair | bursts", it);
+    run<1, 1, 1, 0, 0, 4>("16x16x4 + 4x4x4 stream, s_nop 3 per pair | bursts, prio", it);
+    run<1, 1, 1, 0, 0, 8>("16x16x4 + 4x4x4 stream, s_nop 7 per pair | bursts, prio", it);
+    run<0, 1, 1, 0, 0, 8>("16x16x4 + 4x4x4 stream, s_nop 7 per pair | dependent pairs, prio", it);
+    run<1, 1, 1, 0, 0, 27>("16x16x4 + 4x4x4 stream, s_nop 7 per 2 pairs | bursts, prio", it);
+    run<1, 0, 1, 0, 0, 8>("16x16x4 stream, s_nop 7 per instruction | bursts, prio", it);
+    run<1, 0, 1, 0, 0, 15>("16x16x4 stream, s_nop 14 per instruction | bursts, prio", it);
     return 0;
 }
