@@ -1382,9 +1382,9 @@ int analysis_max_comp(int spin) { return (spin == 2 && (leg_duo() || oneset_enab
 // maps / fields go to the vector-unit kernel.  Ties take the larger sweep first.
 static double sweep_cost(int spin, int units)
 {
-    if (leg_duo()) {  // k_legendre_duo, round 4 (gpurun_out/r4_t6_shapes.log)
-        if (spin == 0) return units <= 4 ? 21.6 * units : (units <= 8 ? 84.5 : (units <= 10 ? 100.7 : 147.0));
-        return units <= 2 ? 61.0 * units : (units <= 4 ? 166.0 : (units == 5 ? 198.0 : (units == 6 ? 221.0 : (units <= 8 ? 276.0 : (units == 9 ? 304.0 : 345.0)))));
+    if (leg_duo()) {  // k_legendre_duo, round 4, with the gaps of HX_DUO_GAP (gpurun_out/ab_gap3.txt, ab_gap4.txt)
+        if (spin == 0) return units <= 4 ? 21.6 * units : (units <= 8 ? 84.1 : (units <= 10 ? 99.2 : 139.7));
+        return units <= 2 ? 61.0 * units : (units <= 4 ? 164.5 : (units == 5 ? 194.1 : (units == 6 ? 222.0 : (units <= 8 ? 272.0 : (units == 9 ? 304.0 : 336.0)))));
     }
     if (spin == 0) return units <= 4 ? 21.6 * units : (units <= 8 ? 100.0 : (units <= 10 ? 115.0 : 162.0));
     return units <= 2 ? 61.0 * units : (units <= 4 ? 196.0 : (units == 5 ? 224.0 : (units <= 8 ? 316.0 : (units == 9 ? 360.0 : 400.0))));
