@@ -118,16 +118,18 @@ __global__ void k_weight_xi(int l3max, int n, const double *__restrict__ x, cons
 //     8 q + 2 (lane >> 4) + h); rows are padded to 18 doubles, which spreads the 16 rows of a read over all 64 banks.
 constexpr int GKT = 16;          // nodes per k tile of the GEMM (GK = 32 stays the padding unit of the tables)
 constexpr int GLT = GKT + 2;     // LDS row stride in doubles
-// Where the kernel stands (round 4, work-group timelines of the HX_GEMM_STAMP build, L = 6144: 1225 tiles on 512 resident groups): a tile
-// takes 2.41 ms when two groups share a CU (1.9-2.9; 2.20 would be the matrix pipe's rate at the 2.15 GHz the part holds here: 0.92) and
-// 2.0 ms alone on a CU (HX_GEMM_HOG build: 0.55 of the pipe -- its loads run ONE k tile = 4096 cycles ahead, less than a trip to memory
-// under load, and with 243 registers a second tile in flight has no room); the launch is two full rounds to 4.3-4.8 ms and a last round
-// of 20-28 tiles per XCD, most of them alone on their CU, to 6.75 ms: matrix pipe busy 0.78.  Measured and not kept: the tiles of that
-// last round as two 128 x 64 halves (same k tiles with half the instructions each cover even less latency: 6.8 ms) and as two halves of
-// the NODES added into a zeroed G (two addends commute: still repeatable bit for bit; parts 1.37 ms each, 6.55 ms -- 3 % for a memset,
-// atomics and a second code path).  Ranges of k tiles dealt evenly to persistent groups (stream-K) would end every group together, but
-// groups that are at different nodes of their tiles no longer share the rows of T through their XCD's L2, which is what the tile order
-// of mix_ctx_init is for.
+// Where this kernel stands (round 4, work-group timelines of the HX_GEMM_STAMP build, tools/analyse_gemm_stamps.py; L = 6144: 1225 tiles
+// on 512 resident groups): a tile takes 2.41 ms when two groups share a CU (1.9-2.9; 2.20 would be the matrix pipe's rate at the 2.15 GHz
+// the part holds here: 0.92) and 2.24 ms ALONE on a CU (HX_GEMM_HOG build: 10.0 ms per product, 0.55 of the pipe -- its loads run ONE k
+// tile = 4096 cycles ahead, less than a trip to memory under load, its LDS reads wait behind every barrier with no other wave to cover
+// them, and 243 registers leave no room for a second tile in flight); the launch is two full rounds, to 4.3-4.8 ms, and a last round of
+// 20-28 tiles per XCD, most of them alone on their CU, to 6.75 ms: matrix pipe busy 0.78.  k_mixmat_gemm_dma below is the answer to the
+// lone group (1.44 ms); this kernel stays for products whose A side is scaled on the way (hx_pinv) and as the A/B reference
+// (HX_GEMM_DMA=0).  Measured and not kept on either kernel: the tiles of the last round as two 128 x 64 halves (6.8 ms) and as the two
+// halves of the NODES added into a zeroed G (two addends commute: repeatable bit for bit; 6.55 ms here, 13.0-13.2 against 12.9-13.0 ms per
+// two products on the other kernel: the rounds are blurred by the spread of the tile times, the memset and the atomics cost what the
+// halves gain).  Equal ranges of k tiles dealt to persistent groups (stream-K) would end every group together, but groups that stand
+// at different nodes of their tiles no longer share the rows of T through their XCD's L2, which is what the tile order is for.
 // SYM: T2 == T, only tiles bi <= bj are listed and both halves are written (the mixing matrices); !SYM: G[i][j] = sum_k T[i][k] s[k] T2[j][k]
 // for every listed tile, colscale may be null (the last product of hx_pinv: V diag(1 / sigma^2) W^T).
 #ifdef HX_GEMM_STAMP  // diagnostic build: when and where every work-group ran
@@ -258,6 +260,174 @@ __global__ __launch_bounds__(256, 2) void k_mixmat_gemm(const double *__restrict
 #endif
 }
 
+// ---- the same product with the k tiles brought in by loads that write LDS directly (round 4, second session) ---------------------
+// Ts = T diag(s) is formed once per mask (k_scale_table: the loads cannot multiply on the way), then  G = Ts T2^T.  A stage is 8
+// nodes of the 128 + 128 rows of a tile: 64-byte rows, 16 KiB per stage, FOUR stages per work-group (64 KiB: two groups per CU as
+// before), three of them in flight -- 6144 cycles of matrix instructions for a group that is alone on its CU, where the register-
+// staged kernel has 4096 and reaches 0.55 of the pipe (see above).  One `global_load_lds_dwordx4` of a wave fills 16 rows: lane l
+// writes row l >> 2, 16-byte position l & 3 (the LDS image of such a load is lane-linear), and FETCHES chunk (l & 3) ^ ((row >> 2) & 3)
+// of that row: the 16 rows of an operand read (fixed chunk, rows r .. r + 15) then hit 16 different bank groups.  Per stage a wave
+// issues 2 + 2 loads; `s_waitcnt vmcnt(8)` (two younger stages) retires its own pieces of the oldest stage, the barrier behind it
+// tells every wave that all pieces have landed AND that stage kt - 1 has been read by everyone, so its buffer is re-filled with
+// stage kt + 3 right behind the barrier.
+constexpr int DK = 8;  // nodes per stage (four stages)
+// one 16-byte load per lane straight into LDS: lane l's data lands at lds_dst + 16 l (lds_dst through M0, which the compiler owns:
+// saved and restored); address = scalar base + 32-bit lane offset -- hipcc's builtin takes a per-lane 64-bit pointer and pays a vector
+// add per load for it
+__device__ __forceinline__ void glds16(const double *sbase, int voff_bytes, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_bytes), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void *)p;
+}
+template <bool SYM>
+__global__ __launch_bounds__(256, 2) void k_mixmat_gemm_dma(const double *__restrict__ Ts, const double *__restrict__ T2, int kpad,
+                                                            const int2 *__restrict__ tiles, int n1, int n2,
+                                                            const double *__restrict__ colscale, double *__restrict__ G, long long ldg)
+{
+    // one array per stage and operand: hipcc orders an LDS read behind EVERY load-to-LDS in flight that it cannot tell apart from it
+    // (s_waitcnt vmcnt(0) in front of the reads: nothing left in flight); distinct LDS variables it can
+    // (one array per STAGE, both operands in it: with eight arrays the compiler runs out of slots to track them and one stage gets its vmcnt(0) back)
+    __shared__ double S0[2][GB][DK], S1[2][GB][DK], S2[2][GB][DK], S3[2][GB][DK];
+#ifdef HX_GEMM_HOG  // diagnostic build (tools/build_variant.sh): ONE work-group per CU
+    __shared__ double hog[6144];
+    if (kpad < 0) { hog[threadIdx.x] = 1.0; G[0] = hog[threadIdx.x ^ 1]; }
+#endif
+    const int2 tl = tiles[blockIdx.x];
+    const int bi = tl.x, bj = tl.y;
+    if (bi < 0) return;
+#ifdef HX_GEMM_STAMP
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+    const unsigned long long r_begin = wall_clock64();
+#endif
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // (a scalar: the LDS destinations of a wave's loads go through M0)
+    const int wr = w >> 1, wc = w & 1;
+    double4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    // this lane's pieces of a stage: rows w 32 + i 16 + (lane >> 2), i = 0, 1.  Scalar base + 32-bit lane offset: the base advances on the
+    // scalar unit (with per-lane 64-bit pointers every load cost a vector add and a v_readfirstlane inside the matrix stream: ~12
+    // cycles of pipe time each, 8 per stage)
+    const int lrow = lane >> 2;
+    const double *pa = Ts + (long long)bi * GB * kpad, *pb = T2 + (long long)bj * GB * kpad;
+    int off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = w * 32 + i * 16 + lrow;
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        off[i] = (row * kpad + 2 * chunk) * (int)sizeof(double);  // bytes
+    }
+#define HX_DMA_ISSUE(S, kt)                                                                                                               \
+    do {                                                                                                                                  \
+        const double *qa_ = pa + (long long)(kt) * DK, *qb_ = pb + (long long)(kt) * DK;                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                                                \
+            glds16(qa_, off[i_], lds_addr(&S[0][w * 32 + i_ * 16][0]));                                                                   \
+            glds16(qb_, off[i_], lds_addr(&S[1][w * 32 + i_ * 16][0]));                                                                   \
+        }                                                                                                                                 \
+    } while (0)
+    const int nk = kpad / DK;  // (a multiple of 4: kpad is a multiple of 32)
+    HX_DMA_ISSUE(S0, 0);
+    HX_DMA_ISSUE(S1, 1);
+    HX_DMA_ISSUE(S2, 2);
+    // operand reads: row (lane & 15) of a 16-row block, nodes 2 c, 2 c + 1 with c = lane >> 4, at position c ^ ((row >> 2) & 3)
+    const int arow = wr * 64 + (lane & 15), brow = wc * 64 + (lane & 15);
+    const int apos = 2 * ((lane >> 4) ^ ((arow >> 2) & 3)), bpos = 2 * ((lane >> 4) ^ ((brow >> 2) & 3));  // (+ 16 i keeps (row >> 2) & 3)
+    // The operands of stage kt + 1 are read while the matrix instructions of stage kt run (two register sets): a group that is alone
+    // on its CU has no other wave to cover the LDS latency behind every barrier.  The reads are inline assembly: behind the loop's
+    // back edge hipcc cannot count the loads to LDS in flight and drains them all (vmcnt(0)) in front of ordinary LDS reads.
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d ra[2][4], rb[2][4];
+#define HX_DMA_READ(S, q)                                                                                                                 \
+    do {                                                                                                                                  \
+        const unsigned la_ = lds_addr(&S[0][arow][apos]), lb_ = lds_addr(&S[1][brow][bpos]);                                              \
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\t" \
+                     "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:1024\n\tds_read_b128 %6, %9 offset:2048\n\tds_read_b128 %7, %9 offset:3072"     \
+                     : "=&v"(ra[q][0]), "=&v"(ra[q][1]), "=&v"(ra[q][2]), "=&v"(ra[q][3]), "=&v"(rb[q][0]), "=&v"(rb[q][1]), "=&v"(rb[q][2]), "=&v"(rb[q][3]) \
+                     : "v"(la_), "v"(lb_)                                                                                                 \
+                     : "memory");                                                                                                         \
+    } while (0)
+    // (the registers are operands of the wait, so that no matrix instruction that reads them is scheduled above it)
+#define HX_DMA_LANDED(q)                                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                                   \
+                 : "+v"(ra[q][0]), "+v"(ra[q][1]), "+v"(ra[q][2]), "+v"(ra[q][3]), "+v"(rb[q][0]), "+v"(rb[q][1]), "+v"(rb[q][2]), "+v"(rb[q][3]) \
+                 :: "memory")
+    // iteration kt: stage kt is in register set q; (Sr) = the buffer of stage kt + 1 (read now), (Sn) = that of stage kt + 3 = kt - 1 (refilled now)
+#define HX_DMA_STAGE(Sr, Sn, q, kt)                                                                                                       \
+    do {                                                                                                                                  \
+        const int left_ = nk - 1 - (kt); /* younger stages issued so far: min(left_, 2); stage kt + 1 must have landed */                   \
+        if (left_ >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                                  \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                             \
+        __builtin_amdgcn_s_barrier();                                                                                                     \
+        if ((kt) + 3 < nk) HX_DMA_ISSUE(Sn, (kt) + 3);                                                                                    \
+        if ((kt) + 1 < nk) HX_DMA_READ(Sr, (q) ^ 1);                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                                \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                                                  \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                              \
+                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                          \
+                    acc[i_][j_] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[q][i_][h_], rb[q][j_][h_], acc[i_][j_], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0); /* (the wait stays BEHIND the matrix instructions) */                                          \
+        HX_DMA_LANDED((q) ^ 1);                                                                                                           \
+    } while (0)
+    // stage 0 into set 0
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    HX_DMA_READ(S0, 0);
+    HX_DMA_LANDED(0);
+    for (int kt = 0; kt < nk; kt += 4) {
+        HX_DMA_STAGE(S1, S3, 0, kt);
+        HX_DMA_STAGE(S2, S0, 1, kt + 1);
+        HX_DMA_STAGE(S3, S1, 0, kt + 2);
+        HX_DMA_STAGE(S0, S2, 1, kt + 3);
+    }
+#undef HX_DMA_READ
+#undef HX_DMA_LANDED
+#undef HX_DMA_STAGE
+#undef HX_DMA_ISSUE
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = bi * GB + wr * 64 + i * 16 + (lane >> 4) + 4 * r;
+                const int gj = bj * GB + wc * 64 + j * 16 + (lane & 15);
+                const double v = acc[i][j][r];
+                if (gi < n1 && gj < n2) G[(long long)gi * ldg + gj] = colscale ? v * colscale[gj] : v;
+                if (SYM && bi != bj && gj < n1 && gi < n2) G[(long long)gj * ldg + gi] = v * colscale[gi];
+            }
+#ifdef HX_GEMM_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_gemm_stamp[blockIdx.x * 4 + 0] = r_begin;
+        g_gemm_stamp[blockIdx.x * 4 + 1] = wall_clock64();
+        g_gemm_stamp[blockIdx.x * 4 + 2] = ((unsigned long long)xcc << 32) | hwid;
+        g_gemm_stamp[blockIdx.x * 4 + 3] = ((unsigned long long)(__builtin_readcyclecounter() - t_begin) << 24) | (bi << 10) | bj;
+    }
+#endif
+}
+
+// Ts[r][k] = T[r][k] s[k]
+__global__ __launch_bounds__(256) void k_scale_table(long long n2, int kpad2, const double2 *__restrict__ T, const double2 *__restrict__ s, double2 *__restrict__ Ts)
+{
+    long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long stp = (long long)gridDim.x * blockDim.x;
+    for (; i < n2; i += stp) {
+        const double2 v = T[i], f = s[i % kpad2];
+        Ts[i] = make_double2(v.x * f.x, v.y * f.y);
+    }
+}
+
 // G (n1 x n2, leading dimension ldg) = T diag(s) T2^T for two zero-padded tables T [rows1_pad][kpad], T2 [rows2_pad][kpad] (rows padded to
 // multiples of 128, kpad to a multiple of 32) on the stream of the library (hx_svd.hip)
 int launch_gemm_tst(const double *T, int rows1_pad, const double *T2, int rows2_pad, int kpad, const double *s, int n1, int n2, double *G, long long ldg)
@@ -320,6 +490,13 @@ static int upload_vec(DevBuf &b, const std::vector<T> &v)
     return HX_OK;
 }
 
+// HX_GEMM_DMA=0: the register-staged kernel of the first half of round 4 (A/B on one device)
+static bool gemm_dma()
+{
+    static const bool on = !(getenv("HX_GEMM_DMA") && getenv("HX_GEMM_DMA")[0] == '0');
+    return on;
+}
+
 struct GLCache {
     int n = 0;
     DevBuf x, w;
@@ -345,6 +522,7 @@ struct MixCtx {
     DevBuf s, d_tiles, d_cs;
     size_t ntiles = 0;
     DevBuf T[4];            // (0,0), (2,0), (2,2), (2,-2)
+    DevBuf Ts;              // T diag(s) of the product in hand (k_mixmat_gemm_dma)
     bool have[4] = {false, false, false, false};
 };
 static const int kAB[4][2] = {{0, 0}, {2, 0}, {2, 2}, {2, -2}};
@@ -431,6 +609,14 @@ static int mix_ctx_product(MixCtx &c, int t, double *d_out)
 {
     HX_TRY(mix_ctx_table(c, t));
     ProfScope ps("mixmat_gemm");
+    if (gemm_dma()) {
+        const size_t nel = (size_t)c.rows_pad * c.kpad;
+        if (!c.Ts.p) HX_TRY(c.Ts.alloc(sizeof(double) * nel));
+        hipLaunchKernelGGL(k_scale_table, dim3(2048), dim3(256), 0, rt().stream, (long long)(nel / 2), c.kpad / 2, c.T[t].as<double2>(), c.s.as<double2>(),
+                           c.Ts.as<double2>());
+        hipLaunchKernelGGL(k_mixmat_gemm_dma<true>, dim3((unsigned)c.ntiles), dim3(256), 0, rt().stream, c.Ts.as<double>(), c.T[t].as<double>(), c.kpad,
+                           c.d_tiles.as<int2>(), c.l1max + 1, c.l2max + 1, c.d_cs.as<double>(), d_out, (long long)(c.l2max + 1));
+    } else
     hipLaunchKernelGGL(k_mixmat_gemm<true>, dim3((unsigned)c.ntiles), dim3(256), 0, rt().stream, c.T[t].as<double>(), c.T[t].as<double>(), c.kpad,
                        c.s.as<double>(), c.d_tiles.as<int2>(), c.l1max + 1, c.l2max + 1, c.d_cs.as<double>(), d_out,
                        (long long)(c.l2max + 1));
