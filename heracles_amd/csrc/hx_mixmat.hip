@@ -614,12 +614,15 @@ static int mix_ctx_product(MixCtx &c, int t, double *d_out)
         if (!c.Ts.p) HX_TRY(c.Ts.alloc(sizeof(double) * nel));
         hipLaunchKernelGGL(k_scale_table, dim3(2048), dim3(256), 0, rt().stream, (long long)(nel / 2), c.kpad / 2, c.T[t].as<double2>(), c.s.as<double2>(),
                            c.Ts.as<double2>());
+        ProfScope pk("mixmat_gemm_kernel");  // (the matrix kernel alone; "mixmat_gemm" includes the scaling pass)
         hipLaunchKernelGGL(k_mixmat_gemm_dma<true>, dim3((unsigned)c.ntiles), dim3(256), 0, rt().stream, c.Ts.as<double>(), c.T[t].as<double>(), c.kpad,
                            c.d_tiles.as<int2>(), c.l1max + 1, c.l2max + 1, c.d_cs.as<double>(), d_out, (long long)(c.l2max + 1));
-    } else
+    } else {
+    ProfScope pk("mixmat_gemm_kernel");
     hipLaunchKernelGGL(k_mixmat_gemm<true>, dim3((unsigned)c.ntiles), dim3(256), 0, rt().stream, c.T[t].as<double>(), c.T[t].as<double>(), c.kpad,
                        c.s.as<double>(), c.d_tiles.as<int2>(), c.l1max + 1, c.l2max + 1, c.d_cs.as<double>(), d_out,
                        (long long)(c.l2max + 1));
+    }
     HX_HIP(hipGetLastError());
 #ifdef HX_GEMM_STAMP
     if (const char *fn = getenv("HX_GEMM_STAMP_FILE")) {
