@@ -24,6 +24,8 @@
 #include <cmath>
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "hx_sht_common.h"
 #ifndef HX_FFT_ABL
 #define HX_FFT_ABL 0  // timing experiments only (tools/fft_ablate.sh)
@@ -156,7 +158,7 @@ constexpr int RING_FB = 8;       // values of j per thread whose pixel loads are
 // the batches of loads splits them (17.2 instead of 14.0 ms per 8 components even without weights); "weights or none" stays the
 // run-time test it was (as a compile-time constant the 64 loads of the generic path are issued together: 256 registers, 34 spilled).
 template <int MODE, bool WSYM = false>
-__global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int *__restrict__ rp_list, int nrings, int nb, int Mclass,
+__global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const RingDesc *__restrict__ desc, int nrings, int nb, int Mclass,
                                                             const double *__restrict__ maps,
                                                             const double *__restrict__ pixw,
                                                             const double2 *__restrict__ zin,
@@ -172,21 +174,33 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
 #if HX_FFT_ABL & 32
     unsigned long long fcyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flast = __builtin_amdgcn_s_memtime();
 #endif
+    // What an item needs to know about its ring pair is ONE 32-byte record (RingDesc; it was rp_list[ring], then P.nsub / startN / startS /
+    // bhat_off [rp]: two dependent trips to memory in front of the pixel loads, a third one -- cycle accounting, profiles/r04_fft_cycles.txt:
+    // "load + tables" 24k cycles per item whatever the length of its ring), and the record of the NEXT item is requested behind the first
+    // batch of pixel loads of this one -- by a vector load with the same address in every lane (a scalar load would make the first
+    // lgkmcnt(0) of the item wait for it) -- and moved to scalars after the fill, when it has long landed.
+    auto ring_of = [&](int item) __attribute__((always_inline)) { return ((item >> 5) / nb) * 8 + (item & 7); };
+    RingDesc cur = RingDesc{0, 0, 0, 1, 0};
+    if ((int)blockIdx.x < nitems && ring_of(blockIdx.x) < nrings) cur = desc[ring_of(blockIdx.x)];
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         // item = 8 (4 s + r) + x: sub-DFT r of set s on XCD x -- the four r of a (ring pair, component) in four groups of that XCD,
         // side by side in time.  Set s = (ring set s / nb, component s % nb): an XCD walks the COMPONENTS of one ring pair before it
         // moves to its next ring pair, so that the pair's pixel weights come from HBM once and from that XCD's L2 for every other
         // component (component-major sets re-read the 1.6 GB weight array per component: +34 ms per step of the bench)
         const int r = (item >> 3) & 3, set = item >> 5;
-        const int ring = (set / nb) * 8 + (item & 7), c = set % nb;
-        if (ring >= nrings) continue;  // padding of the last set of 8 ring pairs
-        const int rp = rp_list[ring];
-        const int n = P.nsub[rp];
-        const long long sN = P.startN[rp], sS = P.startS[rp];
+        const int ring = ring_of(item), c = set % nb;
+        const int itn = item + gridDim.x, ringn = itn < nitems ? ring_of(itn) : nrings;
+        const bool nextv = ringn < nrings;
+        if (ring >= nrings) {  // padding of the last set of 8 ring pairs
+            if (nextv) cur = desc[ringn];
+            continue;
+        }
+        const int n = cur.n;
+        const long long sN = cur.sN, sS = cur.sS;
         const int M = fft_size_for(n), MP = lds_fft_slots(M);
         const bool blu = M != n;
         const int p = ilog2(M);
-        const double2 *bh = P.bhat + P.bhat_off[rp];
+        const double2 *bh = P.bhat + cur.bhat_off;
         const double inv = 1.0 / M, inv4n = 0.25 / (double)n;
         // the thread index goes through an empty asm statement per item, so that what derives from it (LDS addresses, pixel
         // offsets) is set up per item instead of being hoisted out of this loop and kept in registers across the passes
@@ -208,14 +222,21 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
         // shifts (the segment [q n, (q + 1) n) is followed by the next one -- or, for q = 3, by the next ring, which the last
         // ring of the map does not have).
         struct __attribute__((aligned(8))) Pair { double x, y; };
-        auto load_batch = [&](int u0) __attribute__((always_inline)) {
+        // A batch is REQUESTED here and FINISHED (pixel weights of the symmetric kind, the odd-n tail, the missing southern ring) where the
+        // fill uses it: z[u][q], z[u + 1][q] hold the raw northern and southern pair until then.  Finished at the load -- as it was
+        // since the weights came into the path -- every product needs its operand at once and hipcc issued two loads, s_waitcnt vmcnt(0),
+        // two loads, ...: sixteen trips to memory one after the other, 23k of an item's 57-75k cycles whatever the length of its ring
+        // (profiles/r04_fft_cycles.txt).  (Generic weight arrays keep that form: their raw values would need another 128 registers.)
+        Pair wsy[RING_FB / 2];
+        auto load_batch_t = [&](auto WIDEC, int u0) __attribute__((always_inline)) {
+            constexpr bool WIDE = decltype(WIDEC)::value;
 #pragma unroll
             for (int u = 0; u < RING_FB; u += 2) {
                 const int j = 2 * (tid + ((u0 + u) >> 1) * nt);      // first j of the pair; the batch covers j < (u0 + RING_FB) nt
-                const bool tail = j == n - 1 && n >= 2;              // (n = 1: the scalar path below)
+                const bool tail = WIDE && j == n - 1;                // (n = 1: the scalar path below)
                 const int jj = tail ? n - 2 : (j + 1 < n ? j : 0);
-                Pair wq = {1.0, 1.0};
-                if (MODE == 0 && wsym && n >= 2) wq = *reinterpret_cast<const Pair *>(pwN + jj);
+                wsy[u >> 1] = Pair{1.0, 1.0};
+                if (MODE == 0 && wsym && WIDE) wsy[u >> 1] = *reinterpret_cast<const Pair *>(pwN + jj);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int i = jj + q * n;
@@ -224,21 +245,21 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
                         z[u][q] = make_double2(1.0 + j, 2.0 + q); z[u + 1][q] = z[u][q]; continue;
 #endif
                         Pair fn, fs;
-                        if (n >= 2) {
+                        if (WIDE) {
                             fn = *reinterpret_cast<const Pair *>(mpN + i);
                             fs = *reinterpret_cast<const Pair *>(mpS + i);
-                            if (wsym) {
-                                fn.x *= wq.x; fn.y *= wq.y; fs.x *= wq.x; fs.y *= wq.y;
-                            } else if (pw) {
+                            if (!wsym && pw) {
                                 const Pair wn = *reinterpret_cast<const Pair *>(pwN + i), ws = *reinterpret_cast<const Pair *>(pwS + i);
                                 fn.x *= wn.x; fn.y *= wn.y; fs.x *= ws.x; fs.y *= ws.y;
                             }
+                            z[u][q] = make_double2(fn.x, fn.y);      // raw: finish_batch
+                            z[u + 1][q] = make_double2(fs.x, fs.y);
                         } else {
                             fn.x = fn.y = mpN[q]; fs.x = fs.y = mpS[q];
                             if (pw || wsym) { fn.x *= pwN[q]; fs.x *= pwS[q]; fn.y = fn.x; fs.y = fs.x; }
+                            z[u][q] = make_double2(fn.x, haveS ? fs.x : 0.0);
+                            z[u + 1][q] = make_double2(fn.y, haveS ? fs.y : 0.0);
                         }
-                        z[u][q] = make_double2(tail ? fn.y : fn.x, haveS ? (tail ? fs.y : fs.x) : 0.0);
-                        z[u + 1][q] = make_double2(fn.y, haveS ? fs.y : 0.0);
                     } else {
                         const int i0 = (j < n ? j : 0) + q * n, i1 = (j + 1 < n ? j + 1 : 0) + q * n;
                         z[u][q] = zp[i0];
@@ -247,13 +268,43 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
                 }
             }
         };
+        auto load_batch = [&](int u0) __attribute__((always_inline)) {
+            if (n >= 2) load_batch_t(std::true_type{}, u0);
+            else load_batch_t(std::false_type{}, u0);
+        };
+        // raw pairs -> the values of j and j + 1: (north, south) each
+        auto finish_batch = [&](int u0) __attribute__((always_inline)) {
+            if (MODE != 0 || n < 2) return;
+#pragma unroll
+            for (int u = 0; u < RING_FB; u += 2) {
+                const int j = 2 * (tid + ((u0 + u) >> 1) * nt);
+                const bool tail = j == n - 1;
+                const Pair w = wsy[u >> 1];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double2 rn = z[u][q], rs = z[u + 1][q];
+                    const double nx = wsym ? rn.x * w.x : rn.x, ny = wsym ? rn.y * w.y : rn.y;
+                    const double sx = wsym ? rs.x * w.x : rs.x, sy = wsym ? rs.y * w.y : rs.y;
+                    z[u][q] = make_double2(tail ? ny : nx, haveS ? (tail ? sy : sx) : 0.0);
+                    z[u + 1][q] = make_double2(ny, haveS ? sy : 0.0);
+                }
+            }
+        };
         load_batch(0);
+        int4 nd0 = make_int4(0, 0, 0, 0), nd1 = nd0;  // the next item's record (see above)
+        if (nextv) {
+            const int4 *dp = reinterpret_cast<const int4 *>(desc + ringn) + (tid >> 30);
+            nd0 = dp[0];
+            nd1 = dp[1];
+        }
         // (work-group barriers that wait for this wave's LDS traffic only: __syncthreads() would wait for the pixel loads too)
         auto lds_barrier = []() __attribute__((always_inline)) {
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
         };
+        HX_FSTAMP(6);
         lds_barrier();  // the previous item's last readers of the phase tables and of the buffer
+        HX_FSTAMP(7);
         for (int a = tid; a <= (4 * n) >> 6; a += nt) ph_hi[a] = expipi(-(double)(a << 6) / (2.0 * n));
         if (tid < 64) ph_lo[tid] = expipi(-(double)tid / (2.0 * n));
         lds_barrier();
@@ -269,6 +320,7 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
         // d = -i (z1 - z3) ----
         {
             for (int u0 = 0;;) {
+                finish_batch(u0);
 #pragma unroll
                 for (int u = 0; u < RING_FB; ++u) {
                     const int j = 2 * (tid + ((u0 + u) >> 1) * nt) + (u & 1);  // the pairs of load_batch
@@ -289,6 +341,14 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
         }
         __syncthreads();
         HX_FSTAMP(1);
+        if (nextv) {
+            auto sc = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+            cur.sN = ((long long)sc(nd0.y) << 32) | (unsigned)sc(nd0.x);
+            cur.sS = ((long long)sc(nd0.w) << 32) | (unsigned)sc(nd0.z);
+            cur.bhat_off = ((long long)sc(nd1.y) << 32) | (unsigned)sc(nd1.x);
+            cur.n = sc(nd1.z);
+            cur.rp = sc(nd1.w);
+        }
         double2 *out = Y + (long long)c * P.ny + sN + (long long)r * n;
         if (!blu) {
 #if !(HX_FFT_ABL & 2)
@@ -367,7 +427,7 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const int
 //     transform each: half the reads.  Two 4096-point buffers are 139 KiB: one group of 512 threads per CU.
 // =====================================================================================
 template <int MODE, bool WSYM = false>
-__global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const int *__restrict__ rp_list, int nrings, int nb, int M,
+__global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const RingDesc *__restrict__ desc, int nrings, int nb, int M,
                                                              const double *__restrict__ maps, const double *__restrict__ pixw,
                                                              const double2 *__restrict__ zin, double2 *__restrict__ Y)
 {
@@ -394,13 +454,21 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const in
 #if HX_FFT_ABL & 32
     unsigned long long fcyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flast = __builtin_amdgcn_s_memtime();
 #endif
+    // (the record of the next item's ring pair is requested behind this item's pixel loads: see k_ring_subdft)
+    auto ring_of = [&](int item) __attribute__((always_inline)) { return HX_PAIR_ROUNDS == 2 ? item / nb : ((item >> 4) / nb) * 8 + (item & 7); };
+    RingDesc cur = RingDesc{0, 0, 0, 1, 0};
+    if ((int)blockIdx.x < nitems && ring_of(blockIdx.x) < nrings) cur = desc[ring_of(blockIdx.x)];
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         // one round per item: item = 8 (2 s + rpair) + x -- the two items of set s = (ring set s / nb, component s % nb) on XCD x
         const int rfirst = HX_PAIR_ROUNDS == 2 ? 0 : (item >> 3) & 1, set = item >> 4;
-        const int ring = HX_PAIR_ROUNDS == 2 ? item / nb : (set / nb) * 8 + (item & 7), c = HX_PAIR_ROUNDS == 2 ? item % nb : set % nb;
-        if (ring >= nrings) continue;
-        const int rp = rp_list[ring];
-        const long long sN = P.startN[rp], sS = P.startS[rp];
+        const int ring = ring_of(item), c = HX_PAIR_ROUNDS == 2 ? item % nb : set % nb;
+        const int itn = item + gridDim.x, ringn = itn < nitems ? ring_of(itn) : nrings;
+        const bool nextv = ringn < nrings;
+        if (ring >= nrings) {
+            if (nextv) cur = desc[ringn];
+            continue;
+        }
+        const long long sN = cur.sN, sS = cur.sS;
         asm volatile("; item" : "+v"(tid));
         const bool haveS = sS >= 0, pw = MODE == 0 && !WSYM && pixw != nullptr;
         constexpr bool wsym = MODE == 0 && WSYM;
@@ -434,6 +502,8 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const in
                 }
             }
         }
+        int4 nd0 = make_int4(0, 0, 0, 0);
+        if (nextv) nd0 = *(reinterpret_cast<const int4 *>(desc + ringn) + (tid >> 30));
         // round 0 = sub-DFTs 0 and 2, round 1 = sub-DFTs 1 and 3 (one round per work item by default: HX_PAIR_ROUNDS)
 #pragma unroll 1
         for (int rpair = rfirst; rpair < rfirst + HX_PAIR_ROUNDS; ++rpair) {
@@ -459,6 +529,12 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const in
         }
         __syncthreads();
         HX_FSTAMP(2);
+        // the next item's record: taken HERE, in front of this item's stores -- waited for behind them (their number is not known to
+        // the compiler) it is s_waitcnt vmcnt(0), and the next item's loads are issued when the last store has been acknowledged
+        if (nextv && rpair == rfirst) {
+            cur.sN = ((long long)__builtin_amdgcn_readfirstlane(nd0.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(nd0.x);
+            cur.sS = ((long long)__builtin_amdgcn_readfirstlane(nd0.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(nd0.z);
+        }
         const int half = tid >= nh ? 1 : 0, gt = tid - half * nh;
         double2 *bh = buf + half * MP;
         lds_fft_dif(bh, M, twf, P.twN, gt, nh);
@@ -850,6 +926,14 @@ extern "C" hx_plan *hx_plan_create(int nside, int lmax, int max_comp)
     chk(upload(pl->z, z)); chk(upload(pl->omz, omz)); chk(upload(pl->sth, sth)); chk(upload(pl->rwdef, rw));
     chk(upload(pl->nsub, nsub)); chk(upload(pl->shifted, shifted));
     chk(upload(pl->startN, sN)); chk(upload(pl->startS, sS)); chk(upload(pl->bhat_off, boff));
+    {
+        std::vector<RingDesc> desc(pl->h_fft_rp_list.size());
+        for (size_t k = 0; k < desc.size(); ++k) {
+            const int rp = pl->h_fft_rp_list[k];
+            desc[k] = RingDesc{sN[rp], sS[rp], boff[rp], nsub[rp], rp};
+        }
+        chk(upload(pl->fft_desc, desc));
+    }
     chk(pl->bhat.alloc(sizeof(double2) * std::max<long long>(btot, 1)));
     if (rc != HX_OK || plan_tables(pl) != HX_OK) { delete pl; return nullptr; }
     hipStream_t st = rt().stream;
@@ -966,10 +1050,10 @@ static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, cons
             const unsigned groups = (unsigned)std::min<long long>(items, (long long)rt().cus * per_cu);
             if (MODE == 0 && d_pw && pl->pw_mode == 2) {
                 hipLaunchKernelGGL((k_ring_pairfft<MODE, MODE == 0>), dim3(groups), dim3(threads), lds, rt().stream,
-                                   pl->dev(), pl->fft_rp_list.as<int>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+                                   pl->dev(), pl->fft_desc.as<RingDesc>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
             } else {
                 hipLaunchKernelGGL((k_ring_pairfft<MODE, false>), dim3(groups), dim3(threads), lds, rt().stream,
-                                   pl->dev(), pl->fft_rp_list.as<int>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+                                   pl->dev(), pl->fft_desc.as<RingDesc>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
             }
 #if HX_FFT_ABL & 32
             {
@@ -999,10 +1083,10 @@ static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, cons
         const unsigned groups = (unsigned)std::min<long long>(items, (long long)rt().cus * per_cu);
         if (MODE == 0 && d_pw && pl->pw_mode == 2) {
             hipLaunchKernelGGL((k_ring_subdft<MODE, MODE == 0>), dim3(groups), dim3(threads), lds, rt().stream,
-                               pl->dev(), pl->fft_rp_list.as<int>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+                               pl->dev(), pl->fft_desc.as<RingDesc>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
         } else {
             hipLaunchKernelGGL((k_ring_subdft<MODE, false>), dim3(groups), dim3(threads), lds, rt().stream,
-                               pl->dev(), pl->fft_rp_list.as<int>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+                               pl->dev(), pl->fft_desc.as<RingDesc>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
         }
 #if HX_FFT_ABL & 32
         {
@@ -1011,6 +1095,7 @@ static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, cons
             (void)hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_fft_cyc), sizeof(hc));
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fft_cyc), z8, sizeof(z8));
             const double items = (double)c.count * nb;
+            fprintf(stderr, "[hx] fft class M %5d rings %5d: item start + load issue %.0f  barrier %.0f  tables + barrier:\n", c.M, c.count, hc[6] / ((double)c.count * nb), hc[7] / ((double)c.count * nb));
             fprintf(stderr, "[hx] fft class M %5d rings %5d: shader cycles per (ring pair, component): load+tables %.0f  fill %.0f  fwd %.0f  middle %.0f  inv %.0f  out %.0f\n", c.M, c.count,
                     hc[0] / items, hc[1] / items, hc[2] / items, hc[3] / items, hc[4] / items, hc[5] / items);
         }

@@ -34,6 +34,11 @@ struct MTasks {
 };
 
 // Device-side view of a plan (POD, passed by value to kernels).
+// what a work item of the ring Fourier kernels needs to know about its ring pair, in the order of hx_plan::fft_rp_list
+struct alignas(16) RingDesc {
+    long long sN, sS, bhat_off;
+    int n, rp;
+};
 struct PlanDev {
     int nside, lmax, nrp, nrp_pad, twN;
     long long npix, ny;
@@ -314,6 +319,7 @@ struct hx_plan {
     struct FftClass { int M, first, count, big; };
     std::vector<FftClass> fft_classes;   // ring pairs grouped by in-LDS FFT length
     hx::DevBuf fft_rp_list;
+    hx::DevBuf fft_desc;                 // RingDesc of every entry of fft_rp_list (one 32-byte read per work item instead of two dependent ones)
     std::vector<int> h_fft_rp_list;      // (host copy: ring pairs in DESCENDING order within a class)
     hx::DevBuf Y, F, partial, d_dbg, resid, resid_maps, Fsyn, pw_sym;
     const double *pw_checked = nullptr;       // the pixel-weight array of the current call that pw_mode describes
