@@ -496,10 +496,10 @@ def main():
             ell = np.arange(L + 1)
             wl = 4 * np.pi * 0.35 * np.exp(-ell * (ell + 1) / 3000.0) + 1e-3 / (1.0 + ell) ** 2
             hx.mixmat_eb(wl[:65], l1max=64, l2max=64)  # warm-up (module load)
-            # median of three builds, host -> host each (a fresh 0.9 GB numpy array per call, as the reference returns one: its first touch
+            # median of five builds, host -> host each (a 0.9 GB numpy array per call, as the reference returns one: the first touch of fresh pages
             # is part of the figure and varies with the state of the host's page cache; all three are listed)
             mix_all = []
-            for _ in range(3):
+            for _ in range(5):
                 hx._lib.profile_enable(True)
                 hx._lib.profile_reset()
                 tm = time.perf_counter()
@@ -514,7 +514,10 @@ def main():
             gflop = 2.0 * (L + 1) ** 2 * N * 2  # two products
             nb_, kpad_ = (L + 1 + 127) // 128, (N + 31) // 32 * 32
             xflop = 2.0 * 128 * 128 * kpad_ * (nb_ * (nb_ + 1) // 2) * 2  # what k_mixmat_gemm executes: the upper triangle of 128 x 128 tiles, padded nodes
-            mix = {"L": L, "seconds": mix_s, "seconds_all": mix_all, "statistic": "median of 3", "gemm_ms": gms, "gemm_kernel_ms": gkms,
+            mix = {"L": L, "seconds": mix_s, "seconds_all": mix_all, "statistic": "median of 5", "gemm_ms": gms, "gemm_kernel_ms": gkms,
+                   "seconds_is": "hx.mixmat_eb host -> host, five builds in a row, each result dropped when the next one has arrived: the first "
+                                 "two fill fresh pages (first-touch page faults of a 0.9 GB numpy array), the later ones a block of the "
+                                 "library's host result pool that an earlier result has released (heracles_amd/_lib.py: _HostPool; HX_HOST_POOL_MB=0 turns it off)",
                    "gemm_ms_is": "gemm_kernel_ms: the two launches of k_mixmat_gemm_dma; gemm_ms: the same with the two passes that form T diag(s) "
                                  "for them (k_scale_table: the k tiles go from HBM into LDS without passing through registers)",
                    "gemm_tflops_executed": xflop / (gkms * 1e-3) / 1e12 if gkms else None,

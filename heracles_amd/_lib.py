@@ -250,3 +250,80 @@ def profile_get(name: str):
     ms = C.c_double()
     check(load().hx_profile_get(name.encode(), C.byref(n), C.byref(ms)))
     return n.value, ms.value
+
+
+# ---- host arrays of large results ------------------------------------------------------------------------------------
+# A mixing-matrix build at L = 6144 returns 0.9 GB; into a FRESH numpy array that costs 30-60 ms of first-touch page faults on top
+# of the 16 ms the bytes need over PCIe -- more than the GPU spends on the matrices (19 ms).  Large result arrays are therefore
+# taken from a small pool of blocks whose previous owner has let go of them (a finaliser on the array handed out; a block is only
+# recycled when nothing else refers to it, e.g. no slice of the old result is alive), at most HX_HOST_POOL_MB (default 2048; 0: off)
+# in all.  The first build of a process still pays for its pages; results that are kept (heracles.twopoint.mixing_matrices keeps
+# them all) are never recycled.
+class _HostPool:
+    MIN_BYTES = 64 << 20
+
+    def __init__(self):
+        import threading
+
+        self.cap = int(os.environ.get("HX_HOST_POOL_MB", "2048")) << 20
+        self.free = {}
+        self.held = 0
+        self.lock = threading.Lock()
+        # how many references a block has inside _give when nothing but the pool's own machinery refers to it (weakref.finalize's
+        # argument tuple, the frame, getrefcount's argument ...): measured once on a dummy block that goes the same way
+        self.base_refs = None
+        import weakref
+
+        import numpy as np
+
+        raw = np.empty(64, np.uint8)
+        view = raw.view(np.float64).reshape((2, 4))
+        weakref.finalize(view, self._give, raw)
+        del raw, view  # (the finaliser runs here: CPython frees the view at once)
+        if self.base_refs is None:  # (an interpreter that did not: never recycle)
+            self.base_refs = -1
+
+    def _give(self, raw):
+        import sys
+
+        if self.base_refs is None:
+            self.base_refs = sys.getrefcount(raw)
+            return
+        if sys.getrefcount(raw) > self.base_refs:
+            return  # a view of the old result is still alive somewhere: its memory is not ours to hand out
+        with self.lock:
+            if self.held + raw.nbytes <= self.cap:
+                self.free.setdefault(raw.nbytes, []).append(raw)
+                self.held += raw.nbytes
+
+    def empty(self, shape, dtype=None):
+        import weakref
+
+        import numpy as np
+
+        dtype = np.dtype(np.float64 if dtype is None else dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if self.cap <= 0 or nbytes < self.MIN_BYTES:
+            return np.empty(shape, dtype)
+        raw = None
+        with self.lock:
+            lst = self.free.get(nbytes)
+            if lst:
+                raw = lst.pop()
+                self.held -= nbytes
+        if raw is None:
+            raw = np.empty(nbytes, np.uint8)
+        out = raw.view(dtype).reshape(shape)
+        weakref.finalize(out, self._give, raw)
+        return out
+
+
+_host_pool = None
+
+
+def host_empty(shape, dtype=None):
+    """np.empty for a large result the library is about to fill (see _HostPool)."""
+    global _host_pool
+    if _host_pool is None:
+        _host_pool = _HostPool()
+    return _host_pool.empty(shape, dtype)

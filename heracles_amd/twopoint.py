@@ -286,7 +286,7 @@ def mixmat(cl, l1max=None, l2max=None, l3max=None, spin=(0, 0)):
     axis 0 is the output multipole."""
     cl, l1max, l2max, l3max = _mm_args(cl, l1max, l2max, l3max)
     s1, s2 = spin
-    out = np.empty((l1max + 1, l2max + 1))
+    out = _lib.host_empty((l1max + 1, l2max + 1))
     _lib.ensure_init()
     _lib.check(_lib.load().hx_mixmat(_lib.ptr(cl), cl.shape[0], l1max, l2max, l3max, int(s1), int(s2), _lib.ptr(out)))
     return out
@@ -297,7 +297,7 @@ def mixmat_eb(cl, l1max=None, l2max=None, l3max=None, spin=(2, 2)):
     cl, l1max, l2max, l3max = _mm_args(cl, l1max, l2max, l3max)
     if tuple(abs(s) for s in spin) != (2, 2):
         raise NotImplementedError(f"mixmat_eb for spin {spin} not supported")
-    out = np.empty((3, l1max + 1, l2max + 1))
+    out = _lib.host_empty((3, l1max + 1, l2max + 1))
     _lib.ensure_init()
     _lib.check(_lib.load().hx_mixmat_eb(_lib.ptr(cl), cl.shape[0], l1max, l2max, l3max, _lib.ptr(out)))
     return out
@@ -360,7 +360,7 @@ class MixmatContext:
             raise NotImplementedError(f"mixing matrix for spin {tuple(spin)} not supported")
         cl = np.ascontiguousarray(np.asarray(cl, dtype=np.float64))
         shape = (self.l1max + 1, self.l2max + 1)
-        out = np.empty((3,) + shape if kind == 4 else shape)
+        out = _lib.host_empty((3,) + shape if kind == 4 else shape)
         _lib.check(_lib.load().hx_mixctx_apply(self._h, _lib.ptr(cl), cl.shape[0], kind, _lib.ptr(out)))
         return out
 
