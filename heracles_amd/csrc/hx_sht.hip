@@ -455,53 +455,85 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const Ri
     unsigned long long fcyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flast = __builtin_amdgcn_s_memtime();
 #endif
     // (the record of the next item's ring pair is requested behind this item's pixel loads: see k_ring_subdft)
+    static_assert(HX_PAIR_ROUNDS == 1 || HX_PAIR_ROUNDS == 2, "one or two rounds per item");
     auto ring_of = [&](int item) __attribute__((always_inline)) { return HX_PAIR_ROUNDS == 2 ? item / nb : ((item >> 4) / nb) * 8 + (item & 7); };
+    auto comp_of = [&](int item) __attribute__((always_inline)) { return HX_PAIR_ROUNDS == 2 ? item % nb : (item >> 4) % nb; };
     RingDesc cur = RingDesc{0, 0, 0, 1, 0};
     if ((int)blockIdx.x < nitems && ring_of(blockIdx.x) < nrings) cur = desc[ring_of(blockIdx.x)];
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        // one round per item: item = 8 (2 s + rpair) + x -- the two items of set s = (ring set s / nb, component s % nb) on XCD x
-        const int rfirst = HX_PAIR_ROUNDS == 2 ? 0 : (item >> 3) & 1, set = item >> 4;
-        const int ring = ring_of(item), c = HX_PAIR_ROUNDS == 2 ? item % nb : set % nb;
-        const int itn = item + gridDim.x, ringn = itn < nitems ? ring_of(itn) : nrings;
-        const bool nextv = ringn < nrings;
-        if (ring >= nrings) {
-            if (nextv) cur = desc[ringn];
-            continue;
-        }
-        const long long sN = cur.sN, sS = cur.sS;
-        asm volatile("; item" : "+v"(tid));
-        const bool haveS = sS >= 0, pw = MODE == 0 && !WSYM && pixw != nullptr;
-        constexpr bool wsym = MODE == 0 && WSYM;
-        const double *mpN = maps + (long long)c * P.npix + sN, *mpS = maps + (long long)c * P.npix + (haveS ? sS : sN);
-        const double *pwN = pixw + sN, *pwS = pixw + (haveS ? sS : sN);
-        const double2 *zp = zin + (long long)c * P.ny + sN;
-        struct __attribute__((aligned(8))) Pair { double x, y; };
-        // pairs of neighbouring j: 2 (tid + k nt), k < 4 (n / 2 pairs over nt = n / 8 threads, or 128 threads for n <= 1024)
-        double2 z[RING_FB][4];
+    // Pixels: pairs of neighbouring j: 2 (tid + k nt), k < 4 (n / 2 pairs over nt = n / 8 threads, or 128 threads for n <= 1024).  A batch is
+    // REQUESTED raw -- z[u][q], z[u + 1][q] hold the northern and the southern pair, the symmetric weight pair sits beside them -- and
+    // FINISHED where the fill uses it (k_ring_subdft).  The FIRST HALF of the NEXT item's batch (u < 4: 72 registers) is requested
+    // behind this item's fill and lands under its transforms and read-out -- the radix-16 passes (134 registers) leave room for half a
+    // batch, not for a whole one; the second half goes out at the start of the item and lands under the fill of the first.  (An item
+    // used to wait 21k of its 52k cycles for its one batch with nothing to cover it: one work-group per CU.)
+    struct __attribute__((aligned(8))) Pair { double x, y; };
+    double2 z[RING_FB][4];
+    Pair wsy[RING_FB / 2];
+    const bool pw = MODE == 0 && !WSYM && pixw != nullptr;
+    constexpr bool wsym = MODE == 0 && WSYM;
+    auto request = [&](auto U0C, const RingDesc &d, int c) __attribute__((always_inline)) {
+        constexpr int U0 = decltype(U0C)::value;
+        const bool hS = d.sS >= 0;
+        const double *mpN = maps + (long long)c * P.npix + d.sN, *mpS = maps + (long long)c * P.npix + (hS ? d.sS : d.sN);
+        const double *pwN = pixw + d.sN, *pwS = pixw + (hS ? d.sS : d.sN);
+        const double2 *zp = zin + (long long)c * P.ny + d.sN;
 #pragma unroll
-        for (int u = 0; u < RING_FB; u += 2) {
+        for (int u = U0; u < U0 + RING_FB / 2; u += 2) {
             const int j = 2 * (tid + (u >> 1) * nt), jj = j + 1 < n ? j : 0;
-            Pair wq = {1.0, 1.0};
-            if (MODE == 0 && wsym) wq = *reinterpret_cast<const Pair *>(pwN + jj);
+            wsy[u >> 1] = Pair{1.0, 1.0};
+            if (MODE == 0 && wsym) wsy[u >> 1] = *reinterpret_cast<const Pair *>(pwN + jj);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = jj + q * n;
                 if (MODE == 0) {
                     Pair fn = *reinterpret_cast<const Pair *>(mpN + i), fs = *reinterpret_cast<const Pair *>(mpS + i);
-                    if (wsym) {
-                        fn.x *= wq.x; fn.y *= wq.y; fs.x *= wq.x; fs.y *= wq.y;
-                    } else if (pw) {
+                    if (!wsym && pw) {  // (generic weight arrays: applied at the load -- their raw values would need another 128 registers)
                         const Pair wn = *reinterpret_cast<const Pair *>(pwN + i), ws = *reinterpret_cast<const Pair *>(pwS + i);
                         fn.x *= wn.x; fn.y *= wn.y; fs.x *= ws.x; fs.y *= ws.y;
                     }
-                    z[u][q] = make_double2(fn.x, haveS ? fs.x : 0.0);
-                    z[u + 1][q] = make_double2(fn.y, haveS ? fs.y : 0.0);
+                    z[u][q] = make_double2(fn.x, fn.y);
+                    z[u + 1][q] = make_double2(fs.x, fs.y);
                 } else {
                     z[u][q] = zp[i];
                     z[u + 1][q] = zp[i + 1];
                 }
             }
         }
+    };
+    auto finish = [&](bool hS) __attribute__((always_inline)) {
+        if (MODE != 0) return;
+#pragma unroll
+        for (int u = 0; u < RING_FB; u += 2) {
+            const Pair w = wsy[u >> 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double2 rn = z[u][q], rs = z[u + 1][q];
+                const double nx = wsym ? rn.x * w.x : rn.x, ny = wsym ? rn.y * w.y : rn.y;
+                const double sx = wsym ? rs.x * w.x : rs.x, sy = wsym ? rs.y * w.y : rs.y;
+                z[u][q] = make_double2(nx, hS ? sx : 0.0);
+                z[u + 1][q] = make_double2(ny, hS ? sy : 0.0);
+            }
+        }
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, RING_FB / 2>;
+    bool have_half = false;  // the first half of this item's batch was requested by the item before it
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        // one round per item: item = 8 (2 s + rpair) + x -- the two items of set s = (ring set s / nb, component s % nb) on XCD x
+        const int rfirst = HX_PAIR_ROUNDS == 2 ? 0 : (item >> 3) & 1;
+        const int ring = ring_of(item), c = comp_of(item);
+        const int itn = item + gridDim.x, ringn = itn < nitems ? ring_of(itn) : nrings;
+        const bool nextv = ringn < nrings;
+        if (ring >= nrings) {
+            if (nextv) cur = desc[ringn];
+            have_half = false;
+            continue;
+        }
+        const long long sN = cur.sN, sS = cur.sS;
+        asm volatile("; item" : "+v"(tid));
+        const bool haveS = sS >= 0;
+        if (!have_half) request(H0{}, cur, c);
+        request(H1{}, cur, c);
         int4 nd0 = make_int4(0, 0, 0, 0);
         if (nextv) nd0 = *(reinterpret_cast<const int4 *>(desc + ringn) + (tid >> 30));
         // round 0 = sub-DFTs 0 and 2, round 1 = sub-DFTs 1 and 3 (one round per work item by default: HX_PAIR_ROUNDS)
@@ -515,6 +547,7 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const Ri
         __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the pixels have landed
         HX_FSTAMP(1);
 #endif
+        if (rpair == rfirst) finish(haveS);
 #pragma unroll
         for (int u = 0; u < RING_FB; ++u) {
             const int j = 2 * (tid + (u >> 1) * nt) + (u & 1);
@@ -531,9 +564,12 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const Ri
         HX_FSTAMP(2);
         // the next item's record: taken HERE, in front of this item's stores -- waited for behind them (their number is not known to
         // the compiler) it is s_waitcnt vmcnt(0), and the next item's loads are issued when the last store has been acknowledged
-        if (nextv && rpair == rfirst) {
+        have_half = false;
+        if (nextv && rpair == rfirst + HX_PAIR_ROUNDS - 1) {
             cur.sN = ((long long)__builtin_amdgcn_readfirstlane(nd0.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(nd0.x);
             cur.sS = ((long long)__builtin_amdgcn_readfirstlane(nd0.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(nd0.z);
+            request(H0{}, cur, comp_of(itn));  // (z is free behind the last fill of the item)
+            have_half = true;
         }
         const int half = tid >= nh ? 1 : 0, gt = tid - half * nh;
         double2 *bh = buf + half * MP;
