@@ -490,10 +490,14 @@ def test_host_maps_streamed_in_slabs_of_rings_are_bit_identical(nside, lmax):
     operand rows and completed ring groups run behind it.  The ring groups of an order are added in the order they always are, so the
     alms equal those of the same sweeps over device-resident maps bit for bit -- for one job (hx_map2alm), several jobs
     (hx_map2alm_multi, spin 2 then spin 0, with a batch that needs two sweeps) and separate arrays (hx_map2alm_list)."""
+    import os
+
     import torch
 
     import heracles_amd as hx
 
+    if os.environ.get("HX_LEG_KERNEL") == "pipe":
+        pytest.skip("the A/B kernel of rounds 2-3 takes host maps in round 3's sweeps of whole maps (other sweep shapes than the resident call: equal to rounding only)")
     rng = np.random.default_rng(5)
     npix = 12 * nside**2
     plan = hx.get_plan(nside, lmax)
