@@ -199,3 +199,19 @@ def test_mixing_matrices_batched_context(oracle):
             np.testing.assert_array_equal(o02[k], hx.mixmat(cl, l1max=20, l2max=22, l3max=L, spin=(2, 0)))
         if kinds[k] & 4:
             np.testing.assert_array_equal(oeb[k], hx.mixmat_eb(cl, l1max=20, l2max=22, l3max=L))
+
+
+@pytest.mark.parametrize("L", [300, 1023, 2047])
+def test_mixmat_eb_builds_are_bitwise_repeatable(L):
+    """k_mixmat_gemm_dma orders its LDS reads behind loads that write LDS directly by hand (counted vmcnt + barrier): a read that
+    came too early would show as a build that differs from the others.  Sizes with one round of tiles, a partly filled round
+    and several rounds per XCD; the same screen at L = 4096 / 6144, and against the register-staged kernel, is in
+    tools/soak_mixmat.py (profiles/r04_soak_mixmat.txt)."""
+    import hashlib
+
+    import heracles_amd as hx
+
+    ell = np.arange(L + 1)
+    wl = 4 * np.pi * 0.35 * np.exp(-ell * (ell + 1) / (0.08 * L * L)) + 1e-3 / (1.0 + ell) ** 2
+    seen = {hashlib.sha1(np.ascontiguousarray(hx.mixmat_eb(wl)).tobytes()).hexdigest() for _ in range(6)}
+    assert len(seen) == 1
