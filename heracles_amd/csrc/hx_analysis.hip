@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
 // group's matrix block (cycle accounting per wave-block, ten fields: recursion 4180 -> 3260, reduction 1965 -> 740, second barrier 547 ->
 // 208) -- and the matrix block pays for every instruction let in (5390 -> 7850 with s_nop 7): 344 -> 337 ms for ten fields, a wash or a
 // loss elsewhere (five fields 196 -> 203, ten spin-0 maps 100 -> 102); s_nop 3 is a gain of ~1 % everywhere.  HX_DUO_GAP = n: s_nop n - 1
-// behind every such pair (0: none; -1: 8 for the 40-column shape, none for the 24- and 36-column ones -- six fields 222 -> 225 ms, nine 303 -> 310 with s_nop 3 --, 4 otherwise: five fields 196 -> 194, eight 275 -> 272, ten spin-0 maps 100.2 -> 99.2, sixteen 147.6 -> 139.7); HX_DUO_PRIO: s_setprio 3 outside the matrix block.
+// behind every such pair (0: none; -1: 5 for the 40-column shape -- ten fields 344 ms without, 340 / 326 / 328 / 333 / 337 / 347 with n = 4 / 5 / 6 / 7 / 8 / 10 --, 6 for the 36-column one -- nine fields 304 ms without, 310 / 300.5 / 299.6 with n = 4 / 5 / 6 --, none for the 24-column one -- six fields 222 -> 225 ms with n = 3 ... 5 --, 4 otherwise (2 and 3 lose): five fields 196 -> 194, eight 275 -> 272, ten spin-0 maps 100.2 -> 99.2, sixteen 147.6 -> 139.7); HX_DUO_PRIO: s_setprio 3 outside the matrix block.
 #ifndef HX_DUO_GAP
 #define HX_DUO_GAP -1
 #endif
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
     constexpr int NXA = NBX > 0 ? NBX : 1;
     constexpr int DQ0 = NG * 512, DSZ = NG * 512 + NBX * 128;
     constexpr bool HALFB = SPIN == 2;
-    constexpr int GAPN = HX_DUO_GAP >= 0 ? HX_DUO_GAP : ((SPIN == 2 && NG == 2 && NBX == 2) ? 8 : (SPIN == 2 && NG + NBX == 3) ? 0 : 4);
+    constexpr int GAPN = HX_DUO_GAP >= 0 ? HX_DUO_GAP : ((SPIN == 2 && NG == 2 && NBX == 2) ? 5 : (SPIN == 2 && NG == 2 && NBX == 1) ? 6 : (SPIN == 2 && NG == 1 && NBX == 2) ? 0 : 4);
     constexpr int NPB = HALFB ? 1 : 2;  // operand positions kept in registers
     // doubles per wave of its tile: the 16 x 64 lambda tile (2048), or the D tiles of a flush if they need more (two blocks of 36 / 40
     // columns: 2304 / 2560 -- 80 KiB per work-group, still two per CU)
@@ -1384,7 +1384,7 @@ static double sweep_cost(int spin, int units)
 {
     if (leg_duo()) {  // k_legendre_duo, round 4, with the gaps of HX_DUO_GAP (gpurun_out/ab_gap3.txt, ab_gap4.txt)
         if (spin == 0) return units <= 4 ? 21.6 * units : (units <= 8 ? 84.1 : (units <= 10 ? 99.2 : 139.7));
-        return units <= 2 ? 61.0 * units : (units <= 4 ? 164.5 : (units == 5 ? 194.1 : (units == 6 ? 222.0 : (units <= 8 ? 272.0 : (units == 9 ? 304.0 : 336.0)))));
+        return units <= 2 ? 61.0 * units : (units <= 4 ? 164.5 : (units == 5 ? 194.1 : (units == 6 ? 222.0 : (units <= 8 ? 272.0 : (units == 9 ? 299.6 : 326.0)))));
     }
     if (spin == 0) return units <= 4 ? 21.6 * units : (units <= 8 ? 100.0 : (units <= 10 ? 115.0 : 162.0));
     return units <= 2 ? 61.0 * units : (units <= 4 ? 196.0 : (units == 5 ? 224.0 : (units <= 8 ? 316.0 : (units == 9 ? 360.0 : 400.0))));
