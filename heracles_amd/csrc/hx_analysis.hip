@@ -822,6 +822,9 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
 #ifndef HX_DUO_PRIO
 #define HX_DUO_PRIO 1
 #endif
+#ifndef HX_DUO_ORDER
+#define HX_DUO_ORDER -1  // -1: per shape (GORDER)
+#endif
 #ifndef HX_DUO_ABL
 #define HX_DUO_ABL 0  // timing experiments only: 1 no matrix instructions, 2 no recursion, 4 no flush, 8 plain stores instead of atomics, 32 cycle accounting
 #endif
@@ -855,6 +858,9 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
     constexpr int DQ0 = NG * 512, DSZ = NG * 512 + NBX * 128;
     constexpr bool HALFB = SPIN == 2;
     constexpr int GAPN = HX_DUO_GAP >= 0 ? HX_DUO_GAP : ((SPIN == 2 && NG == 2 && NBX == 2) ? 5 : (SPIN == 2 && NG == 2 && NBX == 1) ? 6 : (SPIN == 2 && NG == 1 && NBX == 2) ? 0 : 4);
+    // where the gaps stand: 0 behind every (16 x 16 x 4, 4 x 4 x 4) pair; 1 between the two instructions of a pair (ten spin-0 maps 99.4 ->
+    // 98.1 ms; ten fields 344: not there); 2 behind the 16 x 16 x 4 and behind the 4 x 4 x 4 instructions of a position (ten fields 326.5 -> 324)
+    constexpr int GORDER = HX_DUO_ORDER >= 0 ? HX_DUO_ORDER : ((SPIN == 2 && NG == 2 && NBX == 2) ? 2 : (SPIN == 0 && NG == 1 && NBX == 1) ? 1 : 0);
     constexpr int NPB = HALFB ? 1 : 2;  // operand positions kept in registers
     // doubles per wave of its tile: the 16 x 64 lambda tile (2048), or the D tiles of a flush if they need more (two blocks of 36 / 40
     // columns: 2304 / 2560 -- 80 KiB per work-group, still two per CU)
@@ -1100,6 +1106,28 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
                             const double a = pos ? a1 : a0;
                             if (GAPN > 0) {
                                 // one 16 x 16 x 4 (+ one 4 x 4 x 4) instruction, then a gap of a few cycles: see HX_DUO_GAP
+                                if (GORDER == 1) {  // the gap between the 16 x 16 x 4 and the 4 x 4 x 4 instruction of a pair
+#pragma unroll
+                                for (int g = 0; g < (NG > NBX ? NG : NBX); ++g) {
+                                    if (g < NG) acc[sub][g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[sp][HALFB ? 0 : pos][g], acc[sub][g][pos], 0, 0, 0);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    asm volatile("s_nop %0" ::"n"(GAPN > 0 ? GAPN - 1 : 0));
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    if (g < NBX) accx[sub][g][pos] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[sp][HALFB ? 0 : pos][g], accx[sub][g][pos], 0, 0, 0);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                                } else if (GORDER == 2) {  // all 16 x 16 x 4 of the position, gap, all 4 x 4 x 4, gap
+#pragma unroll
+                                for (int g = 0; g < NG; ++g) acc[sub][g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[sp][HALFB ? 0 : pos][g], acc[sub][g][pos], 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                                asm volatile("s_nop %0" ::"n"(GAPN > 0 ? GAPN - 1 : 0));
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int g = 0; g < NBX; ++g) accx[sub][g][pos] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, frx[sp][HALFB ? 0 : pos][g], accx[sub][g][pos], 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (NBX > 0) asm volatile("s_nop %0" ::"n"(GAPN > 0 ? GAPN - 1 : 0));
+                                __builtin_amdgcn_sched_barrier(0);
+                                } else {
 #pragma unroll
                                 for (int g = 0; g < (NG > NBX ? NG : NBX); ++g) {
                                     if (g < NG) acc[sub][g][pos] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fr[sp][HALFB ? 0 : pos][g], acc[sub][g][pos], 0, 0, 0);
@@ -1107,6 +1135,7 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
                                     __builtin_amdgcn_sched_barrier(0);
                                     asm volatile("s_nop %0" ::"n"(GAPN > 0 ? GAPN - 1 : 0));
                                     __builtin_amdgcn_sched_barrier(0);
+                                }
                                 }
                             } else {
 #pragma unroll
