@@ -9,13 +9,17 @@ weights, a synthetic full-sky pixel-weight array) + all auto/cross Cl of every m
 `value` is that device-resident rate (the task contract: inputs resident in HBM when the timed region starts);
 `value_host_to_host` is SURVEY 8d's definition (pageable host maps in, Cl blocks on the host out; median of --host-steps).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its own N ranks, see self_launch)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1, --scaling weak (default): every rank brings its own 20 maps, alms are all-gathered over RCCL/xGMI, the
-tiled pair list over all 20*N maps is dealt to the ranks (per-GPU SHT work is fixed; pairs grow as N^2).
-N > 1, --scaling strong: the SAME 20-map job is dealt to the N ranks by cost (a spin-2 map = 3 units).
-Rank 0 prints ONE JSON line.
+`value` at EVERY N is pairs/s of the SAME 20-map job (210 map pairs): value(N) / value(1) is a speed-up <= N ("scaling": "strong").
+At N > 1 that job runs through both fixed-job routes of heracles_amd.distributed, each timed for exactly K steps --
+  m-sharded:  ring Fourier stage of the rank's maps -> all-to-all of ring modes by owner of the order m -> Legendre stage of ALL
+              components on the rank's orders -> partial Cl -> all-reduce (MShardedTwoPoint);
+  all-gather: the 20 maps dealt to the ranks by cost -> in-place all-gather of the alms -> tiled pair split (ShardedTwoPoint)
+-- `value` is the better of the two, named in config.parallelism; both are in "routes".  The job that GROWS with N (every rank
+brings its own 20 maps, pairs grow as N^2) is reported beside it as `value_weak` with its pair count and a per-GPU transform rate;
+`--scaling weak` makes that figure `value` instead.  Rank 0 prints ONE JSON line.
 """
 
 from __future__ import annotations
@@ -45,7 +49,9 @@ def parse():
     p.add_argument("--nside", type=int, default=4096)
     p.add_argument("--lmax", type=int, default=6144)
     p.add_argument("--nbins", type=int, default=10, help="tomographic bins: nbins x (spin-0, spin-2) maps per GPU (weak) / in all (strong)")
-    p.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    p.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                   help="which figure is `value` at N > 1: strong = the SAME job at every N (default), weak = a job that grows with N")
+    p.add_argument("--weak-steps", type=int, default=None, help="timed steps of the weak-scaling leg at N > 1 when it is not `value` (default min(steps, 5))")
     p.add_argument("--workload", choices=("north_star", "euclid"), default="north_star",
                    help="north_star: nbins x (spin-0, spin-2) maps (the default line); euclid: BASELINE configs[4] on ONE GPU -- "
                         "13 bins x (2 spin-0 + 1 spin-2) = 39 maps / 52 components / 780 pairs (not the driver's line)")
@@ -56,6 +62,7 @@ def parse():
     p.add_argument("--no-host-leg", action="store_true", help="skip the host -> host (PCIe-inclusive) measurement")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--no-single", action="store_true", help="skip the single-map transform timings")
+    p.add_argument("--launch-check", action="store_true", help="every rank checks its rendezvous variables and exits (rank 0 prints them); no GPU is touched")
     p.add_argument("--generic-weights", action="store_true", help="pixel weights without the symmetry of healpy's files (generic path of the ring kernels)")
     return p.parse_args()
 
@@ -119,8 +126,65 @@ def cpu_baseline(nside, lmax, nmaps0, nmaps2, a0, a2, tim, stride):
     }
 
 
+def fixed_job(workload, nbins):
+    """Spins of the maps of the job `value` is quoted on (the same at every N), in the job's global order."""
+    if workload == "euclid":
+        return [0] * (2 * 13) + [2] * 13  # 13 bins x (2 spin-0 fields + 1 spin-2 field): BASELINE configs[4]
+    return [0] * nbins + [2] * nbins
+
+
+def self_launch(ngpus):
+    """`python3 bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process -- which has not imported
+    torch, initialised HIP or loaded libhxsht, and never will -- starts the N ranks as child processes of this same script with the
+    rendezvous variables torch.distributed reads, relays rank 0's JSON line (the children inherit stdout; only rank 0 prints),
+    waits for all of them and exits non-zero if any did.  Nothing is exec'ed and no child is started a second time."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(ngpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # a rank that dies leaves the others blocked in their next collective: once one has failed, the rest get a grace period and
+    # are then terminated (exactly the processes started here, by their handles)
+    rc, failed_at = 0, None
+    live = list(procs)
+    while live:
+        for pr in list(live):
+            code = pr.poll()
+            if code is not None:
+                live.remove(pr)
+                if code != 0 and rc == 0:
+                    rc, failed_at = code, time.time()
+        if failed_at is not None and live and time.time() - failed_at > 60.0:
+            for pr in live:
+                pr.terminate()
+            time.sleep(5.0)
+            for pr in live:
+                if pr.poll() is None:
+                    pr.kill()
+        time.sleep(0.2)
+    return rc if rc >= 0 else 1
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))  # (before anything that touches the GPU is imported)
+    if args.launch_check:
+        r_, w_ = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        if w_ != args.gpus or not (0 <= r_ < w_) or (w_ > 1 and not os.environ.get("MASTER_PORT")):
+            raise SystemExit(4)
+        if os.environ.get("HX_LAUNCH_CHECK_FAIL") == str(r_):
+            raise SystemExit(3)
+        if r_ == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": w_, "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}), flush=True)
+        return
     import torch
     import torch.distributed as dist
 
@@ -128,8 +192,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # HX_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box only): every rank uses device 0 and the
     # collectives run over gloo on host copies, so the N > 1 code path can be exercised without N GPUs
     share = os.environ.get("HX_BENCH_SHARE_GPU") == "1"
@@ -156,13 +219,14 @@ def main():
     plan = hx.Plan(nside, lmax)
 
     # ---- the job: maps ordered (spin-0 bins, spin-2 bins) per brought-in set ---------------------------------------
-    nsets = world if args.scaling == "weak" else 1
+    # first leg: at N = 1 the job itself; at N > 1 the job that grows with N (every rank brings one set of maps: `value_weak`) -- the
+    # fixed job follows below through both of its routes
+    nsets = world
+    per_set = fixed_job(args.workload, nbins)
     if args.workload == "euclid":
         nbins = 13
-        per_set = [0] * (2 * nbins) + [2] * nbins  # 13 bins x (2 spin-0 fields + 1 spin-2 field): BASELINE configs[4]
-    else:
-        per_set = [0] * nbins + [2] * nbins
     spins = per_set * nsets
+    steps1 = args.steps if (world == 1 or args.scaling == "weak") else (args.weak_steps or min(args.steps, 5))
     nmaps_total = len(spins)
     work = hxd.ShardedTwoPoint(spins, world, rank, nlm, lmax)
     mine = work.local_maps
@@ -205,30 +269,58 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, nsteps, nwarm):
+        """nwarm untimed calls, then EXACTLY nsteps calls between (barrier + synchronize) brackets; seconds = max over the ranks"""
+        res = None
+        for _ in range(nwarm):
+            fn()
+        sync()
+        t_ = time.perf_counter()
+        for _ in range(nsteps):
+            res = fn()
+        sync()
+        d_ = time.perf_counter() - t_
+        if world > 1:
+            tt_ = torch.tensor([d_], dtype=torch.float64, device="cpu" if share else dev)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            d_ = float(tt_.item())
+        return d_, res
+
+    def cl_direct_check(wobj, rows_, checks_):
+        """rows of an all-pairs result against direct sums over the alms in wobj's buffer (independent of the all-pairs kernel):
+        max |got - ref| / max |ref| over the component spectra of the map pairs in checks_, and how many were checked"""
+        w_ = torch.full((nlm,), 2.0, dtype=torch.float64, device=dev)
+        w_[: lmax + 1] = 1.0
+        idx_ = torch.cat([torch.arange(m, lmax + 1, device=dev) for m in range(lmax + 1)])
+        buf_, e_, n_ = wobj.buffer(), 0.0, 0
+        for (i, j) in checks_:
+            i, j = min(i, j), max(i, j)
+            for ka, ca in enumerate(wobj.comps_of_map[i]):
+                for kb, cb in enumerate(wobj.comps_of_map[j]):
+                    a, b_ = buf_[ca], buf_[cb]
+                    ref = torch.zeros(lmax + 1, dtype=torch.float64, device=dev).index_add_(0, idx_, w_ * (a.real * b_.real + a.imag * b_.imag))
+                    ref = (ref / (2.0 * torch.arange(lmax + 1, device=dev) + 1.0)).cpu().numpy()
+                    got = rows_[wobj.row0[i, j] + ka * len(wobj.comps_of_map[j]) + kb]
+                    e_ = max(e_, float(np.abs(got - ref).max() / np.abs(ref).max()))
+                    n_ += 1
+        return e_, n_
+
     for _ in range(args.warmup):
         step()
     hx._lib.profile_enable(True)
     hx._lib.profile_reset()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        cls = step()
-    sync()
-    dt = time.perf_counter() - t0
+    dt, cls = timed(step, steps1, 0)
     hx._lib.profile_enable(False)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
     npairs = len(work.pairs)
-    value = npairs * args.steps / dt
+    value = npairs * steps1 / dt
+    ms_per_step = dt / steps1 * 1e3
 
     # ---- per-family kernel times (HIP events on the library stream) ----------------------------------------------
     prof = {}
     for k in ("ring_fft", "fourier_combine", "legendre_analysis", "legendre_analysis_s0", "legendre_analysis_s2",
               "alm_reduce", "alm2cl"):
         n_, ms_ = hx._lib.profile_get(k)
-        prof[k] = {"launches": n_, "ms_per_step": ms_ / max(args.steps, 1)}
+        prof[k] = {"launches": n_, "ms_per_step": ms_ / max(steps1, 1)}
 
     # ---- roofline of the dominant kernel family (Legendre / Wigner-d analysis, FP64 MFMA + the vector recursion) ----
     F0 = 8.0 * 2 * nside * nlm  # ALGORITHMIC flops of one spin-0 component (SURVEY.md 8d); a spin-2 field is 3 F0
@@ -264,17 +356,17 @@ def main():
         mf, vf = exec2 if spin else exec0
         mf_model = plan.mfma_flops(spin, ncomp) if ncomp else 0.0
         sec = ms_ * 1e-3
-        exe = (mf + vf) * args.steps / sec / 1e12 if sec > 0 else 0.0
+        exe = (mf + vf) * steps1 / sec / 1e12 if sec > 0 else 0.0
         traffic, tpath = pmc_traffic("hx::k_legendre_duo<%d" % spin)
         return {"kernel": kernel, "bound": "mfma", "achieved": exe, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": exe / FP64_PEAK_TFLOPS,
                 "achieved_is": "EXECUTED FP64 flops, counted by the kernel itself (matrix instructions actually issued -- stages whose "
                                "rings are all below 2^-300 skip theirs -- + 4 flops per generated lambda_lm on the vector unit) / kernel time; "
                                "the two share one FP64 pipe (peak 78.6 either way); equals the SQ_INSTS_VALU_MFMA_F64-based figure of profiles/",
-                "task_list_mfma_tflops": mf_model * args.steps / sec / 1e12 if sec > 0 else 0.0,
-                "executed_mfma_tflops": mf * args.steps / sec / 1e12 if sec > 0 else 0.0,
-                "executed_valu_tflops": vf * args.steps / sec / 1e12 if sec > 0 else 0.0,
-                "algorithmic_tflops": alg_flops_step * args.steps / sec / 1e12 if sec > 0 else 0.0,
+                "task_list_mfma_tflops": mf_model * steps1 / sec / 1e12 if sec > 0 else 0.0,
+                "executed_mfma_tflops": mf * steps1 / sec / 1e12 if sec > 0 else 0.0,
+                "executed_valu_tflops": vf * steps1 / sec / 1e12 if sec > 0 else 0.0,
+                "algorithmic_tflops": alg_flops_step * steps1 / sec / 1e12 if sec > 0 else 0.0,
                 "algorithmic_is": "SURVEY 8d's F0 = 8 * 2 nside * nlm per spin-0 component (3 F0 per spin-2 field) / kernel time; "
                                   "exceeds the executed rate because north/south symmetry, ring pruning and the shared recursion "
                                   "remove work -- not a pipe utilisation",
@@ -283,16 +375,20 @@ def main():
                 "launches": nl_, "avg_launch_ms": ms_ / nl_ if nl_ else None}
 
     nc0, nc2 = n0, 2 * n2
+    # (at N > 1 the roofline blocks come from the first leg, whose per-GPU job is the N = 1 job: the same launches of the same kernels)
     roofline = roof("legendre_analysis_s2", "hx::k_legendre_duo<2,*>", n2 * 3 * F0, 2, nc2)
     roofline_s0 = roof("legendre_analysis_s0", "hx::k_legendre_duo<0,*>", n0 * F0, 0, nc0)
 
-    # ---- N > 1: the FIXED job (one set of maps) on all N GPUs, sharded by m (MShardedTwoPoint): ring modes of the rank's maps ->
-    # all-to-all by m-range -> full-batch Legendre on the rank's range -> partial Cl -> all-reduce.  Reported as value_strong. ----
-    strong, verify_multi = None, None
+    # ---- N > 1: the FIXED job (one set of maps: the N = 1 job) on all N GPUs through both routes, K steps each.  `value` is the
+    # better one: the same 210 pairs at every N. ----
+    strong, verify_multi, routes, weak_check = None, None, None, None
     if world > 1:
-        del maps0, maps2  # (the weak-scaling maps are not needed any more at N > 1: room for the fixed job's buffers)
+        if rank == 0 and not args.no_verify:
+            e_, n_ = cl_direct_check(work, cls, [(0, 0), (0, nmaps_total - 1), (nmaps_total - 1, nmaps_total - 1), (0, nbins)])
+            weak_check = {"max_err_over_max": e_, "spectra_checked": n_, "tolerance": 1e-11, "ok": bool(e_ <= 1e-11)}
+        del maps0, maps2, alm0, alm2  # (the weak-scaling job is done: room for the fixed job's buffers)
+        work._buf = None
         torch.cuda.empty_cache()
-        cdev = "cpu" if share else dev
 
         def seeded_maps(gs):
             """maps of the fixed job's global indices gs (spin-0 first, as the routes hold them), seeded by the index: the same
@@ -307,78 +403,97 @@ def main():
                 t2[k] = torch.randn((2, npix), dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(7000 + g))
             return t0, t2
 
-        # (a failure of this leg -- it has never run over RCCL, only over gloo and in a one-GPU rehearsal -- must not cost the line
-        # its weak-scaling value: the ranks agree on success before every collective (guard=True) and an exception is raised by
-        # all of them alike and reported instead of the figure)
-        cls_strong = None
+        def leg_kernels(nsteps):
+            kk = {}
+            for k in ("ring_fft", "ring_modes", "fourier_combine", "legendre_analysis", "alm_reduce", "alm2cl"):
+                n_, ms_ = hx._lib.profile_get(k)
+                if n_:
+                    kk[k] = {"launches": n_, "ms_per_step": ms_ / max(nsteps, 1)}
+            return kk
+
+        routes = {}
+        # (a failure of a route -- neither has run over RCCL before the driver's first N > 1 run, only over gloo and in one-GPU
+        # rehearsals -- must not cost the line the other route: the ranks agree on success before every collective of the m-sharded
+        # route (guard=True) and an exception is raised by all of them alike and reported instead of the figure)
+        cls_m = None
         try:
             ms = hxd.MShardedTwoPoint(per_set, world, rank, nlm, lmax, hxd.HipStages(plan, dev))
             s0, s2 = seeded_maps(ms.local_maps)
-            for _ in range(max(args.warmup, 1)):
+            for _ in range(args.warmup):
                 ms.run(s0, s2, pix_weights=pw, guard=True)
-            sync()
-            ts = time.perf_counter()
-            for _ in range(args.steps):
-                cls_strong = ms.run(s0, s2, pix_weights=pw, guard=True)
-            sync()
-            dts = time.perf_counter() - ts
-            tt = torch.tensor([dts], dtype=torch.float64, device=cdev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dts = float(tt.item())
-            strong = {"value": len(ms.pairs) * args.steps / dts, "unit": "map->Cl pairs/s", "ms_per_step": dts / args.steps * 1e3,
-                      "maps_total": len(per_set), "pairs": len(ms.pairs), "orders_first_count_step": ms.sets,
-                      "checksum": float(np.abs(cls_strong).sum()),
-                      "what": "the SAME job at every N (one set of maps): ring Fourier stage of the rank's maps, all-to-all of the ring modes by "
-                              "owner of the order m (rank q: m = q, q + N, ...) over RCCL, Legendre stage of ALL components on the rank's orders, partial Cl, all-reduce"}
+            hx._lib.profile_enable(True)
+            hx._lib.profile_reset()
+            dts, cls_m = timed(lambda: ms.run(s0, s2, pix_weights=pw, guard=True), args.steps, 0)
+            hx._lib.profile_enable(False)
+            routes["m_sharded"] = {"value": len(ms.pairs) * args.steps / dts, "unit": "map->Cl pairs/s", "ms_per_step": dts / args.steps * 1e3,
+                                   "maps_total": len(per_set), "pairs": len(ms.pairs), "orders_first_count_step": ms.sets,
+                                   "checksum": float(np.abs(cls_m).sum()), "kernels_rank0": leg_kernels(args.steps),
+                                   "what": "ring Fourier stage of the rank's maps, all-to-all of the ring modes by owner of the order m (rank q: m = q, "
+                                           "q + N, ...) over RCCL, Legendre stage of ALL components on the rank's orders, partial Cl, all-reduce"}
             del s0, s2, ms
-            torch.cuda.empty_cache()
         except Exception as exc:  # noqa: BLE001
-            strong = {"value": None, "error": f"{type(exc).__name__}: {exc}"[:400]}
-            cls_strong = None
+            hx._lib.profile_enable(False)
+            routes["m_sharded"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"[:400]}
+            cls_m = None
+        torch.cuda.empty_cache()
 
-        # ---- verification at N > 1 (outside every timed region): the SAME seeded job through the all-gather route, whose rows on
-        # rank 0 are compared (i) with the m-sharded route's spectra and (ii) with direct sums over the gathered alms ----
-        if not args.no_verify:
-            try:
-                wk = hxd.ShardedTwoPoint(per_set, world, rank, nlm, lmax)
-                v0, v2 = seeded_maps(wk.local_maps)
-                a0, a2 = wk.local_alm_views(dev)
+        rows, wk = None, None
+        try:
+            wk = hxd.ShardedTwoPoint(per_set, world, rank, nlm, lmax)
+            v0, v2 = seeded_maps(wk.local_maps)
+            a0, a2 = wk.local_alm_views(dev)
+
+            def ag_step():
                 if v2.shape[0]:
                     plan.map2alm(v2.view(-1, npix), 2, pix_weights=pw, out=a2.view(-1, nlm))
                 wk.exchange_begin(2)
                 if v0.shape[0]:
                     plan.map2alm(v0, 0, pix_weights=pw, out=a0)
                 wk.exchange_begin(0)
-                rows = wk.all_pairs_cl()
-                if rank == 0:
-                    verify_multi = {"routes": None, "cl_vs_direct_sum": None}
-                    if cls_strong is not None:
-                        e = float(np.abs(cls_strong - rows).max() / np.abs(rows).max())
-                        verify_multi["routes"] = {"m_sharded_vs_all_gather_max_err_over_max": e, "spectra": int(rows.shape[0]), "tolerance": 1e-10}
-                    wv = torch.full((nlm,), 2.0, dtype=torch.float64, device=dev)
-                    wv[: lmax + 1] = 1.0
-                    idx_l = torch.cat([torch.arange(m, lmax + 1, device=dev) for m in range(lmax + 1)])
-                    bufv, ecl, nchk = wk.buffer(), 0.0, 0
-                    nm = len(per_set)
-                    for (i, j) in [(0, 0), (0, nm - 1), (nm - 1, nm - 1), (nm // 2, nm // 2 + 1)]:
-                        for ka, ca in enumerate(wk.comps_of_map[i]):
-                            for kb, cb in enumerate(wk.comps_of_map[j]):
-                                a, b_ = bufv[ca], bufv[cb]
-                                ref = torch.zeros(lmax + 1, dtype=torch.float64, device=dev).index_add_(0, idx_l, wv * (a.real * b_.real + a.imag * b_.imag))
-                                ref = (ref / (2.0 * torch.arange(lmax + 1, device=dev) + 1.0)).cpu().numpy()
-                                got = rows[wk.row0[i, j] + ka * len(wk.comps_of_map[j]) + kb]
-                                ecl = max(ecl, float(np.abs(got - ref).max() / np.abs(ref).max()))
-                                nchk += 1
-                    verify_multi["cl_vs_direct_sum"] = {"max_err_over_max": ecl, "spectra_checked": nchk, "tolerance": 1e-11}
-                    verify_multi["ok"] = bool(ecl <= 1e-11 and (verify_multi["routes"] is None or verify_multi["routes"]["m_sharded_vs_all_gather_max_err_over_max"] <= 1e-10))
-                    verify_multi["what"] = ("the fixed job (maps seeded by their global index) through both routes: spectra of the m-sharded route (all-to-all "
-                                            "+ all-reduce) against the rows of the all-gather route on rank 0, and map pairs of the latter against direct sums "
-                                            "over the gathered alms")
-                    del wv, idx_l
-                del v0, v2, wk
+                return wk.all_pairs_cl()
+
+            for _ in range(args.warmup):
+                ag_step()
+            hx._lib.profile_enable(True)
+            hx._lib.profile_reset()
+            dta, rows = timed(ag_step, args.steps, 0)
+            hx._lib.profile_enable(False)
+            routes["all_gather"] = {"value": len(wk.pairs) * args.steps / dta, "unit": "map->Cl pairs/s", "ms_per_step": dta / args.steps * 1e3,
+                                    "maps_total": len(per_set), "pairs": len(wk.pairs), "maps_of_rank": [len(m_) for m_ in wk.maps_of],
+                                    "kernels_rank0": leg_kernels(args.steps),
+                                    "what": "the maps dealt to the ranks by cost (a spin-2 map = 3 units), transforms into the rank's shard of ONE buffer, "
+                                            "in-place all-gather per spin over RCCL (spin-2 part under the spin-0 transform), tiled pair split, Cl blocks gathered on rank 0"}
+            del v0, v2
+        except Exception as exc:  # noqa: BLE001
+            hx._lib.profile_enable(False)
+            routes["all_gather"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"[:400]}
+            rows = None
+
+        # ---- verification at N > 1 (outside every timed region), on the results of the two timed routes -- the same seeded maps went
+        # through both: (i) the m-sharded route's spectra against the all-gather route's rows, (ii) map pairs of the latter against
+        # direct sums over the gathered alms ----
+        if not args.no_verify and rank == 0:
+            try:
+                verify_multi = {"routes": None, "cl_vs_direct_sum": None}
+                if rows is None:
+                    raise RuntimeError("the all-gather route did not produce its rows: " + str(routes["all_gather"].get("error")))
+                if cls_m is not None:
+                    e = float(np.abs(cls_m - rows).max() / np.abs(rows).max())
+                    verify_multi["routes"] = {"m_sharded_vs_all_gather_max_err_over_max": e, "spectra": int(rows.shape[0]), "tolerance": 1e-10}
+                nm = len(per_set)
+                ecl, nchk = cl_direct_check(wk, rows, [(0, 0), (0, nm - 1), (nm - 1, nm - 1), (nm // 2, nm // 2 + 1)])
+                verify_multi["cl_vs_direct_sum"] = {"max_err_over_max": ecl, "spectra_checked": nchk, "tolerance": 1e-11}
+                verify_multi["ok"] = bool(ecl <= 1e-11 and verify_multi["routes"] is not None
+                                          and verify_multi["routes"]["m_sharded_vs_all_gather_max_err_over_max"] <= 1e-10)
+                verify_multi["what"] = ("the fixed job (maps seeded by their global index) through both timed routes: spectra of the m-sharded route "
+                                        "(all-to-all + all-reduce) against the rows of the all-gather route on rank 0, and map pairs of the latter "
+                                        "against direct sums over the gathered alms; ok needs BOTH")
             except Exception as exc:  # noqa: BLE001
                 verify_multi = {"ok": False, "error": f"{type(exc).__name__}: {exc}"[:400]}
-            torch.cuda.empty_cache()
+        del wk
+        torch.cuda.empty_cache()
+        best = max((k for k in routes if routes[k].get("value")), key=lambda k: routes[k]["value"], default=None)
+        strong = dict(routes[best], route=best) if best else {"value": None, "error": "both fixed-job routes failed", "route": None}
 
     out = None
     if rank == 0:
@@ -423,7 +538,7 @@ def main():
             oa0, oa2, tim = oracle_sample(nside, lmax, t_host, qu_host, stride, pix_weights=pw.cpu().numpy())
             osample = (oa0, oa2, tim, stride)
             del t_host, qu_host
-        if not args.no_verify:
+        if not args.no_verify and world == 1:
             verify = {}
             if osample is not None:
                 oa0, oa2, tim, stride = osample
@@ -440,31 +555,15 @@ def main():
                 verify.update(alm_vs_oracle={"spin0_max_err_over_max": e0 / scale0, "spin2_max_err_over_max": e2 / scale2,
                                              "m_checked": len(ms_checked), "m_stride": stride, "tolerance": 1e-10})
             # Cl rows against a direct sum over the device alms (independent of the all-pairs kernel)
-            w = torch.full((nlm,), 2.0, dtype=torch.float64, device=dev)
-            w[: lmax + 1] = 1.0
-            idx_l = torch.cat([torch.arange(m, lmax + 1, device=dev) for m in range(lmax + 1)])
-            buf = work.buffer()
-            ecl = 0.0
-            nchk = 0
             checks = [(0, 0), (0, min(1, nmaps_total - 1)), (nmaps_total - 1, nmaps_total - 1)]
             if nmaps_total > nbins:
                 checks.append((0, nbins))
-            for (i, j) in checks:
-                row = work.row0[min(i, j), max(i, j)]
-                for ka, ca in enumerate(work.comps_of_map[min(i, j)]):
-                    for kb, cb in enumerate(work.comps_of_map[max(i, j)]):
-                        a, b_ = buf[ca], buf[cb]
-                        ref = torch.zeros(lmax + 1, dtype=torch.float64, device=dev).index_add_(0, idx_l, w * (a.real * b_.real + a.imag * b_.imag))
-                        ref = (ref / (2.0 * torch.arange(lmax + 1, device=dev) + 1.0)).cpu().numpy()
-                        got = cls[row + ka * len(work.comps_of_map[max(i, j)]) + kb]
-                        ecl = max(ecl, float(np.abs(got - ref).max() / np.abs(ref).max()))
-                        nchk += 1
+            ecl, nchk = cl_direct_check(work, cls, checks)
             verify.update(cl_vs_direct_sum={"max_err_over_max": ecl, "spectra_checked": nchk, "tolerance": 1e-11})
             ok = ecl <= 1e-11
             if "alm_vs_oracle" in verify:
                 ok = ok and verify["alm_vs_oracle"]["spin0_max_err_over_max"] <= 1e-10 and verify["alm_vs_oracle"]["spin2_max_err_over_max"] <= 1e-10
             verify["ok"] = bool(ok)
-            del w, idx_l
         if not args.no_cpu_baseline and world == 1 and osample is not None:  # reported on rank 0 at N = 1 only
             oa0, oa2, tim, stride = osample
             cpu = cpu_baseline(nside, lmax, per_set.count(0), per_set.count(2), oa0, oa2, tim, stride)
@@ -496,28 +595,64 @@ def main():
             ell = np.arange(L + 1)
             wl = 4 * np.pi * 0.35 * np.exp(-ell * (ell + 1) / 3000.0) + 1e-3 / (1.0 + ell) ** 2
             hx.mixmat_eb(wl[:65], l1max=64, l2max=64)  # warm-up (module load)
-            # median of five builds, host -> host each (a 0.9 GB numpy array per call, as the reference returns one: the first touch of fresh pages
-            # is part of the figure and varies with the state of the host's page cache; all three are listed)
-            mix_all = []
-            for _ in range(5):
-                hx._lib.profile_enable(True)
-                hx._lib.profile_reset()
-                tm = time.perf_counter()
-                mm = hx.mixmat_eb(wl)
-                mix_all.append(time.perf_counter() - tm)
-                hx._lib.profile_enable(False)
+            # Where the result goes decides what a build costs, so every destination is timed and named (round 4's median
+            # over builds into a pool of recycled blocks hid 0.125 s outliers; that pool is gone):
+            #   device      -- a device tensor: the GPU side alone (nodes, tables, two products, combine)
+            #   pinned      -- out= a page-locked array the caller keeps (hx.pinned_empty / MixmatContext.result_buffer): + the DMA
+            #   pageable    -- out= a pageable numpy array the caller keeps and has touched: + the staging copy
+            #   fresh       -- no out=: a new 0.9 GB numpy array per build, as convolvecl returns one: + first-touch page faults
+            # `mixmat_build_sec` is the pinned-destination median of five (what a loop over many masks pays per matrix when it hands each
+            # result on, heracles/twopoint.py:393-397); the fresh-array figures stand beside it, first (cold) build included.
+            shape = (3, L + 1, L + 1)
+
+            def builds(n, **kw):
+                ts = []
+                for _ in range(n):
+                    tm = time.perf_counter()
+                    r_ = hx.mixmat_eb(wl, **kw)
+                    if hasattr(r_, "is_cuda"):
+                        torch.cuda.synchronize(dev)
+                    ts.append(time.perf_counter() - tm)
+                return ts, r_
+
+            t_fresh, mm = builds(3)
+            cold = t_fresh[0]
+            del mm
+            dev_out = torch.empty(shape, dtype=torch.float64, device=dev)
+            t_dev, _ = builds(3, out=dev_out)
+            del dev_out
+            pin = hx.pinned_empty(shape)
+            builds(1, out=pin)
+            hx._lib.load().hx_mixmat_gemm_clock()      # (clear the clock samples of the builds so far)
+            hx._lib.profile_enable(True)
+            hx._lib.profile_reset()
+            mix_all, mm = builds(5, out=pin)
+            hx._lib.profile_enable(False)
+            gemm_clock = hx._lib.load().hx_mixmat_gemm_clock()
+            pageable = np.zeros(shape)
+            t_page, _ = builds(3, out=pageable)
+            del pageable
             mix_s = float(np.median(mix_all))
             ng, gms = hx._lib.profile_get("mixmat_gemm")
             _, gkms = hx._lib.profile_get("mixmat_gemm_kernel")
-            gkms = gkms or gms
+            gms, gkms = gms / 5.0, (gkms or gms) / 5.0   # per build (two products)
             N = (3 * L) // 2 + 1
             gflop = 2.0 * (L + 1) ** 2 * N * 2  # two products
             nb_, kpad_ = (L + 1 + 127) // 128, (N + 31) // 32 * 32
             xflop = 2.0 * 128 * 128 * kpad_ * (nb_ * (nb_ + 1) // 2) * 2  # what k_mixmat_gemm executes: the upper triangle of 128 x 128 tiles, padded nodes
-            mix = {"L": L, "seconds": mix_s, "seconds_all": mix_all, "statistic": "median of 5", "gemm_ms": gms, "gemm_kernel_ms": gkms,
-                   "seconds_is": "hx.mixmat_eb host -> host, five builds in a row, each result dropped when the next one has arrived: the first "
-                                 "two fill fresh pages (first-touch page faults of a 0.9 GB numpy array), the later ones a block of the "
-                                 "library's host result pool that an earlier result has released (heracles_amd/_lib.py: _HostPool; HX_HOST_POOL_MB=0 turns it off)",
+            peak_at_clock = FP64_PEAK_TFLOPS * gemm_clock / 2.4 if gemm_clock else None  # 78.6 TFLOP/s is the datasheet figure at 2.4 GHz
+            mix = {"L": L, "seconds": mix_s, "seconds_all": mix_all, "seconds_min": min(mix_all), "seconds_max": max(mix_all),
+                   "statistic": "median of 5 builds into ONE page-locked out= buffer the caller owns", "gemm_ms": gms, "gemm_kernel_ms": gkms,
+                   "seconds_is": "hx.mixmat_eb(wl, out=pinned) host-visible result, five builds in a row into the same caller-owned page-locked array "
+                                 "(hx.pinned_empty): GPU work + DMA, no staging copy, no page faults, no library-side pool",
+                   "seconds_by_destination": {"device_tensor": t_dev, "pinned_out": mix_all, "pageable_out_reused": t_page, "fresh_numpy_default": t_fresh},
+                   "seconds_cold_first_build_fresh_numpy": cold,
+                   "seconds_by_destination_is": "the same build into a device tensor (GPU side alone), the pinned buffer (+ DMA), a pageable array the caller "
+                                                "re-uses (+ staging copy) and a fresh numpy array per build, the default (+ first-touch page faults; the first "
+                                                "one is also the first L = 6144 build of the process)",
+                   "gemm_clock_ghz": gemm_clock or None,
+                   "gemm_clock_is": "shader clock measured UNDER k_mixmat_gemm_dma (every 64th tile: s_memtime / s_memrealtime around its work) during the five timed builds",
+                   "gemm_frac_of_pipe_at_measured_clock": (xflop / (gkms * 1e-3) / 1e12 / peak_at_clock) if (gkms and peak_at_clock) else None,
                    "gemm_ms_is": "gemm_kernel_ms: the two launches of k_mixmat_gemm_dma; gemm_ms: the same with the two passes that form T diag(s) "
                                  "for them (k_scale_table: the k tiles go from HBM into LDS without passing through registers)",
                    "gemm_tflops_executed": xflop / (gkms * 1e-3) / 1e12 if gkms else None,
@@ -528,26 +663,54 @@ def main():
                                                  "upper triangle of tiles only, so this exceeds what the matrix pipe executes (gemm_tflops_executed) -- not a utilisation",
                    "checksum": float(np.abs(mm[2] - (mm[0] - mm[1])).max())}
         peaks = hx._lib.measure_peaks()
+        ncomp_set = sum(2 if s_ else 1 for s_ in per_set)
+        set_name = f"{nbins} bins x ({'2 spin-0 + 1 spin-2' if args.workload == 'euclid' else 'spin-0, spin-2'}) maps"
+        common = (f"nside={nside}, lmax={lmax}, niter=0, ring weights 1, pix_weights: synthetic file in healpy's format (its files are not "
+                  f"available offline); inputs resident in HBM")
+        weak = None
+        if world > 1:
+            # the job that grows with N: every rank brings one set of maps; pairs grow as N^2 while the transforms per GPU stay what they are,
+            # so its pairs/s is NOT a speed-up -- the per-GPU transform rate beside it is the weak-scaling figure proper
+            weak = {"value": value, "unit": "map->Cl pairs/s", "ms_per_step": ms_per_step, "steps": steps1, "maps_total": nmaps_total,
+                    "pairs": npairs, "maps_per_gpu": len(per_set), "transforms_per_gpu_per_s": len(per_set) * 1e3 / ms_per_step,
+                    "cl_vs_direct_sum": weak_check, "kernels_rank0": prof,
+                    "what": f"every rank brings its own {set_name} ({len(per_set)} maps): transforms, in-place all-gather of the alms in two parts, "
+                            f"tiled pair split over all {nmaps_total} maps; pairs = {nmaps_total} * {nmaps_total + 1} / 2"}
+        if world > 1 and args.scaling == "strong":
+            # `value`: the SAME job as at N = 1, the better of its two routes (both in "routes")
+            value, ms_per_step = strong.get("value"), strong.get("ms_per_step")
+            cfg_maps, cfg_pairs, cfg_mine = len(per_set), len(per_set) * (len(per_set) + 1) // 2, None
+            workload = (f"{set_name} in all = {len(per_set)} maps / {ncomp_set} components sharded over {world} GPU(s), {common}; "
+                        f"{cfg_pairs} auto+cross map pairs: the same job at every N")
+            par = {"m_sharded": f"sharded by the order m over {world} GPUs: ring modes all-to-all (RCCL), full-batch Legendre stage on m = rank mod {world}, Cl all-reduce",
+                   "all_gather": f"maps dealt to {world} GPUs by cost, RCCL all-gather of alms, tiled pair split",
+                   None: "both fixed-job routes failed"}[strong.get("route")]
+            prof_line = strong.get("kernels_rank0") or {}
+        else:
+            cfg_maps, cfg_pairs, cfg_mine = nmaps_total, npairs, len(mine)
+            workload = (f"{set_name} {'per GPU' if world > 1 else 'in all'} = {nmaps_total} maps / {sum(2 if s_ else 1 for s_ in spins)} components "
+                        f"over {world} GPU(s), {common}; {npairs} auto+cross map pairs")
+            par = f"maps dealt to {world} GPUs by cost, RCCL all-gather of alms, tiled pair split" if world > 1 else "1 GPU"
+            prof_line = prof
         out = {
             "metric": "map->Cl pairs/sec + mixing-matrix build sec, nside=%d lmax=%d" % (nside, lmax),
             "value": value, "unit": "map->Cl pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{nbins} bins x ({'2 spin-0 + 1 spin-2' if args.workload == 'euclid' else 'spin-0, spin-2'}) maps "
-                                   f"{'per GPU' if args.scaling == 'weak' else 'in all'} = "
-                                   f"{nmaps_total} maps / {sum(2 if s else 1 for s in spins)} components over {world} GPU(s), nside={nside}, lmax={lmax}, "
-                                   f"niter=0, ring weights 1, pix_weights: synthetic file in healpy's format (its files are not available offline); "
-                                   f"{npairs} auto+cross map pairs; inputs resident in HBM",
-                       "nside": nside, "lmax": lmax, "maps_total": nmaps_total, "maps_this_rank": len(mine), "pairs": npairs,
+            "config": {"workload": workload,
+                       "nside": nside, "lmax": lmax, "maps_total": cfg_maps, "maps_this_rank": cfg_mine, "pairs": cfg_pairs,
                        "pix_weights": ("synthetic array without symmetry (generic path)" if args.generic_weights else "synthetic weights in healpy's compressed format, expanded to the full sky (symmetric like healpy's)") + ", applied in the timed path",
-                       "parallelism": (f"maps dealt to {world} GPUs by cost, RCCL all-gather of alms, tiled pair split"
-                                       if world > 1 else "1 GPU")},
+                       "parallelism": par},
             "verified": (None if verify is None and verify_multi is None
-                         else bool((verify is None or verify.get("ok")) and (world == 1 or (verify_multi or {}).get("ok")))),
+                         else bool((verify is None or verify.get("ok")) and (world == 1 or (verify_multi or {}).get("ok"))
+                                   and (weak_check is None or weak_check["ok"]))),
             "verify": verify,
             "verify_multi": verify_multi,
-            "value_strong": strong.get("value") if strong else None,
+            "value_strong": strong.get("value") if strong else (value if world == 1 else None),
             "strong_scaling": strong,
+            "routes": routes,
+            "value_weak": weak["value"] if weak else None,
+            "weak_scaling": weak,
             "value_host_to_host": host_leg["value"] if host_leg else None,
             "host_to_host": host_leg,
             "single_map_transforms": single,
@@ -557,7 +720,7 @@ def main():
             "roofline_spin0_kernel": roofline_s0,
             "cpu_baseline": cpu,
             "measured_peaks": peaks,
-            "kernels": prof,
+            "kernels": prof_line,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

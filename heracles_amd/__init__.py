@@ -6,7 +6,7 @@ include/hxsht.h).  There is no CPU fallback.
 """
 
 from . import _lib
-from ._lib import HxError, device_count, init, synchronize
+from ._lib import HxError, device_count, init, pinned_empty, synchronize
 from .core import DeviceArray, Result, TocDict, toc_match, update_metadata
 from .discrete import HipDiscreteMapper, PointSHT, alm_resample, get_point_sht
 from .jackknife import RegionAlms, jackknife_cls, region_alms
@@ -22,6 +22,7 @@ from .twopoint import (
     angular_power_spectra,
     apply_mixing_matrix,
     debias_cls,
+    MixmatContext,
     invert_mixing_matrix,
     mixing_matrices,
     mixmat,
@@ -34,5 +35,5 @@ __all__ = [
     "alm2cl", "alm2cl_pairs", "alm2lmax", "angular_power_spectra", "debias_cls",
     "mixing_matrices", "mixmat", "mixmat_eb", "cl2corr", "corr2cl", "gauss_legendre",
     "wigner_d_table", "naturalspice", "Result", "TocDict", "toc_match", "update_metadata", "DeviceArray",
-    "jackknife_cls", "region_alms", "RegionAlms", "transform", "read_vmap", "apply_mixing_matrix", "invert_mixing_matrix",
+    "pinned_empty", "MixmatContext", "jackknife_cls", "region_alms", "RegionAlms", "transform", "read_vmap", "apply_mixing_matrix", "invert_mixing_matrix",
 ]

@@ -31,7 +31,7 @@ SYMBOLS = (
     "hx_mixmat_eb", "hx_mixmat_batch", "hx_mixctx_create", "hx_mixctx_apply", "hx_mixctx_destroy", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_reorder", "hx_matvec", "hx_pinv", "hx_alm_resample", "hx_region_maps", "hx_alm_subtract", "hx_fits_unpack_f64", "hx_fits_pack_f64",
     "hx_pointsht_create", "hx_pointsht_destroy", "hx_pointsht_info", "hx_pointsht_adjoint",
     "hx_pixel_weights_size", "hx_pixel_weights_expand",
-    "hx_ring_modes_size", "hx_ring_modes", "hx_legendre_from_modes",
+    "hx_ring_modes_size", "hx_ring_modes", "hx_legendre_from_modes", "hx_host_alloc", "hx_host_free", "hx_mixmat_gemm_clock",
 )
 
 
@@ -128,6 +128,9 @@ def load():
         L.hx_pixel_weights_size.argtypes = [i]
         L.hx_pixel_weights_size.restype = C.c_int64
         L.hx_pixel_weights_expand.argtypes = [i, C.c_int64, dp, dp]
+        L.hx_host_alloc.argtypes = [C.c_int64, C.POINTER(C.c_void_p)]
+        L.hx_host_free.argtypes = [vp]
+        L.hx_mixmat_gemm_clock.restype = C.c_double
         L.hx_timer_stop.argtypes = [C.POINTER(C.c_float)]
         L.hx_profile_get.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         _lib = L
@@ -253,77 +256,47 @@ def profile_get(name: str):
 
 
 # ---- host arrays of large results ------------------------------------------------------------------------------------
-# A mixing-matrix build at L = 6144 returns 0.9 GB; into a FRESH numpy array that costs 30-60 ms of first-touch page faults on top
-# of the 16 ms the bytes need over PCIe -- more than the GPU spends on the matrices (19 ms).  Large result arrays are therefore
-# taken from a small pool of blocks whose previous owner has let go of them (a finaliser on the array handed out; a block is only
-# recycled when nothing else refers to it, e.g. no slice of the old result is alive), at most HX_HOST_POOL_MB (default 2048; 0: off)
-# in all.  The first build of a process still pays for its pages; results that are kept (heracles.twopoint.mixing_matrices keeps
-# them all) are never recycled.
-class _HostPool:
-    MIN_BYTES = 64 << 20
+# A mixing-matrix build at L = 6144 returns 0.9 GB.  Into a FRESH numpy array (the default, as the reference's convolvecl call
+# returns one) that costs 30-100 ms of first-touch page faults on top of the 16 ms the bytes need over PCIe -- more than the GPU spends
+# on the matrices (19 ms).  A caller that builds many matrices in a loop and hands each one on (heracles.twopoint.mixing_matrices with
+# an `out` mapping that writes them away, heracles/twopoint.py:393-397) passes `out=` instead: an array it owns and re-uses -- any
+# C-contiguous float64 array of the right shape, or `pinned_empty(shape)`, page-locked memory the GPU reaches by DMA without the
+# staging copy.  Ownership is the caller's and visible to it; the library keeps no pool of released results (round 4's _HostPool
+# decided from reference counts whether a block could be handed out again: removed).
+def pinned_empty(shape, dtype=None):
+    """np.empty in page-locked host memory (hx_host_alloc); freed when the array and every view of it are gone."""
+    import weakref
 
-    def __init__(self):
-        import threading
-
-        self.cap = int(os.environ.get("HX_HOST_POOL_MB", "2048")) << 20
-        self.free = {}
-        self.held = 0
-        self.lock = threading.Lock()
-        # how many references a block has inside _give when nothing but the pool's own machinery refers to it (weakref.finalize's
-        # argument tuple, the frame, getrefcount's argument ...): measured once on a dummy block that goes the same way
-        self.base_refs = None
-        import weakref
-
-        import numpy as np
-
-        raw = np.empty(64, np.uint8)
-        view = raw.view(np.float64).reshape((2, 4))
-        weakref.finalize(view, self._give, raw)
-        del raw, view  # (the finaliser runs here: CPython frees the view at once)
-        if self.base_refs is None:  # (an interpreter that did not: never recycle)
-            self.base_refs = -1
-
-    def _give(self, raw):
-        import sys
-
-        if self.base_refs is None:
-            self.base_refs = sys.getrefcount(raw)
-            return
-        if sys.getrefcount(raw) > self.base_refs:
-            return  # a view of the old result is still alive somewhere: its memory is not ours to hand out
-        with self.lock:
-            if self.held + raw.nbytes <= self.cap:
-                self.free.setdefault(raw.nbytes, []).append(raw)
-                self.held += raw.nbytes
-
-    def empty(self, shape, dtype=None):
-        import weakref
-
-        import numpy as np
-
-        dtype = np.dtype(np.float64 if dtype is None else dtype)
-        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
-        if self.cap <= 0 or nbytes < self.MIN_BYTES:
-            return np.empty(shape, dtype)
-        raw = None
-        with self.lock:
-            lst = self.free.get(nbytes)
-            if lst:
-                raw = lst.pop()
-                self.held -= nbytes
-        if raw is None:
-            raw = np.empty(nbytes, np.uint8)
-        out = raw.view(dtype).reshape(shape)
-        weakref.finalize(out, self._give, raw)
-        return out
+    dtype = np.dtype(np.float64 if dtype is None else dtype)
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if nbytes == 0:
+        return np.empty(shape, dtype)
+    ensure_init()
+    L = load()
+    p = C.c_void_p()
+    check(L.hx_host_alloc(C.c_int64(nbytes), C.byref(p)))
+    raw = (C.c_char * nbytes).from_address(p.value)
+    weakref.finalize(raw, L.hx_host_free, C.c_void_p(p.value))  # (numpy keeps `raw` alive as the base of every view)
+    return np.frombuffer(raw, dtype=dtype).reshape(shape)
 
 
-_host_pool = None
+def result_array(shape, out=None):
+    """The destination of a result: a fresh numpy array, or the caller's `out` (numpy array or anything with data_ptr / shape --
+    a torch tensor, host or device -- of that shape, float64, C-contiguous), which is then what the call returns."""
+    shape = tuple(int(x) for x in shape)
+    if out is None:
+        return np.empty(shape)
+    if tuple(out.shape) != shape:
+        raise ValueError(f"out has shape {tuple(out.shape)}, the result has {shape}")
+    if isinstance(out, np.ndarray):
+        if out.dtype != np.float64 or not out.flags.c_contiguous or not out.flags.writeable:
+            raise ValueError("out must be a writeable C-contiguous float64 array")
+    elif hasattr(out, "data_ptr"):
+        import torch
 
-
-def host_empty(shape, dtype=None):
-    """np.empty for a large result the library is about to fill (see _HostPool)."""
-    global _host_pool
-    if _host_pool is None:
-        _host_pool = _HostPool()
-    return _host_pool.empty(shape, dtype)
+        if out.dtype != torch.float64 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float64 tensor")
+    else:
+        raise TypeError(f"out: cannot write into {type(out)!r}")
+    return out

@@ -43,6 +43,7 @@ struct Runtime {
     bool async = false;
     bool profiling = false;
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipEvent_t order_ev = nullptr;  // library stream -> copy stream dependency (hx_mixmat.hip); recreated by hx_init on another device
     struct Prof {
         int launches = 0;
         double ms = 0.0;

@@ -286,6 +286,9 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
 {
     return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void *)p;
 }
+// Shader clock UNDER this kernel: every 64th tile adds its (shader ticks, 100 MHz ticks) from first load to last store; hx_mixmat_gemm_clock
+// reads and clears the sums (two scalar clock reads and two atomics per sampled tile: 1225 tiles -> ~20 samples per product)
+__device__ unsigned long long g_gemm_clk[2];
 template <bool SYM>
 __global__ __launch_bounds__(256, 2) void k_mixmat_gemm_dma(const double *__restrict__ Ts, const double *__restrict__ T2, int kpad,
                                                             const int2 *__restrict__ tiles, int n1, int n2,
@@ -306,6 +309,9 @@ __global__ __launch_bounds__(256, 2) void k_mixmat_gemm_dma(const double *__rest
     const unsigned long long t_begin = __builtin_readcyclecounter();
     const unsigned long long r_begin = wall_clock64();
 #endif
+    const bool sample_clk = (blockIdx.x & 63) == 33;
+    unsigned long long clk_t0 = 0, clk_r0 = 0;
+    if (sample_clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // (a scalar: the LDS destinations of a wave's loads go through M0)
     const int wr = w >> 1, wc = w & 1;
@@ -404,6 +410,10 @@ __global__ __launch_bounds__(256, 2) void k_mixmat_gemm_dma(const double *__rest
                 if (gi < n1 && gj < n2) G[(long long)gi * ldg + gj] = colscale ? v * colscale[gj] : v;
                 if (SYM && bi != bj && gj < n1 && gi < n2) G[(long long)gj * ldg + gi] = v * colscale[gi];
             }
+    if (sample_clk && threadIdx.x == 0) {
+        atomicAdd(&g_gemm_clk[0], (unsigned long long)__builtin_amdgcn_s_memtime() - clk_t0);
+        atomicAdd(&g_gemm_clk[1], (unsigned long long)__builtin_amdgcn_s_memrealtime() - clk_r0);
+    }
 #ifdef HX_GEMM_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
         unsigned xcc, hwid;
@@ -672,6 +682,35 @@ static int stage_cl(const double *cl, int ncl, int l3max, DevBuf &buf)
     return HX_OK;
 }
 
+// The three spin-2 x spin-2 matrices of one mask (context c, node weights set) into vo = [3][n1][n2].
+// b = G^{(2,-2)} first: it IS the third matrix, so a host destination receives it (second stream, ~5 ms at L = 6144) while the
+// product a = G^{(2,2)} is computed; then [0] = (a + b) / 2, [1] = (a - b) / 2.  Complete on return for a host destination.
+static int mix_eb_into(MixCtx &c, OutView &vo)
+{
+    const size_t sz = (size_t)(c.l1max + 1) * (c.l2max + 1);
+    double *o0 = vo.as<double>(), *o1 = o0 + sz, *o2 = o0 + 2 * sz;
+    hipStream_t st = rt().stream;
+    HX_TRY(mix_ctx_product(c, 3, o2));
+    HX_TRY(mix_ctx_table(c, 2));
+    hipStream_t cs = vo.host ? copy_stream() : nullptr;
+    if (cs) {
+        Runtime &r = rt();
+        if (!r.order_ev) HX_HIP(hipEventCreateWithFlags(&r.order_ev, hipEventDisableTiming));
+        HX_HIP(hipEventRecord(r.order_ev, st));
+        HX_HIP(hipStreamWaitEvent(cs, r.order_ev, 0));
+    }
+    HX_TRY(mix_ctx_product(c, 2, o0));
+    if (cs) HX_TRY(copy_d2h((double *)vo.host + 2 * sz, o2, sizeof(double) * sz, cs));  // (complete on return; the product above runs meanwhile)
+    hipLaunchKernelGGL(k_eb_combine, dim3(1024), dim3(256), 0, st, (long long)sz, o0, o1, o2);
+    HX_HIP(hipGetLastError());
+    if (cs) {
+        HX_TRY(copy_d2h(vo.host, o0, sizeof(double) * 2 * sz));
+    } else {
+        HX_TRY(vo.finish());
+    }
+    return HX_OK;
+}
+
 }  // namespace hx
 
 using namespace hx;
@@ -754,33 +793,25 @@ extern "C" int hx_mixmat_eb(const double *cl, int ncl, int l1max, int l2max, int
     HX_TRY(stage_cl(cl, ncl, l3max, d_cl));
     OutView vo;
     HX_TRY(vo.bind(out, sizeof(double) * 3 * sz));
-    double *o0 = vo.as<double>(), *o1 = o0 + sz, *o2 = o0 + 2 * sz;
-    hipStream_t st = rt().stream;
     MixCtx c;
     HX_TRY(mix_ctx_init(c, l1max, l2max, l3max));
     HX_TRY(mix_ctx_mask(c, d_cl.as<double>()));
-    // b = G^{(2,-2)} first: it IS the third matrix, so a host destination receives it (second stream, ~5 ms at L = 6144) while the
-    // product a = G^{(2,2)} is computed; then [0] = (a + b) / 2, [1] = (a - b) / 2
-    HX_TRY(mix_ctx_product(c, 3, o2));
-    HX_TRY(mix_ctx_table(c, 2));
-    hipStream_t cs = vo.host ? copy_stream() : nullptr;
-    if (cs) {
-        static hipEvent_t ev = nullptr;
-        if (!ev) HX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HX_HIP(hipEventRecord(ev, st));
-        HX_HIP(hipStreamWaitEvent(cs, ev, 0));
-    }
-    HX_TRY(mix_ctx_product(c, 2, o0));
-    if (cs) HX_TRY(copy_d2h((double *)vo.host + 2 * sz, o2, sizeof(double) * sz, cs));  // (complete on return; the product above runs meanwhile)
-    hipLaunchKernelGGL(k_eb_combine, dim3(1024), dim3(256), 0, st, (long long)sz, o0, o1, o2);
-    HX_HIP(hipGetLastError());
-    if (cs) {
-        HX_TRY(copy_d2h(vo.host, o0, sizeof(double) * 2 * sz));
-    } else {
-        HX_TRY(vo.finish());
-    }
-    HX_HIP(hipStreamSynchronize(st));  // the context (tables, weights) dies with this scope
+    HX_TRY(mix_eb_into(c, vo));
+    HX_HIP(hipStreamSynchronize(rt().stream));  // the context (tables, weights) dies with this scope
     return HX_OK;
+}
+
+// Shader clock in GHz under k_mixmat_gemm_dma since the last call (sampled tiles: shader ticks / 100 MHz ticks); 0 if none ran.
+extern "C" double hx_mixmat_gemm_clock(void)
+{
+    if (ensure_ready() != HX_OK) return 0.0;
+    unsigned long long h[2] = {0, 0}, z[2] = {0, 0};
+    if (hipStreamSynchronize(rt().stream) != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_clk), sizeof(h)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_clk), z, sizeof(z)) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0.0;
+    }
+    return h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
 }
 
 // y[v][i] = sum_j M[i][j] x[v][j]: the products of heracles.twopoint.apply_mixing_matrix (heracles/twopoint.py:497-524: `_M @ cl` per
@@ -870,12 +901,7 @@ extern "C" int hx_mixmat_batch(int nmask, const double *cls, int ncl, int l1max,
         if (kinds[k] & 4) {
             OutView vo;
             HX_TRY(vo.bind(outeb[k], sizeof(double) * 3 * sz));
-            HX_TRY(mix_ctx_product(c, 2, vo.as<double>()));
-            HX_TRY(mix_ctx_product(c, 3, vo.as<double>() + 2 * sz));
-            hipLaunchKernelGGL(k_eb_combine, dim3(1024), dim3(256), 0, rt().stream, (long long)sz, vo.as<double>(),
-                               vo.as<double>() + sz, vo.as<double>() + 2 * sz);
-            HX_HIP(hipGetLastError());
-            HX_TRY(vo.finish());
+            HX_TRY(mix_eb_into(c, vo));
             HX_HIP(hipStreamSynchronize(rt().stream));
         }
     }
@@ -924,14 +950,11 @@ extern "C" int hx_mixctx_apply(hx_mixctx *x, const double *cl, int ncl, int kind
     OutView vo;
     HX_TRY(vo.bind(out, sizeof(double) * sz * (kind == 4 ? 3 : 1)));
     if (kind == 4) {
-        HX_TRY(mix_ctx_product(c, 2, vo.as<double>()));
-        HX_TRY(mix_ctx_product(c, 3, vo.as<double>() + 2 * sz));
-        hipLaunchKernelGGL(k_eb_combine, dim3(1024), dim3(256), 0, rt().stream, (long long)sz, vo.as<double>(),
-                           vo.as<double>() + sz, vo.as<double>() + 2 * sz);
-        HX_HIP(hipGetLastError());
-    } else
+        HX_TRY(mix_eb_into(c, vo));
+    } else {
         HX_TRY(mix_ctx_product(c, kind == 1 ? 0 : 1, vo.as<double>()));
-    HX_TRY(vo.finish());
+        HX_TRY(vo.finish());
+    }
     HX_HIP(hipStreamSynchronize(rt().stream));
     return HX_OK;
 }

@@ -471,6 +471,8 @@ int hx_init(int device)
         // re-initialisation on another device: the second (copy) stream and the stager's events were created on the old one
         if (r.copy) (void)hipStreamDestroy(r.copy);
         r.copy = nullptr;
+        if (r.order_ev) (void)hipEventDestroy(r.order_ev);
+        r.order_ev = nullptr;
         stager_reset_events();
     }
     HX_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
@@ -519,6 +521,30 @@ int hx_copy(void *dst, const void *src, int64_t bytes)
         return HX_OK;
     }
     HX_HIP(hipStreamSynchronize(rt().stream));
+    return HX_OK;
+}
+
+int hx_host_alloc(int64_t bytes, void **out)
+{
+    HX_TRY(ensure_ready());
+    if (bytes <= 0 || !out) return fail(HX_ERR_ARG, "hx_host_alloc: bad arguments");
+    *out = nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(HX_ERR_MEM, "hx_host_alloc: %lld bytes of page-locked host memory not available", (long long)bytes);
+    }
+    *out = p;
+    return HX_OK;
+}
+
+int hx_host_free(void *p)
+{
+    if (!p) return HX_OK;
+    if (hipHostFree(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(HX_ERR_ARG, "hx_host_free: not a pointer of hx_host_alloc");
+    }
     return HX_OK;
 }
 

@@ -35,8 +35,14 @@ __global__ __launch_bounds__(CL_TW * 64) void k_alm2cl_rows(
     const ClTile *__restrict__ tiles, int ntiles, int ngroups, int nmsplit, int lmax_out, int nlblk, double *__restrict__ part, long long part_stride,
     int m_lo, int m_hi, int m_step)
 {
-    // heavy (high-l) blocks first; consecutive work-groups = the shares of one (l-block, tile group)
-    const int ms = blockIdx.x % nmsplit, g = (blockIdx.x / nmsplit) % ngroups, lblk = nlblk - 1 - (int)(blockIdx.x / (nmsplit * ngroups));
+    // heavy (high-l) blocks first.  Work-groups go to the 8 XCDs round-robin (blockIdx % 8): the tile groups of one (l-block, share of
+    // the orders) read the same rows of the same components, so they are given block indices 8 apart -- the same XCD, dispatched
+    // together -- and find each other's rows in that XCD's L2 (round 5; before, they sat nmsplit apart on different XCDs and every
+    // group fetched its rows from HBM: 2 x the alms for the bench's 15 tiles)
+    const int nq = nlblk * nmsplit;
+    const int q = ((int)blockIdx.x / (8 * ngroups)) * 8 + ((int)blockIdx.x & 7), g = ((int)blockIdx.x >> 3) % ngroups;
+    if (q >= nq) return;
+    const int ms = q % nmsplit, lblk = nlblk - 1 - q / nmsplit;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int ti = g * CL_TW + w;
     const bool have = ti < ntiles;
@@ -146,7 +152,12 @@ extern "C" int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double 
     std::map<std::pair<int, int>, int> tile_of;
     std::vector<ClTile> tiles;
     for (int p = 0; p < npairs; ++p) {
-        int bi = pair_i[p] / CL_T, bj = pair_j[p] / CL_T;
+        // Cl(a, b) = Cl(b, a) term by term (the products commute: bit-identical), so a pair is filed under the tile with block(i) <=
+        // block(j) whichever way it was given: a buffer that holds its spin-2 components in front of its spin-0 ones (distributed.py
+        // since round 4) hands the spin-0 x spin-2 pairs over as (high, low) and would otherwise open 19 tiles instead of 15
+        int ci = pair_i[p], cj = pair_j[p];
+        if (ci / CL_T > cj / CL_T) std::swap(ci, cj);
+        int bi = ci / CL_T, bj = cj / CL_T;
         auto key = std::make_pair(bi, bj);
         auto it = tile_of.find(key);
         if (it == tile_of.end()) {
@@ -158,7 +169,7 @@ extern "C" int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double 
             it = tile_of.emplace(key, (int)tiles.size() - 1).first;
         }
         ClTile &t = tiles[it->second];
-        int slot = (pair_i[p] - t.i0) * CL_T + (pair_j[p] - t.j0);
+        int slot = (ci - t.i0) * CL_T + (cj - t.j0);
         if (t.out[slot] >= 0) {
             // duplicate pair in the list: give it its own tile so each output is written
             ClTile d;
@@ -193,7 +204,7 @@ extern "C" int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double 
     HX_HIP(hipMemsetAsync(d_part.p, 0, sizeof(double) * (size_t)nout * nmsplit, st));  // (shares without orders write nothing)
     {
         ProfScope ps("alm2cl");
-        hipLaunchKernelGGL(k_alm2cl_rows, dim3((unsigned)(nlblk * ngroups * nmsplit)), dim3(CL_TW * 64), 0, st,
+        hipLaunchKernelGGL(k_alm2cl_rows, dim3((unsigned)((nlblk * nmsplit + 7) / 8 * 8 * ngroups)), dim3(CL_TW * 64), 0, st,
                            d_ptrs.as<const double2 *>(), d_lmax.as<int>(), ncomp, d_tiles.as<ClTile>(), (int)tiles.size(), ngroups, nmsplit,
                            lmax_out, nlblk, d_part.as<double>(), nout, m0, m1, mstep);
         hipLaunchKernelGGL(k_alm2cl_finish, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, d_part.as<double>(), nout, nmsplit, nout,

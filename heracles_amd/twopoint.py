@@ -280,24 +280,27 @@ def _mm_args(cl, l1max, l2max, l3max):
     return cl, int(l1max), int(l2max), int(l3max)
 
 
-def mixmat(cl, l1max=None, l2max=None, l3max=None, spin=(0, 0)):
+def mixmat(cl, l1max=None, l2max=None, l3max=None, spin=(0, 0), out=None):
     """Mixing matrix of a mask spectrum for spins (0,0), (0,2) or (2,0); replaces
     ``convolvecl.mixmat`` as called at heracles/twopoint.py:382-388.  Shape (l1max+1, l2max+1),
-    axis 0 is the output multipole."""
+    axis 0 is the output multipole.  ``out``: an array the caller owns and re-uses (float64, that shape, C-contiguous; numpy --
+    pageable or ``heracles_amd.pinned_empty`` -- or a torch tensor, host or device), filled and returned instead of a fresh one."""
     cl, l1max, l2max, l3max = _mm_args(cl, l1max, l2max, l3max)
     s1, s2 = spin
-    out = _lib.host_empty((l1max + 1, l2max + 1))
+    out = _lib.result_array((l1max + 1, l2max + 1), out)
     _lib.ensure_init()
     _lib.check(_lib.load().hx_mixmat(_lib.ptr(cl), cl.shape[0], l1max, l2max, l3max, int(s1), int(s2), _lib.ptr(out)))
     return out
 
 
-def mixmat_eb(cl, l1max=None, l2max=None, l3max=None, spin=(2, 2)):
-    """E/B mixing matrices (EE->EE, EE->BB, EB->EB); replaces ``convolvecl.mixmat_eb``."""
+def mixmat_eb(cl, l1max=None, l2max=None, l3max=None, spin=(2, 2), out=None):
+    """E/B mixing matrices (EE->EE, EE->BB, EB->EB); replaces ``convolvecl.mixmat_eb``.  ``out`` as in ``mixmat``, shape
+    (3, l1max+1, l2max+1): a build into a fresh numpy array pays the first touch of its pages (0.9 GB at L = 6144: more than the GPU
+    spends on the matrices); a loop that hands every result on passes the same ``out`` each time."""
     cl, l1max, l2max, l3max = _mm_args(cl, l1max, l2max, l3max)
     if tuple(abs(s) for s in spin) != (2, 2):
         raise NotImplementedError(f"mixmat_eb for spin {spin} not supported")
-    out = _lib.host_empty((3, l1max + 1, l2max + 1))
+    out = _lib.result_array((3, l1max + 1, l2max + 1), out)
     _lib.ensure_init()
     _lib.check(_lib.load().hx_mixmat_eb(_lib.ptr(cl), cl.shape[0], l1max, l2max, l3max, _lib.ptr(out)))
     return out
@@ -348,7 +351,21 @@ class MixmatContext:
         if not self._h:
             raise _lib.HxError(-1, _lib.load().hx_last_error().decode(errors="replace"))
 
-    def __call__(self, cl, spin):
+    def result_buffer(self, spin=(2, 2)):
+        """A page-locked host array of the shape ``self(cl, spin)`` returns, owned by this context (one per shape, freed with it):
+        pass it as ``out=`` for every matrix of a loop that consumes each result before the next build -- the GPU writes it by DMA,
+        no staging copy, no page faults.  The NEXT call with the same ``out`` overwrites it."""
+        s1, s2 = (abs(int(v)) for v in spin)
+        shape = (self.l1max + 1, self.l2max + 1)
+        if (s1, s2) == (2, 2):
+            shape = (3,) + shape
+        if not hasattr(self, "_buffers"):
+            self._buffers = {}
+        if shape not in self._buffers:
+            self._buffers[shape] = _lib.pinned_empty(shape)
+        return self._buffers[shape]
+
+    def __call__(self, cl, spin, out=None):
         s1, s2 = (abs(int(v)) for v in spin)
         if (s1, s2) == (0, 0):
             kind = 1
@@ -360,7 +377,7 @@ class MixmatContext:
             raise NotImplementedError(f"mixing matrix for spin {tuple(spin)} not supported")
         cl = np.ascontiguousarray(np.asarray(cl, dtype=np.float64))
         shape = (self.l1max + 1, self.l2max + 1)
-        out = _lib.host_empty((3,) + shape if kind == 4 else shape)
+        out = _lib.result_array((3,) + shape if kind == 4 else shape, out)
         _lib.check(_lib.load().hx_mixctx_apply(self._h, _lib.ptr(cl), cl.shape[0], kind, _lib.ptr(out)))
         return out
 
@@ -368,6 +385,7 @@ class MixmatContext:
         if getattr(self, "_h", None):
             _lib.load().hx_mixctx_destroy(self._h)
             self._h = None
+        self._buffers = {}  # (pinned arrays free themselves when their last view goes)
 
     def __enter__(self):
         return self

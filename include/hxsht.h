@@ -49,6 +49,12 @@ int hx_synchronize(void);
 /* dst <- src (bytes), either side host or device memory; host <-> device through the library's pinned staging pipeline (~55 GB/s
  * from / to pageable memory).  Complete on return. */
 int hx_copy(void *dst, const void *src, int64_t bytes);
+/* Page-locked host memory the CALLER owns: a destination (or source) of this kind is reached by DMA directly, without the staging
+ * copy and without first-touch page faults -- the buffer a caller keeps and passes again as `out` of hx_mixmat_eb / hx_mixctx_apply
+ * for every matrix of a loop (the reference hands each result to its `out` mapping and drops it, heracles/twopoint.py:393-397).
+ * hx_host_free(NULL) is a no-op.  The memory stays valid until freed, across hx_init calls. */
+int hx_host_alloc(int64_t bytes, void **out);
+int hx_host_free(void *p);
 
 /* HIP-event timers on the library stream (bench.py's timed region / roofline). */
 int hx_timer_start(void);
@@ -82,6 +88,9 @@ int hx_plan_last_chunks(const hx_plan *plan);
 int hx_measure_peaks(double *out4);
 /* Shader clock in GHz held during the FP64 MFMA probe of the last hx_measure_peaks call (0 before any). */
 double hx_measured_mfma_clock(void);
+/* Shader clock in GHz held UNDER the mixing-matrix GEMM since the last call of this function (every 64th tile samples s_memtime /
+ * s_memrealtime around its work); 0 when no such tile has run.  Measurement aid for bench.py's gemm_frac_of_fp64_mfma_peak. */
+double hx_mixmat_gemm_clock(void);
 /* Measurement aid (bench.py's roofline): matrix-instruction flops one hx_map2alm(niter = 0) of
  * ncomp components EXECUTES (task list x MFMAs per wave-block), as opposed to the algorithmic
  * 8 * 2 nside * nlm per component the roofline is quoted on.                              */

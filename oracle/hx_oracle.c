@@ -974,15 +974,18 @@ int hxo_wigner3j_l3(int l1, int l2, int m1, int m2, double *out, int *n_out)
     return jmin;
 }
 
-void hxo_mixmat(const double *cl, int l1max, int l2max, int l3max, int s1, int s2, double *out)
+/* Any rectangular block l1lo..l1hi x l2lo..l2hi of the matrix: the recursion runs over l3 per (l1, l2), so a block
+ * anywhere costs what the low corner costs.  out[(l1hi-l1lo+1)*(l2hi-l2lo+1)], row-major [l1-l1lo][l2-l2lo]. */
+void hxo_mixmat_block(const double *cl, int l1lo, int l1hi, int l2lo, int l2hi, int l3max, int s1, int s2, double *out)
 {
+    int nc = l2hi - l2lo + 1;
 #pragma omp parallel
     {
-        double *wa = malloc(sizeof(double) * (l1max + l2max + 2));
-        double *wb = malloc(sizeof(double) * (l1max + l2max + 2));
+        double *wa = malloc(sizeof(double) * (l1hi + l2hi + 2));
+        double *wb = malloc(sizeof(double) * (l1hi + l2hi + 2));
 #pragma omp for schedule(dynamic, 1)
-        for (int l1 = 0; l1 <= l1max; ++l1)
-            for (int l2 = 0; l2 <= l2max; ++l2) {
+        for (int l1 = l1lo; l1 <= l1hi; ++l1)
+            for (int l2 = l2lo; l2 <= l2hi; ++l2) {
                 double s = 0.0;
                 int na, nb;
                 if (l1 >= abs(s1) && l2 >= abs(s1) && l1 >= abs(s2) && l2 >= abs(s2)) {
@@ -993,21 +996,28 @@ void hxo_mixmat(const double *cl, int l1max, int l2max, int l3max, int s1, int s
                         s += (2.0 * l3 + 1.0) * cl[l3] * wa[l3 - ja] * wb[l3 - jb];
                     }
                 }
-                out[(int64_t)l1 * (l2max + 1) + l2] = (2.0 * l2 + 1.0) / (4.0 * M_PI) * s;
+                out[(int64_t)(l1 - l1lo) * nc + (l2 - l2lo)] = (2.0 * l2 + 1.0) / (4.0 * M_PI) * s;
             }
         free(wa); free(wb);
     }
 }
 
-void hxo_mixmat_eb(const double *cl, int l1max, int l2max, int l3max, double *out)
+void hxo_mixmat(const double *cl, int l1max, int l2max, int l3max, int s1, int s2, double *out)
 {
-    int64_t sz = (int64_t)(l1max + 1) * (l2max + 1);
+    hxo_mixmat_block(cl, 0, l1max, 0, l2max, l3max, s1, s2, out);
+}
+
+/* the same for the three spin-2 x spin-2 matrices: out[3][rows][cols] */
+void hxo_mixmat_eb_block(const double *cl, int l1lo, int l1hi, int l2lo, int l2hi, int l3max, double *out)
+{
+    int nc = l2hi - l2lo + 1;
+    int64_t sz = (int64_t)(l1hi - l1lo + 1) * nc;
 #pragma omp parallel
     {
-        double *wa = malloc(sizeof(double) * (l1max + l2max + 2));
+        double *wa = malloc(sizeof(double) * (l1hi + l2hi + 2));
 #pragma omp for schedule(dynamic, 1)
-        for (int l1 = 0; l1 <= l1max; ++l1)
-            for (int l2 = 0; l2 <= l2max; ++l2) {
+        for (int l1 = l1lo; l1 <= l1hi; ++l1)
+            for (int l2 = l2lo; l2 <= l2hi; ++l2) {
                 double se = 0.0, so = 0.0;
                 int na;
                 if (l1 >= 2 && l2 >= 2) {
@@ -1018,11 +1028,16 @@ void hxo_mixmat_eb(const double *cl, int l1max, int l2max, int l3max, double *ou
                     }
                 }
                 double f = (2.0 * l2 + 1.0) / (4.0 * M_PI);
-                int64_t k = (int64_t)l1 * (l2max + 1) + l2;
+                int64_t k = (int64_t)(l1 - l1lo) * nc + (l2 - l2lo);
                 out[k] = f * se;
                 out[sz + k] = f * so;
                 out[2 * sz + k] = f * (se - so);
             }
         free(wa);
     }
+}
+
+void hxo_mixmat_eb(const double *cl, int l1max, int l2max, int l3max, double *out)
+{
+    hxo_mixmat_eb_block(cl, 0, l1max, 0, l2max, l3max, out);
 }

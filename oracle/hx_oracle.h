@@ -78,6 +78,10 @@ int hxo_wigner3j_l3(int l1, int l2, int m1, int m2, double *out, int *n_out);
 void hxo_mixmat(const double *cl, int l1max, int l2max, int l3max, int s1, int s2, double *out);
 /* three matrices: [0] EE->EE, [1] EE->BB, [2] EB->EB */
 void hxo_mixmat_eb(const double *cl, int l1max, int l2max, int l3max, double *out);
+/* an arbitrary block l1lo..l1hi x l2lo..l2hi of the same matrices (the 3j recursion runs over l3 per (l1, l2):
+ * a block at l ~ 6000 costs what the low corner costs); out row-major [l1 - l1lo][l2 - l2lo], _eb: [3][rows][cols] */
+void hxo_mixmat_block(const double *cl, int l1lo, int l1hi, int l2lo, int l2hi, int l3max, int s1, int s2, double *out);
+void hxo_mixmat_eb_block(const double *cl, int l1lo, int l1hi, int l2lo, int l2hi, int l3max, double *out);
 
 /* the two stages of hxo_map2alm on their own: F[comp][ring][m] (4 nside - 1 rings, m <= lmax), alm from a given F */
 int hxo_fourier_analysis(int nside, int lmax, int ncomp, const double *maps, const double *pix_weights, double _Complex *F);

@@ -257,6 +257,32 @@ def mixmat_eb(cl, l1max=None, l2max=None, l3max=None, spin=(2, 2)):
     return out
 
 
+def mixmat_block(cl, rows, cols, l3max=None, spin=(0, 0)):
+    """Block rows = (l1lo, l1hi), cols = (l2lo, l2hi) (inclusive) of ``mixmat(cl, l3max=l3max, spin=spin)``."""
+    cl = np.ascontiguousarray(cl, dtype=np.float64)
+    if l3max is None:
+        l3max = cl.shape[-1] - 1
+    if cl.shape[-1] < l3max + 1:
+        cl = np.concatenate([cl, np.zeros(l3max + 1 - cl.shape[-1])])
+    out = np.empty((rows[1] - rows[0] + 1, cols[1] - cols[0] + 1))
+    lib().hxo_mixmat_block(_p(cl), C.c_int(rows[0]), C.c_int(rows[1]), C.c_int(cols[0]), C.c_int(cols[1]),
+                           C.c_int(l3max), C.c_int(spin[0]), C.c_int(spin[1]), _p(out))
+    return out
+
+
+def mixmat_eb_block(cl, rows, cols, l3max=None):
+    """The same block of the three matrices of ``mixmat_eb``: shape (3, rows, cols)."""
+    cl = np.ascontiguousarray(cl, dtype=np.float64)
+    if l3max is None:
+        l3max = cl.shape[-1] - 1
+    if cl.shape[-1] < l3max + 1:
+        cl = np.concatenate([cl, np.zeros(l3max + 1 - cl.shape[-1])])
+    out = np.empty((3, rows[1] - rows[0] + 1, cols[1] - cols[0] + 1))
+    lib().hxo_mixmat_eb_block(_p(cl), C.c_int(rows[0]), C.c_int(rows[1]), C.c_int(cols[0]), C.c_int(cols[1]),
+                              C.c_int(l3max), _p(out))
+    return out
+
+
 # ---- catalogue -> map accumulation (numpy restatement) -------------------------------
 def ang2pix_ring(nside, lon, lat):
     """hp.ang2pix(nside, lon, lat, lonlat=True) as called at heracles/healpy.py:157.

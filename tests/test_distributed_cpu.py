@@ -325,3 +325,52 @@ def test_order_sets_cover_and_balance():
     owner = assign_maps_by_components(spins, 8)
     loads = [sum((2 if spins[g] else 1) for g in range(20) if owner[g] == r) for r in range(8)]
     assert sum(loads) == 30 and max(loads) - min(loads) <= 1, loads
+
+
+def test_bench_job_is_the_same_at_every_n():
+    """bench.py's `value` is quoted on ONE job at every N: the pair count of both fixed-job routes does not depend on
+    the number of ranks, and equals the N = 1 job's."""
+    import importlib.util
+
+    from heracles_amd.distributed import MShardedTwoPoint, ShardedTwoPoint
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)                      # (imports neither torch nor the library at module level)
+    assert "torch" not in bench.__dict__
+    per_set = bench.fixed_job("north_star", 10)
+    assert per_set == [0] * 10 + [2] * 10
+    lmax = 6144
+    nlm = (lmax + 1) * (lmax + 2) // 2
+    one = ShardedTwoPoint(per_set, 1, 0, nlm, lmax, kernel=lambda *a: None)
+    assert len(one.pairs) == 210
+    for world in (2, 4, 8):
+        for rank in (0, world - 1):
+            ag = ShardedTwoPoint(per_set, world, rank, nlm, lmax, kernel=lambda *a: None)
+            ms = MShardedTwoPoint(per_set, world, rank, nlm, lmax, stages=None, kernel=lambda *a: None)
+            assert len(ag.pairs) == len(ms.pairs) == len(one.pairs) == 210
+            assert ag.nrows == ms.nrows == one.nrows
+        # every pair is some rank's, exactly once
+        ag = ShardedTwoPoint(per_set, world, 0, nlm, lmax, kernel=lambda *a: None)
+        assert sorted(p for ps in ag.pairs_of for p in ps) == sorted(one.pairs)
+    assert len(bench.fixed_job("euclid", 10)) == 39
+
+
+def test_bench_self_launch_starts_n_ranks_and_propagates_failure():
+    """`python3 bench.py --gpus N` without a launcher starts N children with the rendezvous variables (no GPU involved with
+    --launch-check), prints ONE line, and exits non-zero when any rank does."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--launch-check"], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-1000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 4 and json.loads(lines[0])["master"].startswith("127.0.0.1:")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--launch-check"], env=dict(env, HX_LAUNCH_CHECK_FAIL="2"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 3

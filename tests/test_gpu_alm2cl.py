@@ -136,3 +136,26 @@ def test_m_range_partial_sums_add_up(oracle):
     # strided sets (the orders of rank q of 3: q, q + 3, ...) add up as well
     strided = [hx.alm2cl_pairs(comps, pairs, lmax, m_range=(q, lmax + 1, 3)) for q in range(3)]
     np.testing.assert_allclose(sum(strided), full, rtol=1e-13, atol=1e-15)
+
+
+def test_pairs_in_either_orientation_and_duplicates(oracle):
+    """A pair list that names component pairs as (high, low), (low, high), on the diagonal blocks both ways, and some twice -- the
+    order a buffer with its spin-2 components in front of its spin-0 ones produces (heracles_amd.distributed): every row is the
+    spectrum of ITS pair, and (a, b) equals (b, a) bit for bit."""
+    import heracles_amd as hx
+
+    lmax, ncomp = 90, 17
+    rng = np.random.default_rng(23)
+    alms = [random_alm(rng, lmax) for _ in range(ncomp)]
+    pairs = [(a, b) for a in range(ncomp) for b in range(ncomp) if (a * 7 + b * 3) % 4 != 1]
+    pairs += [(16, 0), (0, 16), (16, 0), (5, 5), (5, 5), (11, 2)]
+    out = hx.alm2cl_pairs(alms, pairs, lmax)
+    assert out.shape == (len(pairs), lmax + 1)
+    first = {}
+    for k, (a, b) in enumerate(pairs):
+        key = (min(a, b), max(a, b))
+        if key in first:
+            np.testing.assert_array_equal(out[k], out[first[key]])
+        else:
+            first[key] = k
+            np.testing.assert_allclose(out[k], oracle.alm2cl(alms[a], alms[b]), rtol=RTOL, atol=1e-14)

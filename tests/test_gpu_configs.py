@@ -5,7 +5,9 @@
   1  1 spin-0 + 1 spin-2 map, nside 1024, lmax 2048: auto + cross Cl          (oracle in full)
   2  10 bins x (spin 0, spin 2), nside 2048, lmax 3072: one bin here, oracle on every 96th m;
      the all-pairs sharding over ranks is covered on CPU (tests/test_distributed_cpu.py)
-  3  mixing matrix at lmax 4096: identities that hold at any size + the oracle on a corner
+  3  mixing matrix at lmax 4096: identities that hold at any size + the 3j oracle on blocks anywhere in the matrices
+     (low corner here; high-l corner, mid-diagonal and off-diagonal strips, all spins: tests/test_gpu_mixmat.py::
+     test_mixmat_blocks_at_high_l_vs_3j, ::test_mixmat_eb_full_sky_identity_lmax4096)
   4  nside 4096, lmax 6144: tests/test_gpu_fullsize.py
 """
 

@@ -212,6 +212,123 @@ def test_mixmat_eb_builds_are_bitwise_repeatable(L):
     import heracles_amd as hx
 
     ell = np.arange(L + 1)
-    wl = 4 * np.pi * 0.35 * np.exp(-ell * (ell + 1) / (0.08 * L * L)) + 1e-3 / (1.0 + ell) ** 2
+    wl = 4 * np.pi * 0.35 * np.exp(-ell * (ell + 1) / (0.08 * L * L)) + 0.2 / (1.0 + ell) ** 1.5
     seen = {hashlib.sha1(np.ascontiguousarray(hx.mixmat_eb(wl)).tobytes()).hexdigest() for _ in range(6)}
     assert len(seen) == 1
+
+
+def _mask_spectrum(L):
+    ell = np.arange(L + 1)
+    # a survey-like mask spectrum: a broad Gaussian core plus a slow power-law tail, so that every l3 up to L contributes
+    return 4 * np.pi * 0.35 * np.exp(-ell * (ell + 1) / 3000.0) + 0.2 / (1.0 + ell) ** 1.5
+
+
+def _blocks(L):
+    """Where the matrices are hard: the high-l corner, the middle of the diagonal, off-diagonal strips at (L, L/2) and
+    (L/2, L), and the first spin-2 rows against high columns."""
+    h = L // 2
+    return [((L - 23, L), (L - 200, L)), ((h - 12, h + 11), (h - 100, h + 100)), ((L - 23, L), (h - 100, h + 100)),
+            ((h - 12, h + 11), (L - 200, L)), ((2, 25), (L - 200, L)), ((0, 23), (0, 200))]
+
+
+@pytest.mark.parametrize("L", [4096, 6144])
+def test_mixmat_blocks_at_high_l_vs_3j(oracle, L):
+    """BASELINE configs[3] (lmax 4096) and the bench's L = 6144 build against the 3j oracle ON BLOCKS ANYWHERE in the
+    matrices (oracle.mixmat_block / mixmat_eb_block: the Schulten-Gordon recursion per (l1, l2), itself pinned at
+    these sizes on exact big-integer Racah sums, tests/test_oracle_golden.py): spins (0,0), (2,0), (0,2) and the three
+    spin-2 x spin-2 matrices; heracles/twopoint.py:378-388, the roles of the three matrices :445-458."""
+    import heracles_amd as hx
+
+    wl = _mask_spectrum(L)
+    worst = {}
+    for spin in [(0, 0), (2, 0), (0, 2)]:
+        got = hx.mixmat(wl, spin=spin)
+        assert got.shape == (L + 1, L + 1)
+        scale = np.abs(got).max()
+        for rows, cols in _blocks(L):
+            ref = oracle.mixmat_block(wl, rows, cols, spin=spin)
+            blk = got[rows[0]:rows[1] + 1, cols[0]:cols[1] + 1]
+            assert np.abs(ref).max() > 0
+            err = np.abs(blk - ref).max()
+            worst[spin, rows, cols] = err / scale
+            assert err <= 1e-12 * scale, (spin, rows, cols, err / scale)
+        del got
+    eb = hx.mixmat_eb(wl)
+    assert eb.shape == (3, L + 1, L + 1)
+    scale = np.abs(eb).max()
+    for rows, cols in _blocks(L):
+        ref = oracle.mixmat_eb_block(wl, rows, cols)
+        blk = eb[:, rows[0]:rows[1] + 1, cols[0]:cols[1] + 1]
+        for k in range(3):
+            err = np.abs(blk[k] - ref[k]).max()
+            assert err <= 1e-12 * scale, ("eb", k, rows, cols, err / scale)
+    print("worst block error / max|M|:", max(worst.values()))
+
+
+def test_mixmat_eb_full_sky_identity_lmax4096():
+    """A full-sky mask (W_l = 4 pi delta_l0) couples nothing: [0] (EE -> EE) is the identity on l >= 2, [1] (EE -> BB)
+    vanishes and [2] = [0] - [1]; so is the mixed (2,0) matrix the identity on l >= 2.  This touches every d^l_{2,+-2} and
+    d^l_{2,0} table row and every Gauss-Legendre node of the L = 4096 build (orthogonality of the tables under the nodes)."""
+    import heracles_amd as hx
+
+    L = 4096
+    one = np.zeros(L + 1)
+    one[0] = 4 * np.pi
+    eb = hx.mixmat_eb(one)
+    ident = np.zeros(L + 1)
+    ident[2:] = 1.0
+    for k, diag in ((0, ident), (1, 0 * ident), (2, ident)):
+        np.testing.assert_allclose(np.diagonal(eb[k]), diag, atol=2e-11)
+        off = eb[k].copy()
+        np.fill_diagonal(off, 0.0)
+        assert np.abs(off).max() <= 2e-11, k
+        del off
+    del eb
+    m20 = hx.mixmat(one, spin=(2, 0))
+    np.testing.assert_allclose(np.diagonal(m20), ident, atol=2e-11)
+    np.fill_diagonal(m20, 0.0)
+    assert np.abs(m20).max() <= 2e-11
+
+
+def test_mixmat_out_argument_and_pinned_buffers(oracle):
+    """`out=`: the caller's array (pageable numpy, page-locked `pinned_empty`, a context's `result_buffer`, a device tensor) receives
+    the matrices and is what the call returns; results are bit-identical to the default path whatever the destination."""
+    import torch
+
+    import heracles_amd as hx
+
+    L = 300
+    cl = _mask_spectrum(L)
+    ref = hx.mixmat_eb(cl)
+    np.testing.assert_allclose(ref, oracle.mixmat_eb(cl), atol=1e-13 * np.abs(ref).max())
+    mine = np.full((3, L + 1, L + 1), np.nan)
+    assert hx.mixmat_eb(cl, out=mine) is mine
+    np.testing.assert_array_equal(mine, ref)
+    pin = hx.pinned_empty((3, L + 1, L + 1))
+    pin[:] = np.nan
+    assert hx.mixmat_eb(cl, out=pin) is pin
+    np.testing.assert_array_equal(pin, ref)
+    keep = pin[1, 5:9].copy()
+    view = pin[1, 5:9]
+    del pin                                     # a live view keeps the page-locked block
+    np.testing.assert_array_equal(view, keep)
+    dev = torch.empty((3, L + 1, L + 1), dtype=torch.float64, device="cuda")
+    assert hx.mixmat_eb(cl, out=dev) is dev
+    np.testing.assert_array_equal(dev.cpu().numpy(), ref)
+    m00 = hx.mixmat(cl, spin=(0, 0))
+    buf = np.empty((L + 1, L + 1))
+    assert hx.mixmat(cl, spin=(0, 0), out=buf) is buf
+    np.testing.assert_array_equal(buf, m00)
+    with hx.MixmatContext(L, L, L) as ctx:
+        rb = ctx.result_buffer((2, 2))
+        assert rb.shape == (3, L + 1, L + 1) and ctx.result_buffer((2, 2)) is rb
+        got = ctx(cl, (2, 2), out=rb)
+        assert got is rb
+        np.testing.assert_array_equal(rb, ref)
+        cl2 = cl * np.linspace(1.0, 0.5, L + 1)
+        np.testing.assert_array_equal(ctx(cl2, (2, 2), out=rb), hx.mixmat_eb(cl2))       # the next build overwrites the buffer
+        r0 = ctx.result_buffer((0, 0))
+        np.testing.assert_array_equal(ctx(cl, (0, 0), out=r0), m00)
+        np.testing.assert_array_equal(ctx(cl, (0, 2)), hx.mixmat(cl, spin=(0, 2)))
+    with pytest.raises(ValueError):
+        hx.mixmat_eb(cl, out=np.empty((3, L + 1, L)))

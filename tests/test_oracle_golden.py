@@ -127,3 +127,109 @@ def test_mixmat_identities(oracle):
     M = oracle.mixmat(cl, l1max=4, l2max=2 * L, l3max=L)
     assert abs(M[0].sum() - ((2 * np.arange(L + 1) + 1) * cl).sum() / (4 * np.pi)) < 1e-13
     assert oracle.mixmat(cl, l1max=10, l2max=20).shape == (11, 21)
+
+
+def _racah_3j(j1, j2, j3, m1, m2):
+    """Exact Wigner 3j (j1 j2 j3; m1 m2 -(m1+m2)) from Racah's single sum, written as an alternating sum of products of
+    three binomials (exact big integers; the sum cancels over thousands of digits at l ~ 6000) and rounded once at the
+    end (50 digits): independent of every recursion, usable where sympy needs ~10 s per symbol."""
+    from math import comb
+
+    import mpmath
+
+    m3 = -(m1 + m2)
+    if j3 < abs(j1 - j2) or j3 > j1 + j2 or abs(m1) > j1 or abs(m2) > j2 or abs(m3) > j3:
+        return 0.0
+    a, b, c = j1 + j2 - j3, j1 - j2 + j3, -j1 + j2 + j3
+    k0 = max(0, j2 - j3 - m1, j1 - j3 + m2)
+    k1 = min(a, j1 - m1, j2 + m2)
+    # sum_k (-1)^k / (k! (a-k)! (j1-m1-k)! (j3-j2+m1+k)! (j2+m2-k)! (j3-j1-m2+k)!) = S / (a! b! c!)
+    S = 0
+    A, B, Cc = comb(a, k0), comb(b, j1 - m1 - k0), comb(c, j2 + m2 - k0)
+    for k in range(k0, k1 + 1):                  # the three binomials by their exact ratios (math.comb per term: 30 s)
+        t = A * B * Cc
+        S += -t if k & 1 else t
+        if k < k1:
+            A = A * (a - k) // (k + 1)
+            n = j1 - m1 - k
+            B = B * n // (b - n + 1)
+            n = j2 + m2 - k
+            Cc = Cc * n // (c - n + 1)
+    with mpmath.workdps(50):
+        F = mpmath.factorial
+        sq = (F(j1 + m1) * F(j1 - m1) * F(j2 + m2) * F(j2 - m2) * F(j3 + m3) * F(j3 - m3)) / (F(j1 + j2 + j3 + 1) * F(a) * F(b) * F(c))
+        v = mpmath.sqrt(sq) * mpmath.mpf(abs(S))
+        sign = (-1 if (j1 - j2 - m3) & 1 else 1) * (-1 if S < 0 else 1)
+        return float(sign * v)
+
+
+def test_racah_sum_agrees_with_sympy():
+    from sympy import N
+    from sympy.physics.wigner import wigner_3j
+
+    for j1, j2, j3, m1, m2 in [(2, 2, 2, 2, -2), (12, 9, 7, 2, -2), (30, 28, 11, 0, 0), (40, 40, 80, 2, -2), (25, 31, 6, 2, -2),
+                               (17, 17, 1, 2, -2), (9, 14, 20, 0, 0)]:
+        ref = float(N(wigner_3j(j1, j2, j3, m1, m2, -(m1 + m2)), 30))
+        assert abs(_racah_3j(j1, j2, j3, m1, m2) - ref) <= 1e-15 * max(1.0, abs(ref))
+    # one symbol at config 4's size, evaluated once with sympy (12 s) and kept as a constant
+    assert abs(_racah_3j(4096, 4000, 500, 2, -2) - 0.000388713221742114777088655531457) < 1e-18
+
+
+def test_wigner3j_recursion_at_config4_and_bench_sizes(oracle):
+    """The Schulten-Gordon recursion where the GPU tests lean on it: rows and columns near L = 4096 / 6144, the diagonal, an
+    off-diagonal pair and a pair whose l3 range starts in the non-classical tail, against the exact sum."""
+    cases = []
+    for L in (4096, 6144):
+        for l1, l2 in [(L, L), (L, L - 200), (L - 23, L // 2), (L // 2 + 7, L // 2), (L, 2), (L - 5, 37)]:
+            lo, hi = abs(l1 - l2), l1 + l2
+            for m1, m2 in ((2, -2), (0, 0)):
+                picks = sorted({lo, lo + 1, (lo + hi) // 2, (lo + hi) // 2 + 1, min(hi, L) - 1, min(hi, L), hi})
+                cases.append((l1, l2, m1, m2, picks))
+    worst = 0.0
+    for l1, l2, m1, m2, picks in cases:
+        jmin, w = oracle.wigner3j_l3(l1, l2, m1, m2)
+        scale = np.abs(w).max()
+        for l3 in picks:
+            if l3 < jmin:
+                continue
+            ref = _racah_3j(l1, l2, l3, m1, m2)
+            worst = max(worst, abs(w[l3 - jmin] - ref) / scale)
+    assert worst < 5e-13, worst
+
+
+def test_mixmat_blocks_vs_sympy_and_full(oracle):
+    """hxo_mixmat_block / hxo_mixmat_eb_block: equal to the full matrices on every block, and to exact 3j sums at L = 40 (the big-integer
+    Racah sum, which test_racah_sum_agrees_with_sympy pins on sympy)."""
+    L = 40
+    rng = np.random.default_rng(17)
+    cl = rng.uniform(0.5, 1.5, L + 1) / (1 + np.arange(L + 1)) ** 1.5
+    full = {s: oracle.mixmat(cl, spin=s) for s in [(0, 0), (2, 0), (0, 2)]}
+    eb = oracle.mixmat_eb(cl)
+    for rows, cols in [((0, L), (0, L)), ((33, 40), (5, 29)), ((17, 17), (0, 40)), ((2, 9), (38, 40))]:
+        r, c = slice(rows[0], rows[1] + 1), slice(cols[0], cols[1] + 1)
+        for s, M in full.items():
+            np.testing.assert_array_equal(oracle.mixmat_block(cl, rows, cols, spin=s), M[r, c])
+        np.testing.assert_array_equal(oracle.mixmat_eb_block(cl, rows, cols), eb[:, r, c])
+    # exact sums on a block that touches the corner l1 = l2 = l3max (truncated l3 range)
+    rows, cols = (37, 40), (36, 40)
+    w3 = {}
+
+    def w(l1, l2, l3, m):
+        key = (l1, l2, l3, m)
+        if key not in w3:
+            w3[key] = _racah_3j(l1, l2, l3, m, -m)
+        return w3[key]
+
+    ref00 = np.zeros((4, 5)); ref20 = np.zeros((4, 5)); refeb = np.zeros((3, 4, 5))
+    for i, l1 in enumerate(range(rows[0], rows[1] + 1)):
+        for j, l2 in enumerate(range(cols[0], cols[1] + 1)):
+            f = (2 * l2 + 1) / (4 * np.pi)
+            for l3 in range(abs(l1 - l2), L + 1):
+                t = (2 * l3 + 1) * cl[l3]
+                ref00[i, j] += f * t * w(l1, l2, l3, 0) ** 2
+                ref20[i, j] += f * t * w(l1, l2, l3, 2) * w(l1, l2, l3, 0)
+                refeb[(l1 + l2 + l3) & 1, i, j] += f * t * w(l1, l2, l3, 2) ** 2
+    refeb[2] = refeb[0] - refeb[1]
+    np.testing.assert_allclose(oracle.mixmat_block(cl, rows, cols, spin=(0, 0)), ref00, atol=1e-15)
+    np.testing.assert_allclose(oracle.mixmat_block(cl, rows, cols, spin=(2, 0)), ref20, atol=1e-15)
+    np.testing.assert_allclose(oracle.mixmat_eb_block(cl, rows, cols), refeb, atol=1e-15)
