@@ -27,11 +27,11 @@ SYMBOLS = (
     "hx_get_stream", "hx_set_async", "hx_synchronize", "hx_timer_start", "hx_timer_stop",
     "hx_profile_enable", "hx_profile_reset", "hx_profile_get", "hx_plan_create", "hx_set_max_lds_fft",
     "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_set_scratch_budget", "hx_plan_last_chunks", "hx_plan_mfma_flops", "hx_plan_executed_flops", "hx_executed_flops", "hx_measure_peaks", "hx_measured_mfma_clock", "hx_map2alm", "hx_map2alm_multi", "hx_map2alm_list", "hx_alm2map", "hx_copy",
-    "hx_alm2cl_pairs", "hx_alm2cl_pairs_range", "hx_gauss_legendre", "hx_wigner_d_table", "hx_mixmat",
+    "hx_alm2cl_pairs", "hx_alm2cl_pairs_range", "hx_gauss_legendre", "hx_gauss_legendre_dd", "hx_wigner_d_table", "hx_mixmat",
     "hx_mixmat_eb", "hx_mixmat_batch", "hx_mixctx_create", "hx_mixctx_apply", "hx_mixctx_destroy", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_reorder", "hx_matvec", "hx_pinv", "hx_alm_resample", "hx_region_maps", "hx_alm_subtract", "hx_fits_unpack_f64", "hx_fits_pack_f64",
     "hx_pointsht_create", "hx_pointsht_destroy", "hx_pointsht_info", "hx_pointsht_adjoint",
     "hx_pixel_weights_size", "hx_pixel_weights_expand",
-    "hx_ring_modes_size", "hx_ring_modes", "hx_legendre_from_modes", "hx_host_alloc", "hx_host_free", "hx_mixmat_gemm_clock",
+    "hx_ring_modes_size", "hx_ring_modes", "hx_legendre_from_modes", "hx_host_alloc", "hx_host_free", "hx_mixmat_gemm_clock", "hx_mixmat_release",
 )
 
 
@@ -93,6 +93,7 @@ def load():
         L.hx_alm2cl_pairs.argtypes = [i, vp, vp, i, i, vp, vp, dp]
         L.hx_alm2cl_pairs_range.argtypes = [i, vp, vp, i, i, vp, vp, i, i, i, dp]
         L.hx_gauss_legendre.argtypes = [i, dp, dp]
+        L.hx_gauss_legendre_dd.argtypes = [i, dp, dp, dp]
         L.hx_wigner_d_table.argtypes = [i, i, i, i, dp, dp]
         L.hx_mixmat.argtypes = [dp, i, i, i, i, i, i, dp]
         L.hx_mixmat_eb.argtypes = [dp, i, i, i, i, dp]

@@ -1672,6 +1672,27 @@ int valu_tasks(hx_plan *pl, int spin, hx_plan::TaskSet **out, int blocks)
     return HX_OK;
 }
 
+int synth_duo_tasks(hx_plan *pl, int spin, hx_plan::TaskSet **out)
+{
+    if (spin) HX_TRY(ensure_rec2(pl));
+    hx_plan::TaskSet &ts = spin ? pl->ts[3] : pl->ts[2];
+    HX_TRY(build_task_set(pl, spin, PipeCfg<2>::NW * (spin ? PipeCfg<2>::RBS : PipeCfg<0>::RBS), ts));
+    // the highest order every ring pair is synthesised for: the tasks of an order m start at the 32-ring-pair block that holds the first
+    // ring with mlim >= m (build_task_set), so ring pair rp is covered for m <= the largest mlim of its block; the rows beyond are never
+    // written and the spectrum pass does not read them (no 32 GB memset per sweep of ten fields)
+    DevBuf &lim = spin ? pl->syn_mlim2 : pl->syn_mlim0;
+    if (!lim.p) {
+        std::vector<int> h(pl->nrp_pad, -1);
+        for (int rp = 0; rp < pl->nrp; ++rp) {
+            const int last = std::min(rp / RBLK * RBLK + RBLK - 1, pl->nrp - 1);
+            h[rp] = std::min(pl->lmax, ring_mlim(pl->lmax, spin, pl->h_sth[last], pl->h_z[last]));
+        }
+        HX_TRY(upload(lim, h));
+    }
+    *out = &ts;
+    return HX_OK;
+}
+
 static int analysis_batch_valu(hx_plan *pl, int spin, int nb, const double *d_maps, double2 *d_alms, const double *d_rw,
                                const double *d_pw, const double *d_fl, int add)
 {

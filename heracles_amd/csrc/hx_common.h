@@ -114,7 +114,10 @@ double scratch_budget_bytes();
 // G = T diag(s) T2^T on the FP64 matrix unit (hx_mixmat.hip; used by hx_svd.hip)
 int launch_gemm_tst(const double *T, int rows1_pad, const double *T2, int rows2_pad, int kpad, const double *s, int n1, int n2, double *G, long long ldg);
 
+// hx_init on another device: drop the context hx_mixmat / hx_mixmat_eb keep between calls (hx_mixmat.hip)
+void mixmat_drop_cache();
+
 // Gauss-Legendre nodes/weights into device arrays (hx_mixmat.hip)
-int launch_gauss_legendre(int n, double *d_x, double *d_w);
+int launch_gauss_legendre(int n, double *d_x, double *d_w, double *d_xlo = nullptr);  // d_xlo: node k = x[k] + xlo[k] (see k_gauss_legendre)
 
 }  // namespace hx

@@ -21,12 +21,17 @@ constexpr int GB = 128;   // block tile edge (l, l')
 constexpr int GK = 32;    // nodes per k tile
 
 // ---- Gauss-Legendre nodes: Newton on P_n, one thread per node pair ---------------------
-__global__ void k_gauss_legendre(int n, double *__restrict__ x, double *__restrict__ w)
+// xlo (may be null): the part of every node that a double cannot hold -- node = x + xlo, xlo = -P_n(x) / P_n'(x) at the converged
+// double, accurate to ~1 % (P_n(x) ~ P_n' * 1e-16 stands well above the rounding noise of its recurrence).  The mixing-matrix tables
+// need it: next to the poles d^l(x)' ~ l^2 / 2, so rounding a node to a double shifts d^l there by l^2 / 2 * 5e-17 ~ 1e-9 for l = 6000,
+// coherently over all l of a table -- 2.7e-10 on the diagonal of the L = 4096 matrix of a mask whose correlation function peaks at
+// theta = 0 (found by tests/test_gpu_mixmat.py::test_mixmat_blocks_at_high_l_vs_3j; the weights are good to 1e-16 as they are).
+__global__ void k_gauss_legendre(int n, double *__restrict__ x, double *__restrict__ w, double *__restrict__ xlo)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (n + 1) / 2) return;
     double t = cospi((i + 0.75) / (n + 0.5));
-    double dp = 1.0;
+    double dp = 1.0, tl = 0.0, pn = 0.0;
     for (int it = 0; it < 10; ++it) {
         double p0 = 1.0, p1 = t;
         for (int k = 2; k <= n; ++k) {
@@ -42,67 +47,97 @@ __global__ void k_gauss_legendre(int n, double *__restrict__ x, double *__restri
         if (fabs(dt) <= 4e-16) break;
     }
     {
-        double p0 = 1.0, p1 = t;
+        // P_n at the converged node in double-double: in plain doubles the value (~ P_n' x 1e-16) drowns in the rounding noise of the
+        // recurrence (~ n x 1e-16) everywhere but next to the poles, and a correction made of noise is worse than none
+#pragma clang fp contract(off)  // (error-free transformations: every product and sum below rounds on its own)
+        double ph0 = 1.0, pl0 = 0.0, ph1 = t, pl1 = 0.0;
         for (int k = 2; k <= n; ++k) {
-            double p2 = ((2.0 * k - 1.0) * t * p1 - (k - 1.0) * p0) / k;
-            p0 = p1;
-            p1 = p2;
+            const double a = 2.0 * k - 1.0, b = k - 1.0;
+            // u = t * p1 (dd x double), v = a * u, w = b * p0, d = v - w, p2 = d / k
+            double uh = ph1 * t, ul = fma(ph1, t, -uh) + pl1 * t;
+            double vh = uh * a, vl = fma(uh, a, -vh) + ul * a;
+            double wh = ph0 * b, wl = fma(ph0, b, -wh) + pl0 * b;
+            double sh = vh - wh, bb = sh - vh, sl = (vh - (sh - bb)) + (-wh - bb);  // two_sum(vh, -wh)
+            sl += vl - wl;
+            double dh = sh + sl, dl = sl - (dh - sh);                              // quick_two_sum
+            const double q1 = dh / k, r = fma(-q1, (double)k, dh), q2 = (r + dl) / k;
+            ph0 = ph1; pl0 = pl1;
+            ph1 = q1 + q2; pl1 = q2 - (ph1 - q1);
         }
-        dp = n * (t * p1 - p0) / (t * t - 1.0);
+        dp = n * (t * ph1 - ph0) / (t * t - 1.0);
+        pn = ph1 + pl1;
+        tl = -pn / dp;
     }
-    const double ww = 2.0 / ((1.0 - t * t) * dp * dp);
-    if ((n & 1) && i == n / 2) t = 0.0;
+    // the weight belongs to the node t + tl: evaluated at the rounded t it is off by up to 6e-10 next to the poles
+    // (d ln w / dx = -2 x / (1 - x^2)); P_n'(t + tl) = P_n' + tl P_n'' with (1 - t^2) P_n'' = 2 t P_n' - n (n + 1) P_n
+    const double om = (1.0 - t) * (1.0 + t);
+    const double dps = dp + tl * (2.0 * t * dp - (double)n * (n + 1.0) * pn) / om;
+    const double ww = 2.0 / ((om - 2.0 * t * tl) * dps * dps);
+    if ((n & 1) && i == n / 2) { t = 0.0; tl = 0.0; }
     x[i] = -t; x[n - 1 - i] = t;
     w[i] = ww; w[n - 1 - i] = ww;
+    if (xlo) { xlo[i] = -tl; xlo[n - 1 - i] = tl; }
 }
 
 // ---- Wigner-d table: out[l*sl + k*sk] = d^l_{ab}(x_k), l = 0..lmax ----------------------
 // coef[l] = (c1x, c1c, c2): d^{l+1} = (c1x x + c1c) d^l - c2 d^{l-1}
+// xlo (may be null): the node is x + xlo (k_gauss_legendre); the table then holds d^l(x) + xlo d^l'(x), the derivative term carried by a
+// second recurrence e_{l+1} = (c1x x + c1c) e_l - c2 e_{l-1} + c1x xlo d_l (first order in xlo ~ 1e-16 is exact to rounding)
 __global__ void k_wigner_table(int lmax, int a, int b, int n, const double *__restrict__ x,
                                const double4 *__restrict__ coef, double *__restrict__ out,
-                               long long sl, long long sk)
+                               long long sl, long long sk, const double *__restrict__ xlo)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const double xx = x[k];
+    const double xx = x[k], xl = xlo ? xlo[k] : 0.0;
     const int l0 = max(abs(a), abs(b));
-    double d0;
-    if (a == 0 && b == 0) d0 = 1.0;
-    else if (a == 2 && b == 0) d0 = 0.61237243569579452455 * (1.0 - xx) * (1.0 + xx);
-    else if (a == 2 && b == 2) d0 = 0.25 * (1.0 + xx) * (1.0 + xx);
-    else if (a == 1 && b == 1) d0 = 0.5 * (1.0 + xx);                    // d^1_{11}   (transforms.py:68-73)
-    else if (a * b == -1) d0 = 0.5 * (1.0 - xx);                         // d^1_{-1,1} = d^1_{1,-1}
-    else d0 = 0.25 * (1.0 - xx) * (1.0 - xx);  // (2,-2)
+    double d0, e0;  // d^{l0}(x) and xlo times its derivative
+    if (a == 0 && b == 0) { d0 = 1.0; e0 = 0.0; }
+    else if (a == 2 && b == 0) { d0 = 0.61237243569579452455 * (1.0 - xx) * (1.0 + xx); e0 = -2.0 * 0.61237243569579452455 * xx * xl; }
+    else if (a == 2 && b == 2) { d0 = 0.25 * (1.0 + xx) * (1.0 + xx); e0 = 0.5 * (1.0 + xx) * xl; }
+    else if (a == 1 && b == 1) { d0 = 0.5 * (1.0 + xx); e0 = 0.5 * xl; }                    // d^1_{11}   (transforms.py:68-73)
+    else if (a * b == -1) { d0 = 0.5 * (1.0 - xx); e0 = -0.5 * xl; }                        // d^1_{-1,1} = d^1_{1,-1}
+    else { d0 = 0.25 * (1.0 - xx) * (1.0 - xx); e0 = -0.5 * (1.0 - xx) * xl; }  // (2,-2)
     for (int l = 0; l < l0 && l <= lmax; ++l) out[l * sl + k * sk] = 0.0;
     if (l0 > lmax) return;
-    double dp = 0.0, dc = d0;
-    out[l0 * sl + k * sk] = dc;
+    double dp = 0.0, dc = d0, ep = 0.0, ec = e0;
+    out[l0 * sl + k * sk] = dc + ec;
     for (int l = l0; l < lmax; ++l) {
         const double4 c = coef[l];
-        const double dn = fma(fma(c.x, xx, c.y), dc, -c.z * dp);
+        const double t = fma(c.x, xx, c.y);
+        const double dn = fma(t, dc, -c.z * dp);
+        const double en = fma(t, ec, fma(c.x * xl, dc, -c.z * ep));
         dp = dc;
         dc = dn;
-        out[(l + 1) * sl + k * sk] = dc;
+        ep = ec;
+        ec = en;
+        out[(l + 1) * sl + k * sk] = dc + ec;
     }
 }
 
 // ---- s_k = w_k * xi(x_k), xi = sum_l (2l+1)/(4pi) W_l P_l(x) ----------------------------
+// (xlo as in k_wigner_table: xi at the node x + xlo, the derivative term summed on its own)
 __global__ void k_weight_xi(int l3max, int n, const double *__restrict__ x, const double *__restrict__ w,
-                            const double *__restrict__ cl, double *__restrict__ s)
+                            const double *__restrict__ cl, double *__restrict__ s, const double *__restrict__ xlo)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const double xx = x[k];
-    double p0 = 1.0, p1 = xx;
-    double xi = cl[0] * (1.0 / (4.0 * M_PI));
-    if (l3max >= 1) xi += 3.0 / (4.0 * M_PI) * cl[1] * p1;
+    const double xx = x[k], xl = xlo ? xlo[k] : 0.0;
+    double p0 = 1.0, p1 = xx, q0 = 0.0, q1 = xl;  // q_l = xlo P_l'(x)
+    double xi = cl[0] * (1.0 / (4.0 * M_PI)), xe = 0.0;
+    if (l3max >= 1) { xi += 3.0 / (4.0 * M_PI) * cl[1] * p1; xe = 3.0 / (4.0 * M_PI) * cl[1] * q1; }
     for (int l = 2; l <= l3max; ++l) {
         const double p2 = ((2.0 * l - 1.0) * xx * p1 - (l - 1.0) * p0) / l;
+        const double q2 = ((2.0 * l - 1.0) * (xx * q1 + xl * p1) - (l - 1.0) * q0) / l;
         p0 = p1;
         p1 = p2;
-        xi = fma((2.0 * l + 1.0) / (4.0 * M_PI) * cl[l], p2, xi);
+        q0 = q1;
+        q1 = q2;
+        const double f = (2.0 * l + 1.0) / (4.0 * M_PI) * cl[l];
+        xi = fma(f, p2, xi);
+        xe = fma(f, q2, xe);
     }
-    s[k] = w[k] * xi;
+    s[k] = w[k] * (xi + xe);
 }
 
 // ---- symmetric GEMM: G[i][j] = colscale[j] * sum_k T[i][k] s[k] T[j][k] -----------------
@@ -484,10 +519,10 @@ static void wigner_coefs(int lmax, int a, int b, std::vector<double4> &c)
     }
 }
 
-int launch_gauss_legendre(int n, double *d_x, double *d_w)
+int launch_gauss_legendre(int n, double *d_x, double *d_w, double *d_xlo)
 {
     const int half = (n + 1) / 2;
-    hipLaunchKernelGGL(k_gauss_legendre, dim3((half + 63) / 64), dim3(64), 0, rt().stream, n, d_x, d_w);
+    hipLaunchKernelGGL(k_gauss_legendre, dim3((half + 63) / 64), dim3(64), 0, rt().stream, n, d_x, d_w, d_xlo);
     HX_HIP(hipGetLastError());
     return HX_OK;
 }
@@ -509,7 +544,7 @@ static bool gemm_dma()
 
 struct GLCache {
     int n = 0;
-    DevBuf x, w;
+    DevBuf x, w, xlo;  // node k = x[k] + xlo[k]
 };
 
 static int gl_nodes_device(int n, GLCache &c)
@@ -517,7 +552,8 @@ static int gl_nodes_device(int n, GLCache &c)
     if (c.n == n && c.x.p) return HX_OK;
     HX_TRY(c.x.alloc(sizeof(double) * n));
     HX_TRY(c.w.alloc(sizeof(double) * n));
-    HX_TRY(launch_gauss_legendre(n, c.x.as<double>(), c.w.as<double>()));
+    HX_TRY(c.xlo.alloc(sizeof(double) * n));
+    HX_TRY(launch_gauss_legendre(n, c.x.as<double>(), c.w.as<double>(), c.xlo.as<double>()));
     c.n = n;
     return HX_OK;
 }
@@ -596,7 +632,7 @@ static int mix_ctx_table(MixCtx &c, int t)
     {
         ProfScope ps("wigner_tables");
         hipLaunchKernelGGL(k_wigner_table, dim3((c.n + 63) / 64), dim3(64), 0, st, c.L, kAB[t][0], kAB[t][1], c.n,
-                           c.gl.x.as<double>(), d_coef.as<double4>(), c.T[t].as<double>(), (long long)c.kpad, 1LL);
+                           c.gl.x.as<double>(), d_coef.as<double4>(), c.T[t].as<double>(), (long long)c.kpad, 1LL, c.gl.xlo.as<double>());
     }
     HX_HIP(hipStreamSynchronize(st));  // d_coef dies with this scope
     c.have[t] = true;
@@ -609,7 +645,7 @@ static int mix_ctx_mask(MixCtx &c, const double *d_cl)
     hipStream_t st = rt().stream;
     HX_HIP(hipMemsetAsync(c.s.p, 0, sizeof(double) * c.kpad, st));
     hipLaunchKernelGGL(k_weight_xi, dim3((c.n + 255) / 256), dim3(256), 0, st, c.l3max, c.n, c.gl.x.as<double>(), c.gl.w.as<double>(),
-                       d_cl, c.s.as<double>());
+                       d_cl, c.s.as<double>(), c.gl.xlo.as<double>());
     HX_HIP(hipGetLastError());
     return HX_OK;
 }
@@ -649,24 +685,6 @@ static int mix_ctx_product(MixCtx &c, int t, double *d_out)
     return HX_OK;
 }
 
-// Build G^{(ab)} for all requested (a,b) into out matrices (device), (n1 x n2) each, ld = n2.
-static int mixmat_core(const double *d_cl, int l1max, int l2max, int l3max, int nprod,
-                       const int (*ab)[2], double *const *d_out)
-{
-    MixCtx c;
-    HX_TRY(mix_ctx_init(c, l1max, l2max, l3max));
-    HX_TRY(mix_ctx_mask(c, d_cl));
-    for (int p = 0; p < nprod; ++p) {
-        int t = -1;
-        for (int k = 0; k < 4; ++k)
-            if (kAB[k][0] == ab[p][0] && kAB[k][1] == ab[p][1]) t = k;
-        if (t < 0) return fail(HX_ERR_UNSUPPORTED, "mixmat: product (%d,%d) not supported", ab[p][0], ab[p][1]);
-        HX_TRY(mix_ctx_product(c, t, d_out[p]));
-    }
-    HX_HIP(hipStreamSynchronize(rt().stream));  // the context (tables, weights) dies with this scope
-    return HX_OK;
-}
-
 static int stage_cl(const double *cl, int ncl, int l3max, DevBuf &buf)
 {
     std::vector<double> h(l3max + 1, 0.0);
@@ -681,6 +699,98 @@ static int stage_cl(const double *cl, int ncl, int l3max, DevBuf &buf)
     }
     return HX_OK;
 }
+
+// ---- the context and the staging buffer of the one-shot entry points, kept between calls ------------------------------------------
+// hx_mixmat / hx_mixmat_eb / hx_mixmat_batch used to build and free a context per call: nodes, two or three 0.46 GB tables, the 0.46 GB
+// scaled table and -- for a host destination -- a 0.9 GB staging buffer at L = 6144, i.e. ~3 GB of hipMalloc / hipFree per build.  Every
+// second or third build of a row then took 0.12-0.18 s instead of 0.031 (BENCH_r04 seconds_all; round 5's first run: builds 2, 5 and 8 of a
+// row, whatever the destination's kind, never with a device destination): the driver's unmapping of the freed blocks catching up.  The
+// tables do not depend on the mask, so the last context is kept (one (l1max, l2max, l3max) at a time, as hx_mixctx_* keeps its own), and
+// so is the staging buffer: a build allocates nothing.  hx_mixmat_release() frees both; hx_init on another device drops them.
+struct MixCache {
+    MixCtx *ctx = nullptr;
+    DevBuf out_tmp, cl;
+    int device = -1;
+};
+static MixCache &mix_cache()
+{
+    static MixCache c;
+    return c;
+}
+static void mix_cache_drop()
+{
+    MixCache &mc = mix_cache();
+    delete mc.ctx;
+    mc.ctx = nullptr;
+    mc.out_tmp.release();
+    mc.cl.release();
+}
+static int mix_cached_ctx(int l1max, int l2max, int l3max, MixCtx **out)
+{
+    MixCache &mc = mix_cache();
+    if (mc.device != rt().device) {
+        mix_cache_drop();
+        mc.device = rt().device;
+    }
+    if (!mc.ctx || mc.ctx->l1max != l1max || mc.ctx->l2max != l2max || mc.ctx->l3max != l3max) {
+        if (mc.ctx) HX_HIP(hipStreamSynchronize(rt().stream));
+        delete mc.ctx;
+        mc.ctx = new MixCtx;
+        const int rc = mix_ctx_init(*mc.ctx, l1max, l2max, l3max);
+        if (rc != HX_OK) {
+            delete mc.ctx;
+            mc.ctx = nullptr;
+            return rc;
+        }
+    }
+    *out = mc.ctx;
+    return HX_OK;
+}
+}  // namespace hx
+void hx::mixmat_drop_cache() { hx::mix_cache_drop(); }
+namespace hx {
+// destination of a one-shot build: a device pointer as it is, a host pointer through the cached staging buffer
+static int mix_bind_out(OutView &vo, double *out, size_t bytes)
+{
+    vo.bytes = bytes;
+    if (is_device_ptr(out)) {
+        vo.dev = out;
+        vo.host = nullptr;
+        return HX_OK;
+    }
+    HX_TRY(mix_cache().out_tmp.alloc(bytes));
+    vo.dev = mix_cache().out_tmp.p;
+    vo.host = out;
+    return HX_OK;
+}
+// HX_MIXMAT_TRACE=1: wall-clock phases of a build on stderr (synchronises between phases: diagnostic only)
+static bool mix_trace()
+{
+    static const bool on = getenv("HX_MIXMAT_TRACE") && getenv("HX_MIXMAT_TRACE")[0] == '1';
+    return on;
+}
+struct MixTrace {
+    double t0;
+    const char *what;
+    static double now()
+    {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec + 1e-9 * ts.tv_nsec;
+    }
+    explicit MixTrace(const char *w) : t0(0.0), what(w)
+    {
+        if (mix_trace()) t0 = now();
+    }
+    void lap(const char *phase)
+    {
+        if (!mix_trace()) return;
+        (void)hipStreamSynchronize(rt().stream);
+        const double t = now();
+        fprintf(stderr, "[hx mixmat trace] %s: %s %.2f ms\n", what, phase, (t - t0) * 1e3);
+        t0 = t;
+    }
+};
 
 // The three spin-2 x spin-2 matrices of one mask (context c, node weights set) into vo = [3][n1][n2].
 // b = G^{(2,-2)} first: it IS the third matrix, so a host destination receives it (second stream, ~5 ms at L = 6144) while the
@@ -732,6 +842,27 @@ extern "C" int hx_gauss_legendre(int n, double *x, double *w)
     return HX_OK;
 }
 
+// The same with the part of every node that a double cannot hold: node k = x[k] + xlo[k] (|xlo| <~ 1e-16; see k_gauss_legendre).
+extern "C" int hx_gauss_legendre_dd(int n, double *x, double *w, double *xlo)
+{
+    HX_TRY(ensure_ready());
+    if (n < 1 || !x || !w || !xlo) return fail(HX_ERR_ARG, "hx_gauss_legendre_dd: bad argument");
+    GLCache c;
+    HX_TRY(gl_nodes_device(n, c));
+    OutView vx, vw, vl;
+    HX_TRY(vx.bind(x, sizeof(double) * n));
+    HX_TRY(vw.bind(w, sizeof(double) * n));
+    HX_TRY(vl.bind(xlo, sizeof(double) * n));
+    HX_HIP(hipMemcpyAsync(vx.dev, c.x.p, sizeof(double) * n, hipMemcpyDeviceToDevice, rt().stream));
+    HX_HIP(hipMemcpyAsync(vw.dev, c.w.p, sizeof(double) * n, hipMemcpyDeviceToDevice, rt().stream));
+    HX_HIP(hipMemcpyAsync(vl.dev, c.xlo.p, sizeof(double) * n, hipMemcpyDeviceToDevice, rt().stream));
+    HX_TRY(vx.finish());
+    HX_TRY(vw.finish());
+    HX_TRY(vl.finish());
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    return HX_OK;
+}
+
 extern "C" int hx_wigner_d_table(int lmax, int a, int b, int n, const double *x, double *out)
 {
     HX_TRY(ensure_ready());
@@ -750,7 +881,7 @@ extern "C" int hx_wigner_d_table(int lmax, int a, int b, int n, const double *x,
     {
         ProfScope ps("wigner_tables");
         hipLaunchKernelGGL(k_wigner_table, dim3((n + 63) / 64), dim3(64), 0, rt().stream, lmax, a, b, n, vx.as<double>(),
-                           d_coef.as<double4>(), vo.as<double>(), 1LL, (long long)(lmax + 1));
+                           d_coef.as<double4>(), vo.as<double>(), 1LL, (long long)(lmax + 1), (const double *)nullptr);
     }
     HX_HIP(hipGetLastError());
     HX_TRY(vo.finish());
@@ -773,14 +904,20 @@ extern "C" int hx_mixmat(const double *cl, int ncl, int l1max, int l2max, int l3
     if (s1 == 0 && s2 == 0) { ab[0][0] = 0; ab[0][1] = 0; }
     else if ((abs(s1) == 2 && s2 == 0) || (s1 == 0 && abs(s2) == 2)) { ab[0][0] = 2; ab[0][1] = 0; }
     else return fail(HX_ERR_UNSUPPORTED, "hx_mixmat: spin (%d,%d) not supported (use hx_mixmat_eb for (2,2))", s1, s2);
-    DevBuf d_cl;
+    MixTrace tr("hx_mixmat");
+    MixCtx *c = nullptr;
+    HX_TRY(mix_cached_ctx(l1max, l2max, l3max, &c));
+    DevBuf &d_cl = mix_cache().cl;
     HX_TRY(stage_cl(cl, ncl, l3max, d_cl));
     OutView vo;
-    HX_TRY(vo.bind(out, sizeof(double) * (size_t)(l1max + 1) * (l2max + 1)));
-    double *outs[1] = {vo.as<double>()};
-    HX_TRY(mixmat_core(d_cl.as<double>(), l1max, l2max, l3max, 1, ab, outs));
+    HX_TRY(mix_bind_out(vo, out, sizeof(double) * (size_t)(l1max + 1) * (l2max + 1)));
+    tr.lap("context + staging");
+    HX_TRY(mix_ctx_mask(*c, d_cl.as<double>()));
+    HX_TRY(mix_ctx_product(*c, ab[0][0] == 0 ? 0 : 1, vo.as<double>()));
+    tr.lap("node weights + product");
     HX_TRY(vo.finish());
     HX_HIP(hipStreamSynchronize(rt().stream));
+    tr.lap("copy out");
     return HX_OK;
 }
 
@@ -789,15 +926,18 @@ extern "C" int hx_mixmat_eb(const double *cl, int ncl, int l1max, int l2max, int
     HX_TRY(ensure_ready());
     HX_TRY(mixmat_args(cl, ncl, l1max, l2max, l3max, out));
     const size_t sz = (size_t)(l1max + 1) * (l2max + 1);
-    DevBuf d_cl;
+    MixTrace tr("hx_mixmat_eb");
+    MixCtx *c = nullptr;
+    HX_TRY(mix_cached_ctx(l1max, l2max, l3max, &c));
+    DevBuf &d_cl = mix_cache().cl;
     HX_TRY(stage_cl(cl, ncl, l3max, d_cl));
     OutView vo;
-    HX_TRY(vo.bind(out, sizeof(double) * 3 * sz));
-    MixCtx c;
-    HX_TRY(mix_ctx_init(c, l1max, l2max, l3max));
-    HX_TRY(mix_ctx_mask(c, d_cl.as<double>()));
-    HX_TRY(mix_eb_into(c, vo));
-    HX_HIP(hipStreamSynchronize(rt().stream));  // the context (tables, weights) dies with this scope
+    HX_TRY(mix_bind_out(vo, out, sizeof(double) * 3 * sz));
+    tr.lap("context + staging");
+    HX_TRY(mix_ctx_mask(*c, d_cl.as<double>()));
+    HX_TRY(mix_eb_into(*c, vo));
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    tr.lap("node weights + products + copy out");
     return HX_OK;
 }
 
@@ -812,6 +952,15 @@ extern "C" double hx_mixmat_gemm_clock(void)
         return 0.0;
     }
     return h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
+}
+
+// Frees what hx_mixmat / hx_mixmat_eb / hx_mixmat_batch keep between calls (the tables of the last (l1max, l2max, l3max) and the
+// staging buffer of a host destination: ~3 GB at L = 6144).  The next build allocates them again.
+extern "C" int hx_mixmat_release(void)
+{
+    if (rt().ready) (void)hipStreamSynchronize(rt().stream);
+    mix_cache_drop();
+    return HX_OK;
 }
 
 // y[v][i] = sum_j M[i][j] x[v][j]: the products of heracles.twopoint.apply_mixing_matrix (heracles/twopoint.py:497-524: `_M @ cl` per
@@ -875,10 +1024,11 @@ extern "C" int hx_mixmat_batch(int nmask, const double *cls, int ncl, int l1max,
             ((kinds[k] & 4) && (!outeb || !outeb[k])))
             return fail(HX_ERR_ARG, "hx_mixmat_batch: mask %d: kinds=%d without an output buffer", k, kinds[k]);
     const size_t sz = (size_t)(l1max + 1) * (l2max + 1);
-    MixCtx c;
-    HX_TRY(mix_ctx_init(c, l1max, l2max, l3max));
+    MixCtx *cp = nullptr;
+    HX_TRY(mix_cached_ctx(l1max, l2max, l3max, &cp));
+    MixCtx &c = *cp;
     const bool cls_dev = is_device_ptr(cls);
-    DevBuf d_cl;
+    DevBuf &d_cl = mix_cache().cl;
     for (int k = 0; k < nmask; ++k) {
         if (!kinds[k]) continue;
         HX_TRY(stage_cl(cls + (size_t)k * ncl, ncl, l3max, d_cl));

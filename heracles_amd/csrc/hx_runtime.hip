@@ -473,6 +473,7 @@ int hx_init(int device)
         r.copy = nullptr;
         if (r.order_ev) (void)hipEventDestroy(r.order_ev);
         r.order_ev = nullptr;
+        mixmat_drop_cache();
         stager_reset_events();
     }
     HX_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));

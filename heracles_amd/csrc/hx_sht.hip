@@ -720,34 +720,48 @@ __global__ __launch_bounds__(512) void k_ring_subdft_split(PlanDev P, const int 
 // Zc[c][startN + k] = conj(X_N + i X_S).  The values of four consecutive ring pairs at one m share a 128-byte line: a group
 // takes four ring pairs (thread = (ring pair, component, k)).
 __global__ __launch_bounds__(256) void k_synth_spectrum_v(PlanDev P, const double *__restrict__ Fv, int nc, int lmax,
-                                                          double2 *__restrict__ Zc)
+                                                          double2 *__restrict__ Zc, const int *__restrict__ mlim)
 {
     const int rp = blockIdx.x * 4 + (threadIdx.x & 3), rest = threadIdx.x >> 2;
     if (rp >= P.nrp) return;
+    // nc <= 64 components side by side (nc need not divide 64: the threads left over have nothing to do)
     const int c = rest % nc, kk = rest / nc, kstep = (int)(blockDim.x >> 2) / nc;
+    if (kk >= kstep) return;
     const int n = P.nsub[rp], nphi = 4 * n;
     const bool shifted = P.shifted[rp] != 0;
     const long long mstride = (long long)P.nrp_pad * 4 * nc;
     const double *row = Fv + (long long)rp * 4 * nc + 4 * c;
-    for (int k = kk; k < nphi; k += kstep) {
-        double2 xn = make_double2(0.0, 0.0), xs = xn;
-        for (int m = k; m <= lmax; m += nphi) {  // m == k (mod nphi)
+    // mlim (batched matrix-unit synthesis): rows of this ring pair exist for m <= mlim[rp] only (pruned beyond: zero, and not written)
+    const int mtop = mlim ? min(lmax, mlim[rp]) : lmax;
+    // One pass serves the bins k and nphi - k: A = sum_{m == k} (c_m / 2) Ft_m, B = sum_{m == -k} (c_m / 2) Ft_m;
+    // X[k] = A + conj(B), X[nphi - k] = B + conj(A) -- every value of Fv is read once (round 5; two passes before)
+    for (int k = kk; 2 * k <= nphi; k += kstep) {
+        const int k2 = (nphi - k) % nphi;
+        double2 an = make_double2(0.0, 0.0), as = an, bn = an, bs = an;
+        for (int m = k; m <= mtop; m += nphi) {  // m == k (mod nphi)
             const double2 *b = reinterpret_cast<const double2 *>(row + m * mstride);
             double2 ph = make_double2(1.0, 0.0);
             if (shifted) ph = expipi((double)(m % (2 * nphi)) / (double)nphi);
             const double sc = m == 0 ? 0.5 : 1.0;  // c_m / 2
-            xn = cadd(xn, cscale(cmul(b[0], ph), sc));
-            xs = cadd(xs, cscale(cmul(b[1], ph), sc));
+            an = cadd(an, cscale(cmul(b[0], ph), sc));
+            as = cadd(as, cscale(cmul(b[1], ph), sc));
         }
-        for (int m = (nphi - k) % nphi; m <= lmax; m += nphi) {  // m == -k (mod nphi)
-            const double2 *b = reinterpret_cast<const double2 *>(row + m * mstride);
-            double2 ph = make_double2(1.0, 0.0);
-            if (shifted) ph = expipi((double)(m % (2 * nphi)) / (double)nphi);
-            const double sc = m == 0 ? 0.5 : 1.0;
-            xn = cadd(xn, cscale(cconj(cmul(b[0], ph)), sc));
-            xs = cadd(xs, cscale(cconj(cmul(b[1], ph)), sc));
+        if (k2 != k) {
+            for (int m = k2; m <= mtop; m += nphi) {  // m == -k (mod nphi)
+                const double2 *b = reinterpret_cast<const double2 *>(row + m * mstride);
+                double2 ph = make_double2(1.0, 0.0);
+                if (shifted) ph = expipi((double)(m % (2 * nphi)) / (double)nphi);
+                const double sc = m == 0 ? 0.5 : 1.0;
+                bn = cadd(bn, cscale(cmul(b[0], ph), sc));
+                bs = cadd(bs, cscale(cmul(b[1], ph), sc));
+            }
+        } else {
+            bn = an;
+            bs = as;
         }
-        Zc[(long long)c * P.ny + P.startN[rp] + k] = cconj(cadd(xn, mul_pi(xs)));
+        double2 *z = Zc + (long long)c * P.ny + P.startN[rp];
+        z[k] = cconj(cadd(cadd(an, cconj(bn)), mul_pi(cadd(as, cconj(bs)))));
+        if (k2 != k) z[k2] = cconj(cadd(cadd(bn, cconj(an)), mul_pi(cadd(bs, cconj(as)))));
     }
 }
 
@@ -1188,16 +1202,57 @@ int classify_pixel_weights(hx_plan *pl, const double *d_pw)
 // ---- one synthesis pass over a batch (device pointers): one sweep of the vector-unit kernel per map / field (the round-1 matrix
 // kernel it replaces took 100 / 217 ms for one spin-0 map / spin-2 field at nside 4096 against 19 / 57, and 201 / 653 ms for ten
 // against 187 / 570).  If d_ref != NULL the output is the residual ref - synth (Jacobi iteration). ----
+// HX_SYNTH_KERNEL=valu: every batch on the vector-unit kernel (A/B reference of the matrix-unit synthesis of round 5)
+static bool synth_duo_enabled()
+{
+    static const bool on = !(getenv("HX_SYNTH_KERNEL") && !strcmp(getenv("HX_SYNTH_KERNEL"), "valu"));
+    return on;
+}
+
 static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms, double *d_maps,
                            const double *d_ref)
 {
     hipStream_t st = rt().stream;
-    // maps (spin 0) / fields (spin 2) per sweep: as many as the kernel takes (4 / 2: they share the recursion), then the rest
-    const int cpu = spin ? 2 : 1, umax = synth_valu_max_units(spin);
+    const int cpu = spin ? 2 : 1;  // components per unit (map / field)
+    PlanDev P = pl->dev();
+    // batches of >= 5 maps / >= 3 fields: sweeps of up to 20 maps / 10 fields on the matrix unit (hx_synth_duo.hip).  Their ring
+    // modes (Fv) and ring spectra (conj Z) live in the analysis' operand buffer F, which is idle during a synthesis: a Jacobi iteration
+    // of ten fields needs no HBM beyond what its analysis passes hold (F 64 GB >= 32 + 32).
+    const int nunits_all = nb / cpu;
+    if (synth_duo_enabled() && nunits_all >= (spin ? 3 : 5)) {
+        const int umax = synth_duo_max_units(spin);
+        hx_plan::TaskSet *ts = nullptr;
+        HX_TRY(synth_duo_tasks(pl, spin, &ts));
+        for (int u0 = 0; u0 < nunits_all;) {
+            int units = std::min(umax, nunits_all - u0);
+            // (a remainder of one or two units would run a whole sweep of the matrix kernel for 4-8 columns: split the tail evenly instead)
+            if (nunits_all - u0 > umax && nunits_all - u0 < umax + (spin ? 3 : 5)) units = (nunits_all - u0 + 1) / 2;
+            const int nc = units * cpu, rowlen = synth_duo_rowlen(spin, units);
+            const size_t fv_bytes = sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * rowlen;
+            const size_t zc_bytes = sizeof(double2) * (size_t)pl->ny * nc;
+            const size_t fv_pad = (fv_bytes + 255) & ~(size_t)255;
+            HX_TRY(pl->F.alloc(fv_pad + zc_bytes));
+            HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nc));
+            HX_TRY(pl->syn_tab.alloc(synth_duo_table_bytes(pl, spin, units)));
+            double *fv = pl->F.as<double>();
+            double2 *zc = reinterpret_cast<double2 *>(reinterpret_cast<char *>(pl->F.p) + fv_pad);
+            HX_TRY(launch_synth_duo(pl, spin, units, *ts, d_alms + (size_t)u0 * cpu * pl->nlm, pl->syn_tab.as<double>(), fv));
+            ProfScope ps("ring_fft");
+            hipLaunchKernelGGL(k_synth_spectrum_v, dim3((pl->nrp + 3) / 4), dim3(256), 0, st, P, fv, nc, pl->lmax, zc,
+                               (spin ? pl->syn_mlim2 : pl->syn_mlim0).as<int>());
+            HX_TRY(launch_subdft_classes<1>(pl, nc, nullptr, nullptr, zc, pl->Y.as<double2>()));
+            hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, nc), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps + (size_t)u0 * cpu * pl->npix, d_ref ? 1 : 0,
+                               d_ref ? d_ref + (size_t)u0 * cpu * pl->npix : nullptr);
+            u0 += units;
+        }
+        HX_HIP(hipGetLastError());
+        return HX_OK;
+    }
+    // small batches: one sweep of the vector-unit kernel per four maps / two fields (they share the recursion), then the rest
+    const int umax = synth_valu_max_units(spin);
     HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * cpu * umax));
     HX_TRY(pl->resid.alloc(sizeof(double2) * (size_t)pl->ny * cpu * umax));  // conj(Z) spectra
     HX_TRY(pl->Fsyn.alloc(sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * 4 * cpu * umax));
-    PlanDev P = pl->dev();
     for (int c0 = 0; c0 < nb;) {
         int units = umax;
         while (units * cpu > nb - c0) units >>= 1;
@@ -1206,7 +1261,8 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
         HX_TRY(valu_tasks(pl, spin, &ts, synth_valu_task_blocks(spin, units)));
         HX_TRY(launch_synth_valu(pl, spin, units, *ts, d_alms + (size_t)c0 * pl->nlm, pl->Fsyn.as<double>()));
         ProfScope ps("ring_fft");
-        hipLaunchKernelGGL(k_synth_spectrum_v, dim3((pl->nrp + 3) / 4), dim3(256), 0, st, P, pl->Fsyn.as<double>(), nc, pl->lmax, pl->resid.as<double2>());
+        hipLaunchKernelGGL(k_synth_spectrum_v, dim3((pl->nrp + 3) / 4), dim3(256), 0, st, P, pl->Fsyn.as<double>(), nc, pl->lmax, pl->resid.as<double2>(),
+                           (const int *)nullptr);
         HX_TRY(launch_subdft_classes<1>(pl, nc, nullptr, nullptr, pl->resid.as<double2>(), pl->Y.as<double2>()));
         hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, nc), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps + (size_t)c0 * pl->npix, d_ref ? 1 : 0,
                            d_ref ? d_ref + (size_t)c0 * pl->npix : nullptr);

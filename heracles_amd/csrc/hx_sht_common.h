@@ -322,6 +322,8 @@ struct hx_plan {
     hx::DevBuf fft_desc;                 // RingDesc of every entry of fft_rp_list (one 32-byte read per work item instead of two dependent ones)
     std::vector<int> h_fft_rp_list;      // (host copy: ring pairs in DESCENDING order within a class)
     hx::DevBuf Y, F, partial, d_dbg, resid, resid_maps, Fsyn, pw_sym;
+    hx::DevBuf syn_mlim0, syn_mlim2;  // per ring pair: the highest m its rows of Fv are written for (task pruning by blocks of 32 ring pairs)
+    hx::DevBuf syn_tab, syn_boff0, syn_boff2;  // batched synthesis on the matrix unit (hx_synth_duo.hip): B-operand table of a sweep, first table block of every m
     const double *pw_checked = nullptr;       // the pixel-weight array of the current call that pw_mode describes
     int pw_mode = 0;                          // 1: one weight per pixel; 2: the array repeats over the quadrants of every ring and from north to south (healpy's weights)
     static constexpr int NSTAGE = 3;          // staging buffers of the upload pipeline (hx_map2alm_multi / _list; hx_map2alm of host maps is one job of it)
@@ -370,5 +372,11 @@ int valu_exec_flops(unsigned long long *v, bool reset);
 int valu_tasks(hx_plan *pl, int spin, hx_plan::TaskSet **ts, int blocks = 0);  // (hx_analysis.hip) task set of the vector-unit kernels (blocks: 32-ring-pair blocks per task, 0 = valu_task_blocks), built on first use
 int synth_valu_max_units(int spin);                // maps (spin 0) / fields (spin 2) per sweep of the synthesis kernel: 1, 2, .. a power of two
 int synth_valu_task_blocks(int spin, int units);   // ring blocks per task of that sweep
-int launch_synth_valu(hx_plan *pl, int spin, int units, hx_plan::TaskSet &ts, const double2 *d_alm, double *d_Fv);  // alm -> Fv[m][rp][4 per component]  // FP64 vector flops executed by the vector-unit kernels since the last reset
+int launch_synth_valu(hx_plan *pl, int spin, int units, hx_plan::TaskSet &ts, const double2 *d_alm, double *d_Fv);
+// hx_synth_duo.hip: up to 20 maps / 10 fields per sweep on the matrix unit; Fv[m][rp][synth_duo_rowlen] in the lane order of that kernel
+int synth_duo_max_units(int spin);
+int synth_duo_rowlen(int spin, int units);
+size_t synth_duo_table_bytes(hx_plan *pl, int spin, int units);
+int launch_synth_duo(hx_plan *pl, int spin, int units, hx_plan::TaskSet &ts, const double2 *d_alm, double *d_tab, double *d_Fv);
+int synth_duo_tasks(hx_plan *pl, int spin, hx_plan::TaskSet **ts);  // (hx_analysis.hip) tasks of 8 (spin 0) / 4 (spin 2) ring blocks: the ring groups of k_legendre_duo  // alm -> Fv[m][rp][4 per component]  // FP64 vector flops executed by the vector-unit kernels since the last reset
 }  // namespace hx

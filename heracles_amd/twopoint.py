@@ -306,6 +306,12 @@ def mixmat_eb(cl, l1max=None, l2max=None, l3max=None, spin=(2, 2), out=None):
     return out
 
 
+def mixmat_release():
+    """Free what ``mixmat`` / ``mixmat_eb`` keep in HBM between calls (the tables of the last (l1max, l2max, l3max) and the staging
+    buffer of a host destination, ~3 GB at L = 6144: hx_mixmat_release)."""
+    _lib.check(_lib.load().hx_mixmat_release())
+
+
 class _NoProgress:
     def update(self, *a):
         pass

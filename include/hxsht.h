@@ -159,6 +159,10 @@ int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double *const *alm
 /* Gauss-Legendre nodes (ascending) and weights; the `gauss_legendre` hook of
  * heracles/transforms.py:25-43. */
 int hx_gauss_legendre(int n, double *x, double *w);
+/* The same with every node as a double-double: node k = x[k] + xlo[k], |xlo[k]| <~ 1e-16.  The mixing-matrix tables are evaluated at
+ * x + xlo: next to the poles d^l(x)' ~ l^2 / 2, and a node rounded to a double shifts a matrix element at l ~ 4000 by 1e-11 of the
+ * largest (tests/test_gpu_mixmat.py::test_mixmat_blocks_at_high_l_vs_3j). */
+int hx_gauss_legendre_dd(int n, double *x, double *w, double *xlo);
 
 /* D[k][l] = d^l_{ab}(x_k), l = 0..lmax, (a,b) in {(0,0),(2,0),(2,2),(2,-2),(1,1),(-1,1)} (zero below max(|a|,|b|));
  * out is [n][lmax+1] row-major.  (Functions of heracles/transforms.py:46-112: P_l, d20, d22, d2m2, d11, dm11.)       */
@@ -170,6 +174,11 @@ int hx_wigner_d_table(int lmax, int a, int b, int n, const double *x, double *ou
 int hx_mixmat(const double *cl, int ncl, int l1max, int l2max, int l3max, int s1, int s2,
               double *out);
 int hx_mixmat_eb(const double *cl, int ncl, int l1max, int l2max, int l3max, double *out);
+/* hx_mixmat / hx_mixmat_eb / hx_mixmat_batch keep the mask-independent part of their last build (nodes and Wigner-d tables of one
+ * (l1max, l2max, l3max)) and the staging buffer of a host destination in HBM between calls (~3 GB at L = 6144), so that the next
+ * build of that size allocates nothing; this frees them.  (The reference rebuilds everything per convolvecl call,
+ * heracles/twopoint.py:378-388.) */
+int hx_mixmat_release(void);
 /* ---- FITS wire format of maps and alms (heracles/io.py:128-218, "next" row) ------------------------------------
  * Payload conversion between a FITS binary table of 'D' columns (row-major, big-endian) and the component-major
  * native arrays of the path, one pass on the GPU; `table` / `array` host or device.

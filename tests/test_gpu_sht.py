@@ -145,18 +145,69 @@ def test_alm2map_batches(oracle, nside, lmax, spin, ncomp):
 
 @pytest.mark.parametrize("spin", [0, 2])
 def test_alm2map_sweeps_of_several_maps_match_single_sweeps(spin):
-    """Four spin-0 maps / two spin-2 fields per synthesis sweep share the recursion (other ring slots per lane, other block
-    lengths): every lane still adds the same terms in the same order, so a batch is bitwise what its maps give one by one."""
+    """Vector-unit synthesis (batches of <= 4 maps / <= 2 fields): four spin-0 maps / two spin-2 fields per sweep share the recursion
+    (other ring slots per lane, other block lengths): every lane still adds the same terms in the same order, so a batch is bitwise
+    what its maps give one by one."""
     import heracles_amd as hx
 
     rng = np.random.default_rng(91 + spin)
     nside, lmax = 128, 200
-    alm = random_alm(rng, lmax, spin, (7,) if spin == 0 else (6,))  # sweeps of 4 + 2 + 1 maps / 2 + 1 fields
+    alm = random_alm(rng, lmax, spin, (4,))  # one sweep of 4 maps / 2 fields
     plan = hx.get_plan(nside, lmax)
     batch = plan.alm2map(alm, spin)
     unit = 1 if spin == 0 else 2
     for c in range(0, alm.shape[0], unit):
         np.testing.assert_array_equal(batch[c : c + unit], plan.alm2map(alm[c : c + unit], spin))
+    three = plan.alm2map(alm[: 3 * unit] if spin == 0 else alm[:2], spin)   # 2 + 1 maps / one field
+    np.testing.assert_array_equal(three, batch[: three.shape[0]])
+
+
+# units = maps (spin 0) / fields (spin 2): every shape of k_synth_duo -- (1,0) (1,1) (1,2) (2,0) (2,1) (2,2) -- with and without
+# padding columns, a second sweep and an evenly split tail
+@pytest.mark.parametrize("spin,units", [(0, 5), (0, 8), (0, 9), (0, 10), (0, 11), (0, 12), (0, 16), (0, 17), (0, 19), (0, 20), (0, 23), (0, 41),
+                                        (2, 3), (2, 4), (2, 5), (2, 6), (2, 7), (2, 8), (2, 9), (2, 10), (2, 11), (2, 13), (2, 21)])
+def test_alm2map_batches_on_the_matrix_unit(oracle, spin, units):
+    """Batched synthesis on the matrix unit (hx_synth_duo.hip: >= 5 maps / >= 3 fields per call) against the oracle's direct sums, and
+    against the same maps / fields synthesised one by one on the vector-unit kernel (1e-12: other orders of summation).  Sizes at which
+    the polar chains start far below 2^-300 (scaled-only blocks, mixed blocks, live blocks), odd l ranges, m = 0, 1 (spin 2: off = 1)."""
+    import heracles_amd as hx
+
+    nside, lmax = (64, 150) if units % 2 else (32, 77)
+    unit = 1 if spin == 0 else 2
+    rng = np.random.default_rng(100 * units + spin)
+    alm = random_alm(rng, lmax, spin, (units * unit,))
+    plan = hx.get_plan(nside, lmax)
+    out = plan.alm2map(alm, spin)
+    assert out.shape == (units * unit, 12 * nside * nside)
+    scale = np.abs(out).max()
+    for u in sorted({0, 1, units // 2, units - 2, units - 1}):
+        sl = slice(u * unit, (u + 1) * unit)
+        close(out[sl], oracle.alm2map(alm[sl], nside, lmax, spin=spin), 1e-11)
+        one = plan.alm2map(alm[sl], spin)
+        assert np.abs(out[sl] - one).max() <= 1e-12 * scale
+    # run-to-run: the kernel has no atomics and no order that depends on timing
+    np.testing.assert_array_equal(out, plan.alm2map(alm, spin))
+
+
+@pytest.mark.parametrize("spin,units", [(0, 10), (2, 5), (2, 10)])
+def test_alm2map_matrix_unit_medium(oracle, spin, units):
+    """The same at nside 256 / lmax 400 (tasks of several ring groups per m, pruned polar rings, chains that become live late): first and
+    last unit against the oracle, every unit against the vector-unit kernel."""
+    import heracles_amd as hx
+
+    nside, lmax = 256, 400
+    unit = 1 if spin == 0 else 2
+    rng = np.random.default_rng(7 * units + spin)
+    alm = random_alm(rng, lmax, spin, (units * unit,))
+    plan = hx.get_plan(nside, lmax)
+    out = plan.alm2map(alm, spin)
+    scale = np.abs(out).max()
+    for u in (0, units - 1):
+        sl = slice(u * unit, (u + 1) * unit)
+        close(out[sl], oracle.alm2map(alm[sl], nside, lmax, spin=spin), 1e-11)
+    for u in range(units):
+        sl = slice(u * unit, (u + 1) * unit)
+        assert np.abs(out[sl] - plan.alm2map(alm[sl], spin)).max() <= 1e-12 * scale
 
 
 @pytest.mark.parametrize("spin", [0, 2])
