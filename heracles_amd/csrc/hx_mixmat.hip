@@ -31,7 +31,7 @@ __global__ void k_gauss_legendre(int n, double *__restrict__ x, double *__restri
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (n + 1) / 2) return;
     double t = cospi((i + 0.75) / (n + 0.5));
-    double dp = 1.0, tl = 0.0, pn = 0.0;
+    double dp = 1.0, tl = 0.0, pn = 0.0, om = 1.0;
     for (int it = 0; it < 10; ++it) {
         double p0 = 1.0, p1 = t;
         for (int k = 2; k <= n; ++k) {
@@ -64,13 +64,14 @@ __global__ void k_gauss_legendre(int n, double *__restrict__ x, double *__restri
             ph0 = ph1; pl0 = pl1;
             ph1 = q1 + q2; pl1 = q2 - (ph1 - q1);
         }
-        dp = n * (t * ph1 - ph0) / (t * t - 1.0);
+        // (1 - t^2 as (1 - t)(1 + t): t * t - 1 loses 7e-10 of its value next to the poles, and the weights with it)
+        om = (1.0 - t) * (1.0 + t);
+        dp = -n * (t * ph1 - ph0) / om;
         pn = ph1 + pl1;
         tl = -pn / dp;
     }
     // the weight belongs to the node t + tl: evaluated at the rounded t it is off by up to 6e-10 next to the poles
     // (d ln w / dx = -2 x / (1 - x^2)); P_n'(t + tl) = P_n' + tl P_n'' with (1 - t^2) P_n'' = 2 t P_n' - n (n + 1) P_n
-    const double om = (1.0 - t) * (1.0 + t);
     const double dps = dp + tl * (2.0 * t * dp - (double)n * (n + 1.0) * pn) / om;
     const double ww = 2.0 / ((om - 2.0 * t * tl) * dps * dps);
     if ((n & 1) && i == n / 2) { t = 0.0; tl = 0.0; }
@@ -81,63 +82,124 @@ __global__ void k_gauss_legendre(int n, double *__restrict__ x, double *__restri
 
 // ---- Wigner-d table: out[l*sl + k*sk] = d^l_{ab}(x_k), l = 0..lmax ----------------------
 // coef[l] = (c1x, c1c, c2): d^{l+1} = (c1x x + c1c) d^l - c2 d^{l-1}
-// xlo (may be null): the node is x + xlo (k_gauss_legendre); the table then holds d^l(x) + xlo d^l'(x), the derivative term carried by a
-// second recurrence e_{l+1} = (c1x x + c1c) e_l - c2 e_{l-1} + c1x xlo d_l (first order in xlo ~ 1e-16 is exact to rounding)
 __global__ void k_wigner_table(int lmax, int a, int b, int n, const double *__restrict__ x,
                                const double4 *__restrict__ coef, double *__restrict__ out,
-                               long long sl, long long sk, const double *__restrict__ xlo)
+                               long long sl, long long sk)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const double xx = x[k], xl = xlo ? xlo[k] : 0.0;
+    const double xx = x[k];
     const int l0 = max(abs(a), abs(b));
-    double d0, e0;  // d^{l0}(x) and xlo times its derivative
-    if (a == 0 && b == 0) { d0 = 1.0; e0 = 0.0; }
-    else if (a == 2 && b == 0) { d0 = 0.61237243569579452455 * (1.0 - xx) * (1.0 + xx); e0 = -2.0 * 0.61237243569579452455 * xx * xl; }
-    else if (a == 2 && b == 2) { d0 = 0.25 * (1.0 + xx) * (1.0 + xx); e0 = 0.5 * (1.0 + xx) * xl; }
-    else if (a == 1 && b == 1) { d0 = 0.5 * (1.0 + xx); e0 = 0.5 * xl; }                    // d^1_{11}   (transforms.py:68-73)
-    else if (a * b == -1) { d0 = 0.5 * (1.0 - xx); e0 = -0.5 * xl; }                        // d^1_{-1,1} = d^1_{1,-1}
-    else { d0 = 0.25 * (1.0 - xx) * (1.0 - xx); e0 = -0.5 * (1.0 - xx) * xl; }  // (2,-2)
+    double d0;
+    if (a == 0 && b == 0) d0 = 1.0;
+    else if (a == 2 && b == 0) d0 = 0.61237243569579452455 * (1.0 - xx) * (1.0 + xx);
+    else if (a == 2 && b == 2) d0 = 0.25 * (1.0 + xx) * (1.0 + xx);
+    else if (a == 1 && b == 1) d0 = 0.5 * (1.0 + xx);                    // d^1_{11}   (transforms.py:68-73)
+    else if (a * b == -1) d0 = 0.5 * (1.0 - xx);                         // d^1_{-1,1} = d^1_{1,-1}
+    else d0 = 0.25 * (1.0 - xx) * (1.0 - xx);  // (2,-2)
     for (int l = 0; l < l0 && l <= lmax; ++l) out[l * sl + k * sk] = 0.0;
     if (l0 > lmax) return;
-    double dp = 0.0, dc = d0, ep = 0.0, ec = e0;
-    out[l0 * sl + k * sk] = dc + ec;
+    double dp = 0.0, dc = d0;
+    out[l0 * sl + k * sk] = dc;
     for (int l = l0; l < lmax; ++l) {
         const double4 c = coef[l];
-        const double t = fma(c.x, xx, c.y);
-        const double dn = fma(t, dc, -c.z * dp);
-        const double en = fma(t, ec, fma(c.x * xl, dc, -c.z * ep));
+        const double dn = fma(fma(c.x, xx, c.y), dc, -c.z * dp);
         dp = dc;
         dc = dn;
-        ep = ec;
-        ec = en;
-        out[(l + 1) * sl + k * sk] = dc + ec;
+        out[(l + 1) * sl + k * sk] = dc;
     }
 }
 
-// ---- s_k = w_k * xi(x_k), xi = sum_l (2l+1)/(4pi) W_l P_l(x) ----------------------------
-// (xlo as in k_wigner_table: xi at the node x + xlo, the derivative term summed on its own)
-__global__ void k_weight_xi(int l3max, int n, const double *__restrict__ x, const double *__restrict__ w,
-                            const double *__restrict__ cl, double *__restrict__ s, const double *__restrict__ xlo)
+// ---- the same tables in double-double arithmetic (the mixing-matrix contexts) -----------------------------------------
+// At l ~ 4000-6000 a table value next to the poles carries ~l^1.5 x 1e-16 of rounding noise from the upward recurrence (every
+// step's rounding error is carried on by a solution that grows like l there), and the noise is alike for the ~100 polar nodes,
+// which carry the whole integrand when the mask's correlation function peaks at theta = 0: 5e-11 on a diagonal element of 10.8 at
+// L = 4096 (with exact nodes and weights; tests/test_gpu_mixmat.py::test_mixmat_blocks_at_high_l_vs_3j).  In double-double the noise is
+// ~1e-32 l^1.5; the coefficients come as (hi, lo) pairs from the host's long doubles, the node as x + xlo.  One thread per node, a
+// dependent chain of ~16 operations per step: ~0.4 ms per table at L = 6144, once per context; the weights xi(x_k) ~0.4 ms per mask.
+struct DD {
+    double h, l;
+};
+__device__ __forceinline__ DD dd_quick(double a, double b)
+{
+#pragma clang fp contract(off)
+    const double s = a + b;
+    return DD{s, b - (s - a)};
+}
+__device__ __forceinline__ DD dd_add(DD a, DD b)
+{
+#pragma clang fp contract(off)
+    const double s = a.h + b.h, bb = s - a.h;
+    const double e = ((a.h - (s - bb)) + (b.h - bb)) + (a.l + b.l);
+    return dd_quick(s, e);
+}
+__device__ __forceinline__ DD dd_mul(DD a, DD b)
+{
+#pragma clang fp contract(off)
+    const double p = a.h * b.h;
+    const double e = fma(a.h, b.h, -p) + (a.h * b.l + a.l * b.h);
+    return dd_quick(p, e);
+}
+__device__ __forceinline__ DD dd_neg(DD a) { return DD{-a.h, -a.l}; }
+
+struct WigCoefDD {
+    double c1xh, c1xl, c1ch, c1cl, c2h, c2l;
+};
+// out[l * sl + k * sk] = d^l_{ab}(x_k + xlo_k), l = 0..lmax; s6: sqrt(6) / 4 as (hi, lo)
+__global__ void k_wigner_table_dd(int lmax, int a, int b, int n, const double *__restrict__ x, const double *__restrict__ xlo,
+                                  const WigCoefDD *__restrict__ coef, double *__restrict__ out, long long sl, long long sk, double s6h,
+                                  double s6l)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const double xx = x[k], xl = xlo ? xlo[k] : 0.0;
-    double p0 = 1.0, p1 = xx, q0 = 0.0, q1 = xl;  // q_l = xlo P_l'(x)
-    double xi = cl[0] * (1.0 / (4.0 * M_PI)), xe = 0.0;
-    if (l3max >= 1) { xi += 3.0 / (4.0 * M_PI) * cl[1] * p1; xe = 3.0 / (4.0 * M_PI) * cl[1] * q1; }
+    const DD xx = dd_quick(x[k], xlo[k]);
+    const DD one = DD{1.0, 0.0};
+    const DD om = dd_add(one, dd_neg(xx)), op = dd_add(one, xx);
+    const int l0 = max(abs(a), abs(b));
+    DD d0;
+    if (a == 0 && b == 0) d0 = one;
+    else if (a == 2 && b == 0) d0 = dd_mul(DD{s6h, s6l}, dd_mul(om, op));
+    else if (a == 2 && b == 2) { d0 = dd_mul(op, op); d0.h *= 0.25; d0.l *= 0.25; }
+    else { d0 = dd_mul(om, om); d0.h *= 0.25; d0.l *= 0.25; }  // (2,-2)
+    for (int l = 0; l < l0 && l <= lmax; ++l) out[l * sl + k * sk] = 0.0;
+    if (l0 > lmax) return;
+    DD dp = DD{0.0, 0.0}, dc = d0;
+    out[l0 * sl + k * sk] = dc.h + dc.l;
+    for (int l = l0; l < lmax; ++l) {
+        const WigCoefDD c = coef[l];
+        const DD t = dd_add(dd_mul(DD{c.c1xh, c.c1xl}, xx), DD{c.c1ch, c.c1cl});
+        const DD dn = dd_add(dd_mul(t, dc), dd_neg(dd_mul(DD{c.c2h, c.c2l}, dp)));
+        dp = dc;
+        dc = dn;
+        out[(l + 1) * sl + k * sk] = dc.h + dc.l;
+    }
+}
+
+// s_k = w_k xi(x_k + xlo_k), xi = sum_l (2 l + 1) / (4 pi) W_l P_l, P_l and the sum in double-double (the integer coefficients of
+// l P_l = (2 l - 1) x P_{l-1} - (l - 1) P_{l-2} are exact)
+__global__ void k_weight_xi_dd(int l3max, int n, const double *__restrict__ x, const double *__restrict__ xlo, const double *__restrict__ w,
+                               const double *__restrict__ cl, double *__restrict__ s)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const DD xx = dd_quick(x[k], xlo[k]);
+    DD p0 = DD{1.0, 0.0}, p1 = xx;
+    DD xi = DD{cl[0] * (1.0 / (4.0 * M_PI)), 0.0};
+    if (l3max >= 1) xi = dd_add(xi, dd_mul(DD{3.0 / (4.0 * M_PI) * cl[1], 0.0}, p1));
     for (int l = 2; l <= l3max; ++l) {
-        const double p2 = ((2.0 * l - 1.0) * xx * p1 - (l - 1.0) * p0) / l;
-        const double q2 = ((2.0 * l - 1.0) * (xx * q1 + xl * p1) - (l - 1.0) * q0) / l;
+        const DD num = dd_add(dd_mul(DD{2.0 * l - 1.0, 0.0}, dd_mul(xx, p1)), dd_neg(dd_mul(DD{l - 1.0, 0.0}, p0)));
+        // num / l: quotient of the high part, exact remainder, quotient of the rest
+        DD p2;
+        {
+#pragma clang fp contract(off)
+            const double q1 = num.h / l, r = fma(-q1, (double)l, num.h), q2 = (r + num.l) / l;
+            p2 = dd_quick(q1, q2);
+        }
         p0 = p1;
         p1 = p2;
-        q0 = q1;
-        q1 = q2;
-        const double f = (2.0 * l + 1.0) / (4.0 * M_PI) * cl[l];
-        xi = fma(f, p2, xi);
-        xe = fma(f, q2, xe);
+        xi = dd_add(xi, dd_mul(DD{(2.0 * l + 1.0) / (4.0 * M_PI) * cl[l], 0.0}, p2));
     }
-    s[k] = w[k] * (xi + xe);
+    s[k] = w[k] * (xi.h + xi.l);
 }
 
 // ---- symmetric GEMM: G[i][j] = colscale[j] * sum_k T[i][k] s[k] T[j][k] -----------------
@@ -519,6 +581,24 @@ static void wigner_coefs(int lmax, int a, int b, std::vector<double4> &c)
     }
 }
 
+static void wigner_coefs_dd(int lmax, int a, int b, std::vector<WigCoefDD> &c)
+{
+    c.assign(lmax + 1, WigCoefDD{0, 0, 0, 0, 0, 0});
+    auto split = [](long double v, double &h, double &l) {
+        h = (double)v;
+        l = (double)(v - (long double)h);
+    };
+    for (int l = 0; l <= lmax; ++l) {
+        if (l == 0) { c[l].c1xh = 1.0; continue; }
+        long double dl = l, lp = l + 1.0L;
+        long double den = dl * sqrtl((lp * lp - (long double)a * a) * (lp * lp - (long double)b * b));
+        if (den == 0.0L) continue;
+        split((2 * dl + 1) * dl * lp / den, c[l].c1xh, c[l].c1xl);
+        split(-(2 * dl + 1) * (long double)a * b / den, c[l].c1ch, c[l].c1cl);
+        split(lp * sqrtl((dl * dl - (long double)a * a) * (dl * dl - (long double)b * b)) / den, c[l].c2h, c[l].c2l);
+    }
+}
+
 int launch_gauss_legendre(int n, double *d_x, double *d_w, double *d_xlo)
 {
     const int half = (n + 1) / 2;
@@ -623,16 +703,18 @@ static int mix_ctx_table(MixCtx &c, int t)
 {
     if (c.have[t]) return HX_OK;
     hipStream_t st = rt().stream;
-    std::vector<double4> coef;
-    wigner_coefs(c.L, kAB[t][0], kAB[t][1], coef);
+    std::vector<WigCoefDD> coef;
+    wigner_coefs_dd(c.L, kAB[t][0], kAB[t][1], coef);
     DevBuf d_coef;
     HX_TRY(upload_vec(d_coef, coef));
     HX_TRY(c.T[t].alloc(sizeof(double) * (size_t)c.rows_pad * c.kpad));
     HX_HIP(hipMemsetAsync(c.T[t].p, 0, sizeof(double) * (size_t)c.rows_pad * c.kpad, st));
     {
         ProfScope ps("wigner_tables");
-        hipLaunchKernelGGL(k_wigner_table, dim3((c.n + 63) / 64), dim3(64), 0, st, c.L, kAB[t][0], kAB[t][1], c.n,
-                           c.gl.x.as<double>(), d_coef.as<double4>(), c.T[t].as<double>(), (long long)c.kpad, 1LL, c.gl.xlo.as<double>());
+        const long double s6 = sqrtl(6.0L) / 4.0L;
+        const double s6h = (double)s6, s6l = (double)(s6 - (long double)s6h);
+        hipLaunchKernelGGL(k_wigner_table_dd, dim3((c.n + 63) / 64), dim3(64), 0, st, c.L, kAB[t][0], kAB[t][1], c.n, c.gl.x.as<double>(),
+                           c.gl.xlo.as<double>(), d_coef.as<WigCoefDD>(), c.T[t].as<double>(), (long long)c.kpad, 1LL, s6h, s6l);
     }
     HX_HIP(hipStreamSynchronize(st));  // d_coef dies with this scope
     c.have[t] = true;
@@ -644,8 +726,8 @@ static int mix_ctx_mask(MixCtx &c, const double *d_cl)
 {
     hipStream_t st = rt().stream;
     HX_HIP(hipMemsetAsync(c.s.p, 0, sizeof(double) * c.kpad, st));
-    hipLaunchKernelGGL(k_weight_xi, dim3((c.n + 255) / 256), dim3(256), 0, st, c.l3max, c.n, c.gl.x.as<double>(), c.gl.w.as<double>(),
-                       d_cl, c.s.as<double>(), c.gl.xlo.as<double>());
+    hipLaunchKernelGGL(k_weight_xi_dd, dim3((c.n + 63) / 64), dim3(64), 0, st, c.l3max, c.n, c.gl.x.as<double>(), c.gl.xlo.as<double>(),
+                       c.gl.w.as<double>(), d_cl, c.s.as<double>());
     HX_HIP(hipGetLastError());
     return HX_OK;
 }
@@ -881,7 +963,7 @@ extern "C" int hx_wigner_d_table(int lmax, int a, int b, int n, const double *x,
     {
         ProfScope ps("wigner_tables");
         hipLaunchKernelGGL(k_wigner_table, dim3((n + 63) / 64), dim3(64), 0, rt().stream, lmax, a, b, n, vx.as<double>(),
-                           d_coef.as<double4>(), vo.as<double>(), 1LL, (long long)(lmax + 1), (const double *)nullptr);
+                           d_coef.as<double4>(), vo.as<double>(), 1LL, (long long)(lmax + 1));
     }
     HX_HIP(hipGetLastError());
     HX_TRY(vo.finish());

@@ -15,8 +15,36 @@ def test_gauss_legendre(oracle):
         x, w = hx.gauss_legendre(n)
         xo, wo = oracle.gauss_legendre(n)
         np.testing.assert_allclose(x, xo, atol=3e-16 * 4)
-        np.testing.assert_allclose(w, wo, rtol=5e-10)  # end-point weights amplify node rounding by ~n^2
+        np.testing.assert_allclose(w, wo, rtol=2e-12)  # (the weights belong to the nodes x + xlo: evaluated at the rounded x the end-point ones are 6e-10 off)
         assert abs(w.sum() - 2) < 1e-12
+
+
+def test_gauss_legendre_double_double_nodes(oracle):
+    """hx_gauss_legendre_dd: node k = x[k] + xlo[k].  x is the oracle's node (long-double Newton, rounded) to an ulp, |xlo| stays below
+    an ulp of 1, and P_n(x + xlo) vanishes to first order: P_n(x) + xlo P_n'(x) ~ 1e-16 x the size P_n(x) has at a node that is only
+    known to a double (checked in long double)."""
+    import ctypes  # noqa: F401
+
+    import heracles_amd as hx
+    from heracles_amd import _lib
+
+    hx.init()
+    for n in (7, 155, 1000, 6145):
+        x, w, xlo = np.empty(n), np.empty(n), np.empty(n)
+        _lib.check(_lib.load().hx_gauss_legendre_dd(n, _lib.ptr(x), _lib.ptr(w), _lib.ptr(xlo)))
+        xo, wo = oracle.gauss_legendre(n)
+        np.testing.assert_allclose(x, xo, atol=2.3e-16)
+        assert np.abs(xlo).max() <= 2.3e-16
+        np.testing.assert_allclose(w, wo, rtol=2e-12)
+        ld = np.longdouble
+        t = x.astype(ld)
+        p0, p1 = np.ones_like(t), t.copy()
+        for k in range(1, n):
+            p0, p1 = p1, ((2 * k + 1) * t * p1 - k * p0) / (k + 1)
+        dp = n * (t * p1 - p0) / (t * t - 1)
+        resid = np.abs((p1 + xlo.astype(ld) * dp).astype(np.float64))     # P_n(x + xlo), first order
+        plain = np.abs(p1.astype(np.float64))                             # P_n(x)
+        assert resid.max() <= 1e-3 * max(plain.max(), 1e-300) + 1e-17 * np.abs(dp.astype(np.float64)).max(), (n, resid.max(), plain.max())
 
 
 @pytest.mark.parametrize("ab", [(0, 0), (2, 0), (2, 2), (2, -2)])
