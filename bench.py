@@ -38,7 +38,7 @@ if ROOT not in sys.path:
 
 FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 matrix (= vector) peak
 HBM_PEAK_GBS = 8000.0
-PROFILE_ROUND = "r04"    # profiles/<round>_traffic.json holds the committed PMC passes of THIS round's kernels
+PROFILE_ROUND = "r05"    # profiles/<round>_traffic.json holds the committed PMC passes of THIS round's kernels
 
 
 def parse():
@@ -62,6 +62,7 @@ def parse():
     p.add_argument("--no-host-leg", action="store_true", help="skip the host -> host (PCIe-inclusive) measurement")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--no-single", action="store_true", help="skip the single-map transform timings")
+    p.add_argument("--no-niter3", action="store_true", help="skip the niter = 3 leg (the 20-map job with healpy's default iterations)")
     p.add_argument("--launch-check", action="store_true", help="every rank checks its rendezvous variables and exits (rank 0 prints them); no GPU is touched")
     p.add_argument("--generic-weights", action="store_true", help="pixel weights without the symmetry of healpy's files (generic path of the ring kernels)")
     return p.parse_args()
@@ -358,11 +359,14 @@ def main():
         sec = ms_ * 1e-3
         exe = (mf + vf) * steps1 / sec / 1e12 if sec > 0 else 0.0
         traffic, tpath = pmc_traffic("hx::k_legendre_duo<%d" % spin)
-        return {"kernel": kernel, "bound": "mfma", "achieved": exe, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": exe / FP64_PEAK_TFLOPS,
-                "achieved_is": "EXECUTED FP64 flops, counted by the kernel itself (matrix instructions actually issued -- stages whose "
-                               "rings are all below 2^-300 skip theirs -- + 4 flops per generated lambda_lm on the vector unit) / kernel time; "
-                               "the two share one FP64 pipe (peak 78.6 either way); equals the SQ_INSTS_VALU_MFMA_F64-based figure of profiles/",
+        mfx = mf * steps1 / sec / 1e12 if sec > 0 else 0.0
+        return {"kernel": kernel, "bound": "mfma", "achieved": mfx, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": mfx / FP64_PEAK_TFLOPS,
+                "achieved_is": "EXECUTED FP64 flops of the MATRIX instructions the kernel issued, counted by the kernel itself (stages whose rings are "
+                               "all below 2^-300 skip theirs) / kernel time: the figure SQ_VALU_MFMA_BUSY_CYCLES of profiles/ gives (busy cycles x 32 flop; "
+                               "0.72 of the pipe's cycles at 2.38 GHz).  The recursion's vector flops share the same FP64 pipe and are reported beside it "
+                               "(executed_valu_tflops, frac_incl_vector), not added",
+                "frac_incl_vector": exe / FP64_PEAK_TFLOPS,
                 "task_list_mfma_tflops": mf_model * steps1 / sec / 1e12 if sec > 0 else 0.0,
                 "executed_mfma_tflops": mf * steps1 / sec / 1e12 if sec > 0 else 0.0,
                 "executed_valu_tflops": vf * steps1 / sec / 1e12 if sec > 0 else 0.0,
@@ -568,6 +572,34 @@ def main():
             oa0, oa2, tim, stride = osample
             cpu = cpu_baseline(nside, lmax, per_set.count(0), per_set.count(2), oa0, oa2, tim, stride)
 
+        # ---- the same 20-map job with the mapper's own default, healpy's iter = 3 (HipHealpixMapper(niter=3): three Jacobi iterations =
+        # three batched syntheses + three more analyses per transform; the reference passes no iter, heracles/healpy.py:183-189).
+        # Informational: `value` is the niter = 0 job SURVEY 8d prescribes. ----
+        niter3 = None
+        if world == 1 and not args.no_niter3:
+            def step3():
+                if n2:
+                    plan.map2alm(maps2.view(2 * n2, npix), 2, pix_weights=pw, out=alm2.view(2 * n2, nlm), niter=3)
+                if n0:
+                    plan.map2alm(maps0, 0, pix_weights=pw, out=alm0, niter=3)
+                return work.all_pairs_cl()
+
+            step3()
+            hx._lib.profile_enable(True)
+            hx._lib.profile_reset()
+            d3, _ = timed(step3, 2, 0)
+            hx._lib.profile_enable(False)
+            k3 = {}
+            for k in ("ring_fft", "fourier_combine", "legendre_analysis", "legendre_synthesis", "legendre_synth_duo", "synth_table", "alm_reduce", "alm2cl"):
+                n_, ms_ = hx._lib.profile_get(k)
+                k3[k] = {"launches": n_, "ms_per_step": ms_ / 2.0}
+            niter3 = {"value": npairs * 2 / d3, "unit": "map->Cl pairs/s", "ms_per_step": d3 / 2 * 1e3, "steps": 2, "kernels": k3,
+                      "what": "the timed job with niter = 3 (the mapper's default, healpy's iter): per transform 4 analyses + 3 syntheses; batched "
+                              "synthesis on the matrix unit (k_synth_duo, round 5), residuals formed in the scatter pass"}
+            # (restore the niter = 0 alms the verification below looks at)
+            step()
+            torch.cuda.synchronize()
+
         # ---- the reference's own call shape: ONE map / ONE field per transform (heracles/mapping.py:171), resident inputs; with
         # niter = 0 (weights supplied) and with healpy's default three Jacobi iterations; one alm2map.  Informational: not `value`.
         single = None
@@ -713,6 +745,7 @@ def main():
             "weak_scaling": weak,
             "value_host_to_host": host_leg["value"] if host_leg else None,
             "host_to_host": host_leg,
+            "niter3": niter3,
             "single_map_transforms": single,
             "mixmat_build_sec": mix["seconds"] if mix else None,
             "mixmat": mix,

@@ -1836,7 +1836,19 @@ bool analysis_can_stream(hx_plan *pl, int spin, int nb)
     const double p_bytes = 0.5 * (pl->lmax + 1.0) * (pl->lmax + 2.0 + LBLK) * sweep_pcol(sh) * sizeof(double);
     double budget = 80e9;
     if (scratch_budget_bytes() > 0.0) budget = scratch_budget_bytes();
-    return f_bytes + p_bytes <= budget;
+    if (f_bytes + p_bytes > budget) return false;
+    // ... and what the streamed sweep holds beside them -- Y of the whole sweep and two staging buffers of whole maps -- must fit the HBM
+    // that is free now plus what this plan already holds in those buffers (on a device with less free memory the plan's
+    // allocations failed and the call with them; the caller now falls back to the capped sweeps of whole maps, a few GB each)
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const double y_bytes = (double)pl->ny * nb * sizeof(double2), stage_bytes = 2.0 * nb * (double)pl->npix * sizeof(double);
+    const double held = (double)pl->F.bytes + (double)pl->partial.bytes + (double)pl->Y.bytes + (double)pl->stage[0].bytes + (double)pl->stage[1].bytes +
+                        (double)pl->stage[2].bytes;
+    return f_bytes + p_bytes + y_bytes + stage_bytes <= 0.95 * ((double)fr + held);
 }
 
 int analysis_stream_plan(hx_plan *pl, int spin, int nb, int nslab, StreamSweep &s)

@@ -83,8 +83,11 @@ __global__ __launch_bounds__(256) void k_svd_gram(const double *__restrict__ W, 
 // square roots of the rotation between two barriers, one wave per SIMD.)
 // offmax (one double, as ordered integer bits): max over all pairs of |G_ij| / sqrt(G_ii G_jj) BEFORE the diagonalisation -- the
 // convergence measure of the outer (one-sided) iteration.
+// null2: squared norm below which a column counts as numerically zero for that measure (1e-30 of the matrix' squared Frobenius norm:
+// sigma / sigma_max < 1e-15 sqrt(n)) -- the null columns of a rank-deficient matrix are rounding noise, any two of them "parallel" at
+// O(1), and the measure never fell below the tolerance: such inputs ran all 60 sweeps (and, since round 5, would be refused)
 __global__ __launch_bounds__(256) void k_svd_eig(const double *__restrict__ G, double *__restrict__ Qout, unsigned long long *__restrict__ offmax,
-                                                 int max_sweeps, double stop_below)
+                                                 int max_sweeps, double stop_below, double null2)
 {
     __shared__ __attribute__((aligned(16))) double A[SP][SLD], QT[SP][SLD];
     __shared__ double2 rot[SB];   // (c, s) of the round's rotations
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void k_svd_eig(const double *__restrict__ G, d
             const int i = e >> 6, j = e & 63;
             if (i < j) {
                 const double d = A[i][i] * A[j][j];
-                if (d > 0.0) mx = fmax(mx, fabs(A[i][j]) / sqrt(d));
+                if (d > 0.0 && A[i][i] > null2 && A[j][j] > null2) mx = fmax(mx, fabs(A[i][j]) / sqrt(d));
             }
         }
         atomicMax(&lmax_bits, (unsigned long long)__double_as_longlong(mx));
@@ -342,14 +345,26 @@ extern "C" int hx_pinv(int n, int m, const double *M, double rcond, double *out,
     const char *e_in = getenv("HX_SVD_INNER");
     const int inner_sweeps = e_in ? std::max(1, atoi(e_in)) : 1;
     const double inner_stop = 1e-8;   // (a sweep that met nothing above 1e-8 leaves nothing above 1e-16: quadratic convergence)
+    // squared Frobenius norm (invariant under the rotations): the scale of "numerically zero" columns in the convergence measure
+    hipLaunchKernelGGL(k_svd_colnorm2, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, st, W.as<double>(), ld, nw, (int)ld, d_s.as<double>());
+    double fro2 = 0.0;
+    {
+        std::vector<double> c2(ld);
+        HX_HIP(hipMemcpyAsync(c2.data(), d_s.p, sizeof(double) * ld, hipMemcpyDeviceToHost, st));
+        HX_HIP(hipStreamSynchronize(st));
+        for (double v : c2) fro2 += v;
+    }
+    const double null2 = 1e-30 * fro2;
     int sweeps = 0;
+    bool converged = false;
+    double last_off = 0.0;
     for (; sweeps < 60; ++sweeps) {
         HX_HIP(hipMemsetAsync(d_off.p, 0, sizeof(unsigned long long), st));
         for (int r = 0; r < nsteps; ++r) {
             const int2 *pr = d_pairs.as<int2>() + (size_t)r * npair;
             HX_HIP(hipMemsetAsync(G.p, 0, sizeof(double) * (size_t)npair * SP * SP, st));
             hipLaunchKernelGGL(k_svd_gram, dim3(npair, wchunks), dim3(256), 0, st, W.as<double>(), ld, nw, pr, rpc, G.as<double>());
-            hipLaunchKernelGGL(k_svd_eig, dim3(npair), dim3(256), 0, st, G.as<double>(), Q.as<double>(), d_off.as<unsigned long long>(), inner_sweeps, inner_stop);
+            hipLaunchKernelGGL(k_svd_eig, dim3(npair), dim3(256), 0, st, G.as<double>(), Q.as<double>(), d_off.as<unsigned long long>(), inner_sweeps, inner_stop, null2);
             hipLaunchKernelGGL(k_svd_rotate, dim3(npair, std::max(wchunks, vchunks), 2), dim3(256), 0, st, W.as<double>(), nw, V.as<double>(), (int)ld, ld, pr, rpc,
                                Q.as<double>());
         }
@@ -360,8 +375,13 @@ extern "C" int hx_pinv(int n, int m, const double *M, double rcond, double *out,
         double off;
         memcpy(&off, &bits, sizeof(off));
         if (getenv("HX_TRACE")) fprintf(stderr, "[hx] pinv: sweep %d, largest |G_ij| / sqrt(G_ii G_jj) = %.3e\n", sweeps, off);
-        if (off < tol) { ++sweeps; break; }
+        last_off = off;
+        if (off < tol) { ++sweeps; converged = true; break; }
     }
+    // (a pseudo-inverse from columns that are not orthogonal yet is silently wrong -- 60 sweeps are three times what the
+    // hardest spectrum tried needs, tools/time_pinv.py; running out of them is an error, not a result)
+    if (!converged)
+        return fail(HX_ERR_UNSUPPORTED, "hx_pinv: the Jacobi sweeps did not converge (%d sweeps, largest |G_ij| / sqrt(G_ii G_jj) = %.3e, tolerance %.3e)", sweeps, last_off, tol);
     // singular values, cut-off, pinv = V diag(mask / sigma^2) W^T
     hipLaunchKernelGGL(k_svd_colnorm2, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, st, W.as<double>(), ld, nw, (int)ld, d_s.as<double>());
     std::vector<double> s2(ld);

@@ -421,8 +421,11 @@ def read_vmap(filename, nside=None, field=0, *, transform=False, lmax=None, pixw
     divided by the pixel window (``hx_map2alm`` with ``fl = 1 / pw``).
 
     Not in the reference's signature, because healpy's data files are not available here: ``pixwin=(pw_T, pw_P)`` (the window table; else
-    healpy's, if installed), ``datapath`` (directory of healpy's weight files; without one the quadrature uses unit weights and
-    ``niter`` Jacobi iterations -- healpy's ``map2alm`` default is three)."""
+    healpy's, if installed), ``datapath`` (directory of healpy's weight files; without one the quadrature uses unit weights), ``niter``
+    (Jacobi iterations -- healpy's ``map2alm`` default of three, which the reference's call does not override: heracles/io.py:377).
+    ONE rule for this function and ``HipHealpixMapper.transform``: ``niter`` is passed through unchanged whether or not a weight file
+    is used, so the two give the same alms for the same map, weights and window (tests/test_gpu_widen.py; which of weights + 0 or
+    weights + 3 iterations healpy itself runs is parity-unpinned: healpy is not importable here)."""
     from warnings import warn
 
     from .mapper import pixel_window, ud_grade
@@ -463,5 +466,5 @@ def read_vmap(filename, nside=None, field=0, *, transform=False, lmax=None, pixw
         if datapath is not None and weights is None:
             raise FileNotFoundError(f"no pixel-weight file for NSIDE={nside_t} under datapath {datapath!r}")
         plan = sht.get_plan(nside_t, lmax_t)
-        vmap = plan.map2alm(vmap[None], 0, pix_weights=weights, fl=1.0 / pw, niter=0 if weights is not None else niter)[0]
+        vmap = plan.map2alm(vmap[None], 0, pix_weights=weights, fl=1.0 / pw, niter=niter)[0]
     return vmap

@@ -206,7 +206,9 @@ int hx_matvec(int n, int m, const double *M, int nvec, const double *x, double *
 /* np.linalg.pinv(M, rcond) as heracles.twopoint.invert_mixing_matrix calls it (heracles/twopoint.py:447-460): out (m x n) = pseudo-inverse
  * of M (n x m, row-major), singular values <= rcond * the largest are dropped.  Blocked one-sided Jacobi SVD on the GPU (Gram matrices of
  * column-block pairs, their 64 x 64 eigenproblems in LDS, rotations), the final product on the FP64 matrix unit.  M / out host or device;
- * info (nullable, 4 doubles on the host): sweeps, singular values kept, largest, smallest kept.                               */
+ * info (nullable, 4 doubles on the host): sweeps, singular values kept, largest, smallest kept.  Fails (HX_ERR_UNSUPPORTED, nothing
+ * written to out) if the sweeps run out before the columns are orthogonal to rounding.  Unlike hx_matvec / hx_alm2cl_pairs the result
+ * is NOT bitwise repeatable run to run: the Gram sums are unordered f64 atomics (differences at the 1e-16 level of the sums).       */
 int hx_pinv(int n, int m, const double *M, double rcond, double *out, double *info);
 
 typedef struct hx_mixctx hx_mixctx;

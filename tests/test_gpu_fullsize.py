@@ -66,11 +66,11 @@ def test_analysis_is_the_adjoint_of_synthesis(plan, spin):
 
 @pytest.mark.parametrize("spin", [0, 2])
 def test_synthesis_sweeps_of_several_maps_full_size(plan, spin):
-    """The multi-map shapes of the synthesis kernel at nside 4096 (four spin-0 maps / two spin-2 fields share one recursion):
-    bitwise equal to the single-map sweeps, which the adjointness test above ties to the analysis."""
+    """The multi-map shapes of the vector-unit synthesis kernel at nside 4096 (four spin-0 maps / two spin-2 fields share one
+    recursion): bitwise equal to the single-map sweeps, which the adjointness test above ties to the analysis."""
     import torch
 
-    nc = 5 if spin == 0 else 6  # sweeps of 4 + 1 maps / 2 + 1 fields
+    nc = 4  # one sweep of 4 maps / 2 fields (larger batches run on the matrix unit: next test)
     a = _random_alm(torch, nc, 31 + spin, lmin=spin)
     y = torch.empty((nc, NPIX), dtype=torch.float64, device="cuda")
     plan.alm2map(a, spin, out=y)
@@ -79,6 +79,33 @@ def test_synthesis_sweeps_of_several_maps_full_size(plan, spin):
     for c in (0, nc - unit):
         plan.alm2map(a[c : c + unit], spin, out=one)
         assert torch.equal(one, y[c : c + unit])
+    assert bool(torch.isfinite(y).all())
+
+
+@pytest.mark.parametrize("spin,units", [(0, 10), (2, 10), (2, 5), (0, 20)])
+def test_matrix_unit_synthesis_full_size(plan, spin, units):
+    """Batched synthesis on the matrix unit (k_synth_duo, round 5) at nside 4096 / lmax 6144 in the shapes the Jacobi iterations of the
+    bench's job use (ten maps, ten fields) and two more: first, middle and last unit against the single-unit sweeps of the vector-unit
+    kernel (other order of summation: 1e-12 of the largest pixel), which the adjointness and closed-form tests of this file tie to the
+    analysis and to an independent recursion; bitwise repeatable (no atomics, no order that depends on timing)."""
+    import torch
+
+    unit = 1 if spin == 0 else 2
+    nc = units * unit
+    a = _random_alm(torch, nc, 57 + spin + units, lmin=spin)
+    y = torch.empty((nc, NPIX), dtype=torch.float64, device="cuda")
+    plan.alm2map(a, spin, out=y)
+    scale = float(y.abs().max())
+    one = torch.empty((unit, NPIX), dtype=torch.float64, device="cuda")
+    worst = 0.0
+    for u in (0, units // 2, units - 1):
+        plan.alm2map(a[u * unit : (u + 1) * unit], spin, out=one)
+        worst = max(worst, float((one - y[u * unit : (u + 1) * unit]).abs().max()))
+    assert worst <= 1e-12 * scale, worst / scale
+    y2 = torch.empty_like(y)
+    plan.alm2map(a, spin, out=y2)
+    assert torch.equal(y, y2)
+    del y2
     assert bool(torch.isfinite(y).all())
 
 

@@ -573,3 +573,28 @@ def test_host_maps_streamed_in_slabs_of_rings_are_bit_identical(nside, lmax):
     for i, s in enumerate(spins):
         want = r0[i // 2] if s == 0 else r2[2 * (i // 2):2 * (i // 2) + 2]
         np.testing.assert_array_equal(np.asarray(out[i]).reshape(want.shape), want)
+
+
+def test_host_maps_fall_back_to_whole_map_sweeps_when_a_streamed_sweep_does_not_fit():
+    """a streamed sweep holds F and the accumulation rows of all orders, Y of the whole sweep and two staging buffers.  When
+    that does not fit (here: a scratch budget of 1 MB; on a device: the HBM that is free) the call must not fail -- host maps then go
+    through the capped sweeps of whole maps, whose sums differ from the resident sweep's by rounding only."""
+    import torch
+
+    import heracles_amd as hx
+    from heracles_amd import _lib
+
+    nside, lmax = 64, 100
+    rng = np.random.default_rng(77)
+    npix = 12 * nside**2
+    plan = hx.get_plan(nside, lmax)
+    m = rng.standard_normal((20, npix))
+    ref = plan.map2alm(torch.as_tensor(m).cuda(), 2).cpu().numpy()
+    streamed = plan.map2alm(m, 2)
+    np.testing.assert_array_equal(streamed, ref)
+    _lib.set_scratch_budget(1e6)
+    try:
+        small = plan.map2alm(m, 2)                     # (m-chunked, whole maps in sweeps of five fields)
+    finally:
+        _lib.set_scratch_budget(0)
+    assert np.abs(small - ref).max() <= 1e-12 * np.abs(ref).max()

@@ -252,3 +252,23 @@ def test_pinv_edge_cases():
     np.testing.assert_allclose(pinv(a, 0.5), np.linalg.pinv(a, rcond=0.5), atol=1e-12)
     with pytest.raises(hx.HxError):
         hx._lib.check(hx._lib.load().hx_pinv(3, 3, hx._lib.ptr(np.eye(3)), -1.0, hx._lib.ptr(np.eye(3)), None))
+
+
+@pytest.mark.parametrize("niter", [0, 3])
+def test_read_vmap_transform_equals_mapper_transform_with_a_weight_file(tmp_path, niter):
+    """one rule for ``read_vmap(transform=True, datapath=)`` and ``HipHealpixMapper(datapath=).transform`` -- ``niter`` passed
+    through unchanged beside the weight file -- so the same map, weights and window give the same alms through both doors."""
+    import heracles_amd as hx
+    from heracles_amd import weights as hxw
+
+    nside, lmax = 16, 30
+    rng = np.random.default_rng(5 + niter)
+    npix = 12 * nside**2
+    m = rng.uniform(0.0, 1.0, npix)
+    hxw.write_compressed_weights(tmp_path / hxw.weights_filename(nside), nside, 1e-2 * rng.standard_normal(hxw.compressed_size(nside)))
+    path = tmp_path / "vmap.fits"
+    _write_healpix_table(path, [m], nside, ordering="RING", width=8)
+    pw = (np.linspace(1.0, 0.8, lmax + 1), np.linspace(1.0, 0.7, lmax + 1))
+    alm = hx.read_vmap(path, transform=True, lmax=lmax, pixwin=pw, datapath=tmp_path, niter=niter)
+    mapper = hx.HipHealpixMapper(nside, lmax, deconvolve=True, niter=niter, datapath=tmp_path, pixwin=pw)
+    np.testing.assert_array_equal(alm, np.asarray(mapper.transform(m, spin=0)))
