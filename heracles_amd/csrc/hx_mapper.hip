@@ -14,7 +14,7 @@
 // and on the pix2ang round trip of every pixel centre (tests/test_gpu_mapper.py).
 #include "hx_common.h"
 
-#include <rocprim/rocprim.hpp>
+#include "hx_sort.h"
 
 namespace hx {
 
@@ -98,14 +98,15 @@ __global__ __launch_bounds__(256) void k_ang2pix(long long nside, long long n, c
 }
 
 // one thread per sorted position; the first position of each run of equal pixels owns it
-__global__ __launch_bounds__(256) void k_run_add(long long n, const long long *__restrict__ pix_sorted,
+template <class PIX>
+__global__ __launch_bounds__(256) void k_run_add(long long n, const PIX *__restrict__ pix_sorted,
                                                  const unsigned *__restrict__ idx_sorted, int nval,
                                                  const double *__restrict__ values, long long vstride,
                                                  double *__restrict__ maps, long long npix)
 {
     long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
-    long long p = pix_sorted[s];
+    const PIX p = pix_sorted[s];
     if (s > 0 && pix_sorted[s - 1] == p) return;
     long long e = s + 1;
     while (e < n && pix_sorted[e] == p) ++e;
@@ -336,6 +337,9 @@ extern "C" int hx_map_values(int nside, int64_t n, const double *lon, const doub
         dmaps = mtmp.as<double>();
     }
     DevBuf bpix, bord, bpix2, bord2, btmp;
+    long long *spix64 = nullptr;
+    unsigned *spix = nullptr;    // the sorted (pixel, point index) pairs: whichever buffers the last pass wrote (keys narrowed to 32 bits)
+    unsigned *sord = nullptr;
     HX_TRY(bpix.alloc(sizeof(long long) * n));
     const bool ordered = !(flags & HX_MAP_ATOMIC);
     unsigned blocks = (unsigned)((n + 255) / 256);
@@ -350,19 +354,22 @@ extern "C" int hx_map_values(int nside, int64_t n, const double *lon, const doub
         HX_TRY(bord2.alloc(sizeof(unsigned) * n));
         unsigned end_bit = 1;
         while ((1ll << end_bit) < npix) ++end_bit;
-        size_t tbytes = 0;
         ProfScope ps("map_sort");
-        HX_HIP(rocprim::radix_sort_pairs(nullptr, tbytes, bpix.as<long long>(), bpix2.as<long long>(), bord.as<unsigned>(),
-                                         bord2.as<unsigned>(), (size_t)n, 0u, end_bit, st));
-        HX_TRY(btmp.alloc(tbytes ? tbytes : 16));
-        HX_HIP(rocprim::radix_sort_pairs(btmp.p, tbytes, bpix.as<long long>(), bpix2.as<long long>(), bord.as<unsigned>(),
-                                         bord2.as<unsigned>(), (size_t)n, 0u, end_bit, st));
+        if (end_bit <= 32) {
+            // pixel indices fit 32 bits (nside <= 16384): the first pass narrows the keys, bpix2 holds the two 32-bit key buffers of the later passes
+            HX_TRY(rsort::radix_sort_pairs_narrow(bpix.as<long long>(), bord.as<unsigned>(), bpix2.as<unsigned>(), bpix2.as<unsigned>() + n, bord2.as<unsigned>(),
+                                                  (unsigned long long)n, (int)end_bit, btmp, st, &spix, &sord));
+        } else {
+            HX_TRY(rsort::radix_sort_pairs<long long>(bpix.as<long long>(), bord.as<unsigned>(), bpix2.as<long long>(), bord2.as<unsigned>(),
+                                                      (unsigned long long)n, (int)end_bit, btmp, st, &spix64, &sord));
+        }
     }
     {
         ProfScope ps("map_add");
-        if (ordered)
-            hipLaunchKernelGGL(k_run_add, dim3(blocks), dim3(256), 0, st, (long long)n, bpix2.as<long long>(),
-                               bord2.as<unsigned>(), nval, vval.as<double>(), (long long)n, dmaps, npix);
+        if (ordered && spix64)
+            hipLaunchKernelGGL(k_run_add<long long>, dim3(blocks), dim3(256), 0, st, (long long)n, spix64, sord, nval, vval.as<double>(), (long long)n, dmaps, npix);
+        else if (ordered)
+            hipLaunchKernelGGL(k_run_add<unsigned>, dim3(blocks), dim3(256), 0, st, (long long)n, spix, sord, nval, vval.as<double>(), (long long)n, dmaps, npix);
         else
             hipLaunchKernelGGL(k_scatter_atomic, dim3(blocks), dim3(256), 0, st, (long long)n, bpix.as<long long>(), nval,
                                vval.as<double>(), (long long)n, dmaps, npix);

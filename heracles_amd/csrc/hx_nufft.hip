@@ -28,7 +28,7 @@
 
 #include "hx_sht_common.h"
 
-#include <rocprim/rocprim.hpp>
+#include "hx_sort.h"
 
 using namespace hx;
 using namespace hxfft;
@@ -379,6 +379,7 @@ extern "C" int hx_pointsht_adjoint(hx_pointsht *ps, int spin, int ncomp, int64_t
     if (const char *e = getenv("HX_NUFFT_TILES")) tiles = atoi(e) != 0;
     if (npoints == 0 || npoints > 0xfffffff0ll) tiles = false;
     const int ntx = n1 / NUFFT_TS + 1, nty = (n1 / 2 + W + NUFFT_TPAD) / NUFFT_TS + 1;
+    unsigned *skey = nullptr, *sidx = nullptr;  // the sorted (tile key, point index) pairs
     if (tiles) {
         ProfScope pf("nufft_sort");
         HX_TRY(ps->key.alloc(sizeof(unsigned) * (size_t)npoints));
@@ -388,13 +389,9 @@ extern "C" int hx_pointsht_adjoint(hx_pointsht *ps, int spin, int ncomp, int64_t
         const long long nblk = std::min<long long>((npoints + 255) / 256, 1 << 20);
         hipLaunchKernelGGL(k_nufft_keys, dim3((unsigned)nblk), dim3(256), 0, st, (long long)npoints, vloc.as<double2>(), n1, W, ntx,
                            ps->key.as<unsigned>(), ps->idx.as<unsigned>(), ps->nbad.as<unsigned long long>());
-        const unsigned end_bit = 32;  // all bits: invalid points carry the key 0xffffffff
-        size_t tbytes = 0;
-        HX_HIP(rocprim::radix_sort_pairs(nullptr, tbytes, ps->key.as<unsigned>(), ps->key2.as<unsigned>(), ps->idx.as<unsigned>(),
-                                         ps->idx2.as<unsigned>(), (size_t)npoints, 0u, end_bit, st));
-        HX_TRY(ps->sort_tmp.alloc(tbytes ? tbytes : 16));
-        HX_HIP(rocprim::radix_sort_pairs(ps->sort_tmp.p, tbytes, ps->key.as<unsigned>(), ps->key2.as<unsigned>(), ps->idx.as<unsigned>(),
-                                         ps->idx2.as<unsigned>(), (size_t)npoints, 0u, end_bit, st));
+        // all 32 bits: invalid points carry the key 0xffffffff
+        HX_TRY(rsort::radix_sort_pairs<unsigned>(ps->key.as<unsigned>(), ps->idx.as<unsigned>(), ps->key2.as<unsigned>(), ps->idx2.as<unsigned>(),
+                                                 (unsigned long long)npoints, 32, ps->sort_tmp, st, &skey, &sidx));
     }
     for (int c0 = 0, nb = 0; c0 < ncomp; c0 += nb) {
         nb = analysis_next_batch(spin, ncomp - c0);
@@ -404,8 +401,7 @@ extern "C" int hx_pointsht_adjoint(hx_pointsht *ps, int spin, int ncomp, int64_t
                 HX_HIP(hipMemsetAsync(ps->grid.p, 0, sizeof(double) * (size_t)n1 * n1, st));
                 if (tiles) {
                     hipLaunchKernelGGL(k_nufft_spread_tiles, dim3((unsigned)(ntx * nty)), dim3(256), 0, st, (long long)npoints,
-                                       vloc.as<double2>(), vmap.as<double>() + (size_t)(c0 + c) * npoints, ps->key2.as<unsigned>(),
-                                       ps->idx2.as<unsigned>(), ps->grid.as<double>(), n1, W, ps->beta, ntx,
+                                       vloc.as<double2>(), vmap.as<double>() + (size_t)(c0 + c) * npoints, skey, sidx, ps->grid.as<double>(), n1, W, ps->beta, ntx,
                                        ps->nbad.as<unsigned long long>());
                 } else if (npoints > 0) {
                     const long long nblk = std::min<long long>((npoints + 255) / 256, 1 << 20);
