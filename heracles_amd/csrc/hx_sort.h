@@ -1,5 +1,6 @@
-// hx_sort.h -- stable LSD radix sort of (key, 32-bit value) pairs on the GPU, 8-bit digits (round 5: the library primitive that sorted here until round 4 is gone
-// on the two "next" rows that sort: catalogue points by pixel (hx_mapper.hip, heracles/healpy.py:144-160) and by LDS tile (hx_nufft.hip)).
+// hx_sort.h -- stable LSD radix sort of (key, 32-bit value) pairs on the GPU, 8-bit digits.  Round 5: written for the two "next" rows that
+// sort -- catalogue points by pixel (hx_mapper.hip, heracles/healpy.py:144-160) and by LDS tile (hx_nufft.hip) --, which called a library
+// primitive until round 4.
 //
 // Per pass:  k_sort_hist     per tile of 4096 keys a 256-bin histogram (LDS atomics), written bin-major: counts[digit][tile];
 //            k_scan_*        exclusive scan over the 256 x tiles counts (block sums, one block over the sums, apply);
