@@ -737,10 +737,10 @@ __global__ __launch_bounds__(512) void k_ring_subdft_split(PlanDev P, const int 
 // Zc[c][startN + k] = conj(X_N + i X_S).  The values of four consecutive ring pairs at one m share a 128-byte line: a group
 // takes four ring pairs (thread = (ring pair, component, k)).
 __global__ __launch_bounds__(256) void k_synth_spectrum_v(PlanDev P, const double *__restrict__ Fv, int nc, int lmax,
-                                                          double2 *__restrict__ Zc, const int *__restrict__ mlim)
+                                                          double2 *__restrict__ Zc, const int *__restrict__ mlim, int rp_hi)
 {
     const int rp = blockIdx.x * 4 + (threadIdx.x & 3), rest = threadIdx.x >> 2;
-    if (rp >= P.nrp) return;
+    if (rp >= P.nrp || rp >= rp_hi) return;  // (ring pairs from rp_hi on: k_synth_spectrum_t)
     // nc <= 64 components side by side (nc need not divide 64: the threads left over have nothing to do)
     const int c = rest % nc, kk = rest / nc, kstep = (int)(blockDim.x >> 2) / nc;
     if (kk >= kstep) return;
@@ -779,6 +779,55 @@ __global__ __launch_bounds__(256) void k_synth_spectrum_v(PlanDev P, const doubl
         double2 *z = Zc + (long long)c * P.ny + P.startN[rp];
         z[k] = cconj(cadd(cadd(an, cconj(bn)), mul_pi(cadd(as, cconj(bs)))));
         if (k2 != k) z[k2] = cconj(cadd(cadd(bn, cconj(an)), mul_pi(cadd(bs, cconj(as)))));
+    }
+}
+
+// The same for ring pairs with 4 n >= 2 lmax + 2 pixels per ring (round 5; at nside 4096 / lmax 6144: 5120 of the 8192 ring pairs, 73 % of
+// the pixels): no two orders fall on one bin, so the pass is a TRANSPOSITION -- bin m = conj(Ft_N + i Ft_S), bin nphi - m =
+// conj(conj Ft_N + i conj Ft_S), zeros between lmax and nphi - lmax -- and goes through LDS: a block takes one ring pair and 64
+// orders, reads their rows of Fv (nc x 32 contiguous bytes each), and writes, per component, two runs of 64 consecutive bins.  The
+// gather above walks the orders per bin with one or two 32-byte reads in flight per thread and scatters 16-byte writes: 48 ms for the
+// twenty components of ten fields against ~16 ms of traffic at copy rate.
+constexpr int SPT_M = 64;
+__global__ __launch_bounds__(256) void k_synth_spectrum_t(PlanDev P, const double *__restrict__ Fv, int nc, int lmax, double2 *__restrict__ Zc,
+                                                          const int *__restrict__ mlim, int rp_lo)
+{
+    extern __shared__ double2 spt[];  // [2][nc][SPT_M]: the bins m and nphi - m of the block's orders
+    const int rp = rp_lo + blockIdx.x;
+    const int n = P.nsub[rp], nphi = 4 * n, m0 = blockIdx.y * SPT_M;
+    if (2 * m0 > nphi) return;  // (orders beyond nphi / 2 belong to the mirrored run of another block)
+    const bool shifted = P.shifted[rp] != 0;
+    const int mtop = mlim ? min(lmax, mlim[rp]) : lmax;
+    const long long mstride = (long long)P.nrp_pad * 4 * nc;
+    const double *row = Fv + (long long)rp * 4 * nc;
+    // element e = (order j of the tile, component c): 32 contiguous bytes; consecutive threads take consecutive components of an order
+    for (int e = threadIdx.x; e < SPT_M * nc; e += blockDim.x) {
+        const int j = e / nc, c = e % nc, m = m0 + j;
+        double2 z1 = make_double2(0.0, 0.0), z2 = z1;
+        if (m <= mtop) {
+            const double2 *b = reinterpret_cast<const double2 *>(row + m * mstride + 4 * c);
+            double2 fn = b[0], fs = b[1];
+            if (shifted) {
+                const double2 ph = expipi((double)(m % (2 * nphi)) / (double)nphi);
+                fn = cmul(fn, ph);
+                fs = cmul(fs, ph);
+            }
+            if (m == 0) {  // c_0 / 2 = 1 / 2 and both sums meet in bin 0
+                z1 = cconj(cadd(make_double2(fn.x, 0.0), mul_pi(make_double2(fs.x, 0.0))));
+            } else {
+                z1 = cconj(cadd(fn, mul_pi(fs)));
+                z2 = cconj(cadd(cconj(fn), mul_pi(cconj(fs))));
+            }
+        }
+        spt[c * SPT_M + j] = z1;
+        spt[(nc + c) * SPT_M + j] = z2;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < SPT_M * nc; e += blockDim.x) {
+        const int c = e / SPT_M, j = e % SPT_M, m = m0 + j;
+        double2 *z = Zc + (long long)c * P.ny + P.startN[rp];
+        if (2 * m <= nphi) z[m] = spt[c * SPT_M + j];
+        if (m > 0 && 2 * m < nphi) z[nphi - m] = spt[(nc + c) * SPT_M + j];
     }
 }
 
@@ -1255,8 +1304,21 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
             double2 *zc = reinterpret_cast<double2 *>(reinterpret_cast<char *>(pl->F.p) + fv_pad);
             HX_TRY(launch_synth_duo(pl, spin, units, *ts, d_alms + (size_t)u0 * cpu * pl->nlm, pl->syn_tab.as<double>(), fv));
             ProfScope ps("ring_fft");
-            hipLaunchKernelGGL(k_synth_spectrum_v, dim3((pl->nrp + 3) / 4), dim3(256), 0, st, P, fv, nc, pl->lmax, zc,
-                               (spin ? pl->syn_mlim2 : pl->syn_mlim0).as<int>());
+            {
+                // ring pairs whose rings hold every order in a bin of its own go through the transposing pass, the polar ones through the gather
+                const int *ml = (spin ? pl->syn_mlim2 : pl->syn_mlim0).as<int>();
+                int rp_t = pl->nrp;
+                static const bool use_t = !(getenv("HX_SYNTH_SPECTRUM") && !strcmp(getenv("HX_SYNTH_SPECTRUM"), "gather"));
+                if (use_t)
+                    while (rp_t > 0 && 4 * pl->h_nsub[rp_t - 1] >= 2 * pl->lmax + 2) --rp_t;
+                if (rp_t > 0)
+                    hipLaunchKernelGGL(k_synth_spectrum_v, dim3((rp_t + 3) / 4), dim3(256), 0, st, P, fv, nc, pl->lmax, zc, ml, rp_t);
+                if (rp_t < pl->nrp) {
+                    const int nphi_max = 4 * pl->h_nsub[pl->nrp - 1];
+                    const dim3 grid(pl->nrp - rp_t, (nphi_max / 2 + SPT_M) / SPT_M);
+                    hipLaunchKernelGGL(k_synth_spectrum_t, grid, dim3(256), sizeof(double2) * 2 * nc * SPT_M, st, P, fv, nc, pl->lmax, zc, ml, rp_t);
+                }
+            }
             HX_TRY(launch_subdft_classes<1>(pl, nc, nullptr, nullptr, zc, pl->Y.as<double2>()));
             hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, nc), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps + (size_t)u0 * cpu * pl->npix, d_ref ? 1 : 0,
                                d_ref ? d_ref + (size_t)u0 * cpu * pl->npix : nullptr);
@@ -1279,7 +1341,7 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
         HX_TRY(launch_synth_valu(pl, spin, units, *ts, d_alms + (size_t)c0 * pl->nlm, pl->Fsyn.as<double>()));
         ProfScope ps("ring_fft");
         hipLaunchKernelGGL(k_synth_spectrum_v, dim3((pl->nrp + 3) / 4), dim3(256), 0, st, P, pl->Fsyn.as<double>(), nc, pl->lmax, pl->resid.as<double2>(),
-                           (const int *)nullptr);
+                           (const int *)nullptr, pl->nrp);
         HX_TRY(launch_subdft_classes<1>(pl, nc, nullptr, nullptr, pl->resid.as<double2>(), pl->Y.as<double2>()));
         hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, nc), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps + (size_t)c0 * pl->npix, d_ref ? 1 : 0,
                            d_ref ? d_ref + (size_t)c0 * pl->npix : nullptr);
