@@ -796,8 +796,8 @@ struct MixCache {
 };
 static MixCache &mix_cache()
 {
-    static MixCache c;
-    return c;
+    static MixCache *c = new MixCache;  // (never destroyed: its buffers must not be freed behind the HIP runtime's back at process exit)
+    return *c;
 }
 static void mix_cache_drop()
 {

@@ -1275,6 +1275,35 @@ static bool synth_duo_enabled()
     return on;
 }
 
+// small batches: one sweep of the vector-unit kernel per four maps / two fields (they share the recursion), then the rest
+static int synthesis_batch_valu(hx_plan *pl, int spin, int nb, const double2 *d_alms, double *d_maps, const double *d_ref)
+{
+    hipStream_t st = rt().stream;
+    const int cpu = spin ? 2 : 1;
+    PlanDev P = pl->dev();
+    const int umax = synth_valu_max_units(spin);
+    HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * cpu * umax));
+    HX_TRY(pl->resid.alloc(sizeof(double2) * (size_t)pl->ny * cpu * umax));  // conj(Z) spectra
+    HX_TRY(pl->Fsyn.alloc(sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * 4 * cpu * umax));
+    for (int c0 = 0; c0 < nb;) {
+        int units = umax;
+        while (units * cpu > nb - c0) units >>= 1;
+        const int nc = units * cpu;
+        hx_plan::TaskSet *ts = nullptr;
+        HX_TRY(valu_tasks(pl, spin, &ts, synth_valu_task_blocks(spin, units)));
+        HX_TRY(launch_synth_valu(pl, spin, units, *ts, d_alms + (size_t)c0 * pl->nlm, pl->Fsyn.as<double>()));
+        ProfScope ps("ring_fft");
+        hipLaunchKernelGGL(k_synth_spectrum_v, dim3((pl->nrp + 3) / 4), dim3(256), 0, st, P, pl->Fsyn.as<double>(), nc, pl->lmax, pl->resid.as<double2>(),
+                           (const int *)nullptr, pl->nrp);
+        HX_TRY(launch_subdft_classes<1>(pl, nc, nullptr, nullptr, pl->resid.as<double2>(), pl->Y.as<double2>()));
+        hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, nc), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps + (size_t)c0 * pl->npix, d_ref ? 1 : 0,
+                           d_ref ? d_ref + (size_t)c0 * pl->npix : nullptr);
+        c0 += nc;
+    }
+    HX_HIP(hipGetLastError());
+    return HX_OK;
+}
+
 static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms, double *d_maps,
                            const double *d_ref)
 {
@@ -1289,10 +1318,29 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
         const int umax = synth_duo_max_units(spin);
         hx_plan::TaskSet *ts = nullptr;
         HX_TRY(synth_duo_tasks(pl, spin, &ts));
+        // what a sweep of `units` holds: ring modes + ring spectra (in F), Y, the B-operand table
+        auto sweep_bytes = [&](int units) {
+            const double nc = (double)units * cpu;
+            return sizeof(double) * (double)(pl->lmax + 1) * pl->nrp_pad * synth_duo_rowlen(spin, units) + 2.0 * sizeof(double2) * (double)pl->ny * nc +
+                   (double)synth_duo_table_bytes(pl, spin, units);
+        };
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = 0; }
+        double avail = 0.92 * ((double)fr + (double)pl->F.bytes + (double)pl->Y.bytes + (double)pl->syn_tab.bytes);
+        if (scratch_budget_bytes() > 0.0) avail = std::min(avail, scratch_budget_bytes());  // (hx_set_scratch_budget bounds this scratch too)
         for (int u0 = 0; u0 < nunits_all;) {
             int units = std::min(umax, nunits_all - u0);
             // (a remainder of one or two units would run a whole sweep of the matrix kernel for 4-8 columns: split the tail evenly instead)
             if (nunits_all - u0 > umax && nunits_all - u0 < umax + (spin ? 3 : 5)) units = (nunits_all - u0 + 1) / 2;
+            // a sweep that does not fit the free HBM (nside 8192: 213 + 129 GB for ten fields) is cut down; below the matrix kernel's
+            // smallest useful batch the rest goes to the vector-unit kernel's sweeps of four maps / two fields
+            while (units > 1 && sweep_bytes(units) > avail) --units;
+            if (units < (spin ? 3 : 5) && sweep_bytes(units) > avail) units = 0;
+            if (units < (spin ? 3 : 5) && (units == 0 || nunits_all - u0 >= (spin ? 3 : 5))) {
+                HX_TRY(synthesis_batch_valu(pl, spin, (nunits_all - u0) * cpu, d_alms + (size_t)u0 * cpu * pl->nlm, d_maps + (size_t)u0 * cpu * pl->npix,
+                                            d_ref ? d_ref + (size_t)u0 * cpu * pl->npix : nullptr));
+                break;
+            }
             const int nc = units * cpu, rowlen = synth_duo_rowlen(spin, units);
             const size_t fv_bytes = sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * rowlen;
             const size_t zc_bytes = sizeof(double2) * (size_t)pl->ny * nc;
@@ -1327,28 +1375,7 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
         HX_HIP(hipGetLastError());
         return HX_OK;
     }
-    // small batches: one sweep of the vector-unit kernel per four maps / two fields (they share the recursion), then the rest
-    const int umax = synth_valu_max_units(spin);
-    HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * cpu * umax));
-    HX_TRY(pl->resid.alloc(sizeof(double2) * (size_t)pl->ny * cpu * umax));  // conj(Z) spectra
-    HX_TRY(pl->Fsyn.alloc(sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * 4 * cpu * umax));
-    for (int c0 = 0; c0 < nb;) {
-        int units = umax;
-        while (units * cpu > nb - c0) units >>= 1;
-        const int nc = units * cpu;
-        hx_plan::TaskSet *ts = nullptr;
-        HX_TRY(valu_tasks(pl, spin, &ts, synth_valu_task_blocks(spin, units)));
-        HX_TRY(launch_synth_valu(pl, spin, units, *ts, d_alms + (size_t)c0 * pl->nlm, pl->Fsyn.as<double>()));
-        ProfScope ps("ring_fft");
-        hipLaunchKernelGGL(k_synth_spectrum_v, dim3((pl->nrp + 3) / 4), dim3(256), 0, st, P, pl->Fsyn.as<double>(), nc, pl->lmax, pl->resid.as<double2>(),
-                           (const int *)nullptr, pl->nrp);
-        HX_TRY(launch_subdft_classes<1>(pl, nc, nullptr, nullptr, pl->resid.as<double2>(), pl->Y.as<double2>()));
-        hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, nc), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps + (size_t)c0 * pl->npix, d_ref ? 1 : 0,
-                           d_ref ? d_ref + (size_t)c0 * pl->npix : nullptr);
-        c0 += nc;
-    }
-    HX_HIP(hipGetLastError());
-    return HX_OK;
+    return synthesis_batch_valu(pl, spin, nb, d_alms, d_maps, d_ref);
 }
 
 static int check_sht_args(hx_plan *pl, int spin, int ncomp, const void *a, const void *b)

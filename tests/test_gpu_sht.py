@@ -598,3 +598,30 @@ def test_host_maps_fall_back_to_whole_map_sweeps_when_a_streamed_sweep_does_not_
     finally:
         _lib.set_scratch_budget(0)
     assert np.abs(small - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("spin", [0, 2])
+def test_matrix_unit_synthesis_sweeps_shrink_to_the_memory_there_is(oracle, spin):
+    """A sweep of the batched synthesis holds ring modes, ring spectra, Y and its operand table (213 + 129 GB for ten fields at nside
+    8192): it is cut to what fits (here: the scratch budget), and below the matrix kernel's smallest batch the vector-unit kernel takes
+    the rest -- never an allocation failure.  Results: the full sweep's to rounding."""
+    import heracles_amd as hx
+    from heracles_amd import _lib
+
+    nside, lmax = 64, 150
+    unit = 1 if spin == 0 else 2
+    units = 12 if spin == 0 else 10
+    rng = np.random.default_rng(400 + spin)
+    alm = random_alm(rng, lmax, spin, (units * unit,))
+    plan = hx.get_plan(nside, lmax)
+    full = plan.alm2map(alm, spin)
+    close(full[:unit], oracle.alm2map(alm[:unit], nside, lmax, spin=spin), 1e-11)
+    scale = np.abs(full).max()
+    # bytes of a sweep of u units at this size: ring modes (lmax + 1) nrp_pad 4 nc 8 + two arrays of ny nc 16 + the table
+    for budget in (6e6, 2.5e6, 1e5):            # ~ 6 units, ~ 2-3 units, nothing: vector-unit kernel
+        _lib.set_scratch_budget(budget)
+        try:
+            got = plan.alm2map(alm, spin)
+        finally:
+            _lib.set_scratch_budget(0)
+        assert np.abs(got - full).max() <= 1e-12 * scale, budget
