@@ -355,7 +355,9 @@ extern "C" int hx_map_values(int nside, int64_t n, const double *lon, const doub
         unsigned end_bit = 1;
         while ((1ll << end_bit) < npix) ++end_bit;
         ProfScope ps("map_sort");
-        if (end_bit <= 32) {
+        // HX_SORT_WIDE=1 (tests): the 64-bit path that nside > 16384 takes, at any size
+        static const bool force_wide = getenv("HX_SORT_WIDE") && getenv("HX_SORT_WIDE")[0] == '1';
+        if (end_bit <= 32 && !force_wide) {
             // pixel indices fit 32 bits (nside <= 16384): the first pass narrows the keys, bpix2 holds the two 32-bit key buffers of the later passes
             HX_TRY(rsort::radix_sort_pairs_narrow(bpix.as<long long>(), bord.as<unsigned>(), bpix2.as<unsigned>(), bpix2.as<unsigned>() + n, bord2.as<unsigned>(),
                                                   (unsigned long long)n, (int)end_bit, btmp, st, &spix, &sord));

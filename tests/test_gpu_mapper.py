@@ -449,3 +449,33 @@ def test_transform_many_takes_device_maps_and_warns_like_transform(oracle):
         warnings.simplefilter("ignore")
         out = hx.transform(fields, {("POS", 0): torch.as_tensor(t).cuda()})
     np.testing.assert_allclose(out["POS", 0].cpu().numpy(), r0, atol=1e-11 * np.abs(r0).max())
+
+
+def test_map_values_wide_keys_path_in_a_child_process(tmp_path):
+    """Pixel indices beyond 32 bits (nside > 16384) keep 64-bit keys through every pass of the sort (hx_sort.h: radix_sort_pairs<long long>);
+    HX_SORT_WIDE=1 sends an ordinary catalogue down that path: order-exact like the narrowed one (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+from oracle import hxoracle as ho
+from heracles_amd.mapper import map_values
+nside = 16
+rng = np.random.default_rng(8)
+n = 70001
+lon = rng.uniform(0, 360, n); lat = np.degrees(np.arcsin(rng.uniform(-1, 1, n)))
+lon[:9000] = 77.0; lat[:9000] = 12.0
+vals = rng.standard_normal((2, n)) * 10.0 ** rng.integers(-6, 6, (2, n))
+exp = np.zeros((2, 12 * nside**2)); got = exp.copy()
+ho.map_values(nside, lon, lat, exp, vals)
+map_values(nside, lon, lat, got, vals)
+assert np.array_equal(got, exp)
+print("wide ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HX_SORT_WIDE="1"), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "wide ok" in res.stdout, res.stderr[-1500:]
