@@ -159,9 +159,10 @@ int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double *const *alm
 /* Gauss-Legendre nodes (ascending) and weights; the `gauss_legendre` hook of
  * heracles/transforms.py:25-43. */
 int hx_gauss_legendre(int n, double *x, double *w);
-/* The same with every node as a double-double: node k = x[k] + xlo[k], |xlo[k]| <~ 1e-16.  The mixing-matrix tables are evaluated at
- * x + xlo: next to the poles d^l(x)' ~ l^2 / 2, and a node rounded to a double shifts a matrix element at l ~ 4000 by 1e-11 of the
- * largest (tests/test_gpu_mixmat.py::test_mixmat_blocks_at_high_l_vs_3j). */
+/* The same with every node as a double-double: node k = x[k] + xlo[k], |xlo[k]| <~ 1e-16.  The tables behind hx_mixmat / hx_mixmat_eb
+ * (convolvecl.mixmat / mixmat_eb at heracles/twopoint.py:378-388) are evaluated at x + xlo: next to the poles d^l(x)' ~ l^2 / 2, and a
+ * node rounded to a double shifts a matrix element at l ~ 4000 by 1e-11 of the largest
+ * (tests/test_gpu_mixmat.py::test_mixmat_blocks_at_high_l_vs_3j). */
 int hx_gauss_legendre_dd(int n, double *x, double *w, double *xlo);
 
 /* D[k][l] = d^l_{ab}(x_k), l = 0..lmax, (a,b) in {(0,0),(2,0),(2,2),(2,-2),(1,1),(-1,1)} (zero below max(|a|,|b|));
