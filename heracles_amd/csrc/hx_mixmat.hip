@@ -1118,21 +1118,21 @@ extern "C" int hx_mixmat_batch(int nmask, const double *cls, int ncl, int l1max,
         HX_TRY(mix_ctx_mask(c, d_cl.as<double>()));
         if (kinds[k] & 1) {
             OutView vo;
-            HX_TRY(vo.bind(out00[k], sizeof(double) * sz));
+            HX_TRY(mix_bind_out(vo, out00[k], sizeof(double) * sz));
             HX_TRY(mix_ctx_product(c, 0, vo.as<double>()));
             HX_TRY(vo.finish());
             HX_HIP(hipStreamSynchronize(rt().stream));
         }
         if (kinds[k] & 2) {
             OutView vo;
-            HX_TRY(vo.bind(out02[k], sizeof(double) * sz));
+            HX_TRY(mix_bind_out(vo, out02[k], sizeof(double) * sz));
             HX_TRY(mix_ctx_product(c, 1, vo.as<double>()));
             HX_TRY(vo.finish());
             HX_HIP(hipStreamSynchronize(rt().stream));
         }
         if (kinds[k] & 4) {
             OutView vo;
-            HX_TRY(vo.bind(outeb[k], sizeof(double) * 3 * sz));
+            HX_TRY(mix_bind_out(vo, outeb[k], sizeof(double) * 3 * sz));
             HX_TRY(mix_eb_into(c, vo));
             HX_HIP(hipStreamSynchronize(rt().stream));
         }
@@ -1180,7 +1180,7 @@ extern "C" int hx_mixctx_apply(hx_mixctx *x, const double *cl, int ncl, int kind
     HX_TRY(stage_cl(cl, ncl, c.l3max, d_cl));
     HX_TRY(mix_ctx_mask(c, d_cl.as<double>()));
     OutView vo;
-    HX_TRY(vo.bind(out, sizeof(double) * sz * (kind == 4 ? 3 : 1)));
+    HX_TRY(mix_bind_out(vo, out, sizeof(double) * sz * (kind == 4 ? 3 : 1)));  // (the staging buffer of a host destination is kept between calls)
     if (kind == 4) {
         HX_TRY(mix_eb_into(c, vo));
     } else {
