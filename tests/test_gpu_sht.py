@@ -590,8 +590,13 @@ def test_host_maps_fall_back_to_whole_map_sweeps_when_a_streamed_sweep_does_not_
     plan = hx.get_plan(nside, lmax)
     m = rng.standard_normal((20, npix))
     ref = plan.map2alm(torch.as_tensor(m).cuda(), 2).cpu().numpy()
+    import os
+
     streamed = plan.map2alm(m, 2)
-    np.testing.assert_array_equal(streamed, ref)
+    if os.environ.get("HX_LEG_KERNEL") == "pipe":  # (the A/B kernel of rounds 2-3 takes host maps in whole-map sweeps: equal to rounding only)
+        assert np.abs(streamed - ref).max() <= 1e-12 * np.abs(ref).max()
+    else:
+        np.testing.assert_array_equal(streamed, ref)
     _lib.set_scratch_budget(1e6)
     try:
         small = plan.map2alm(m, 2)                     # (m-chunked, whole maps in sweeps of five fields)
