@@ -44,6 +44,13 @@ constexpr int SB = HX_SYN_SB;
 #ifndef HX_SYN_PRIO
 #define HX_SYN_PRIO 1
 #endif
+#ifndef HX_SYN_QLDS
+// 1: the additive recursion coefficient q' of a step comes from a wave-private LDS table (a broadcast read instead of the row-broadcast
+// move: 2 vector instructions per step instead of 3).  Measured and not kept (same device, two runs each): ten fields 330.6 against
+// 319.8 ms, eight 281 / 269, five 175 / 172, ten spin-0 maps 90.1 / 88.1 -- the recursion is bound by the latency of its dependent
+// chain, not by the number of vector instructions, and an LDS trip per step lengthens the chain
+#define HX_SYN_QLDS 0
+#endif
 #ifndef HX_SYN_ABL
 #define HX_SYN_ABL 0  // timing experiments only: 1 no matrix instructions, 2 no recursion
 #endif
@@ -164,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void k_synth_duo(SynDuoParams A, const doub
     static_assert(NG >= 1 && NG <= 2 && NBX >= 0 && NBX <= 2 && NP <= 512, "shape");
     __shared__ double tile[NW][64 * 16];  // 8 KiB per wave
     __shared__ double tab[2][SB][RD];     // <= 40 KiB: two stages of SB blocks
+    __shared__ double qtab[NW][SLB];      // HX_SYN_QLDS: q' of the block's 16 steps, per wave
     const PlanDev &P = A.P;
     const LegTask task = A.tasks[blockIdx.x];
     const int m = task.m, lmax = P.lmax;
@@ -221,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void k_synth_duo(SynDuoParams A, const doub
     // the 16 steps of a block; cl = this lane's coefficient pair (p', q') of step (lane & 15): wave-uniform per step, taken by row broadcast
     auto recursion = [&](auto RMM, const double2 cl) __attribute__((always_inline)) {
         constexpr int RM = decltype(RMM)::value;
+        if (HX_SYN_QLDS && lane < SLB) qtab[w][lane] = cl.y;  // (read back by this wave only: LDS operations of a wave execute in order)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             double cur[8];
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void k_synth_duo(SynDuoParams A, const doub
                 const int kk = 8 * h + k;
                 double tq = 0.0;
                 switch (kk) {
-#define HX_BC(K) case K: tq = syn_row_bcast_fmac<K>(syn_row_bcast<K>(cl.y), cl.x, xx); break;
+#define HX_BC(K) case K: tq = syn_row_bcast_fmac<K>(HX_SYN_QLDS ? qtab[w][K] : syn_row_bcast<K>(cl.y), cl.x, xx); break;
                     HX_BC(0) HX_BC(1) HX_BC(2) HX_BC(3) HX_BC(4) HX_BC(5) HX_BC(6) HX_BC(7)
                     HX_BC(8) HX_BC(9) HX_BC(10) HX_BC(11) HX_BC(12) HX_BC(13) HX_BC(14) HX_BC(15)
 #undef HX_BC
