@@ -53,6 +53,16 @@ def test_no_cpu_fallback_without_gpu():
     m = heracles_amd.HipHealpixMapper(4, 4, deconvolve=False)
     with pytest.raises(heracles_amd.HxError):
         m.transform(m.create(), spin=0)
+    # round 5's entry points: page-locked memory, the mixing-matrix cache, double-double nodes
+    with pytest.raises(heracles_amd.HxError):
+        heracles_amd.pinned_empty((4, 4))
+    with pytest.raises(heracles_amd.HxError):
+        heracles_amd.mixmat_eb(np.ones(4), out=np.empty((3, 4, 4)))
+    with pytest.raises(heracles_amd.HxError):
+        heracles_amd.MixmatContext(3, 3, 3)
+    x = np.empty(5)
+    assert heracles_amd._lib.load().hx_gauss_legendre_dd(5, heracles_amd._lib.ptr(x), heracles_amd._lib.ptr(x.copy()), heracles_amd._lib.ptr(x.copy())) == -2
+    assert heracles_amd._lib.load().hx_mixmat_gemm_clock() == 0.0
 
 
 def test_product_never_imports_oracle():
