@@ -1123,7 +1123,7 @@ extern "C" int64_t hx_plan_scratch_bytes(const hx_plan *pl)
 {
     if (!pl) return 0;
     return (int64_t)(pl->stage[0].bytes + pl->stage[1].bytes + pl->stage[2].bytes + pl->resid_maps.bytes + pl->Y.bytes + pl->F.bytes + pl->partial.bytes + pl->rec0.bytes + pl->rec2.bytes + pl->cn0.bytes + pl->al0.bytes + pl->cn2.bytes + pl->al2.bytes +
-                     pl->bhat.bytes + pl->resid.bytes + pl->Fsyn.bytes);
+                     pl->bhat.bytes + pl->syn_tab.bytes);
 }
 
 extern "C" int hx_plan_last_chunks(const hx_plan *pl) { return pl ? pl->last_chunks : 0; }
@@ -1283,19 +1283,22 @@ static int synthesis_batch_valu(hx_plan *pl, int spin, int nb, const double2 *d_
     PlanDev P = pl->dev();
     const int umax = synth_valu_max_units(spin);
     HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * cpu * umax));
-    HX_TRY(pl->resid.alloc(sizeof(double2) * (size_t)pl->ny * cpu * umax));  // conj(Z) spectra
-    HX_TRY(pl->Fsyn.alloc(sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * 4 * cpu * umax));
+    // ring modes and ring spectra live in the analysis' operand buffer F, as in the batched path (F is idle during a synthesis, and a plan
+    // that has run a batched synthesis holds most of the HBM in it already: separate buffers failed to allocate at nside 8192)
+    const size_t fv_pad = (sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * 4 * cpu * umax + 255) & ~(size_t)255;
+    HX_TRY(pl->F.alloc(fv_pad + sizeof(double2) * (size_t)pl->ny * cpu * umax));
+    double *fsyn = pl->F.as<double>();
+    double2 *zc = reinterpret_cast<double2 *>(reinterpret_cast<char *>(pl->F.p) + fv_pad);
     for (int c0 = 0; c0 < nb;) {
         int units = umax;
         while (units * cpu > nb - c0) units >>= 1;
         const int nc = units * cpu;
         hx_plan::TaskSet *ts = nullptr;
         HX_TRY(valu_tasks(pl, spin, &ts, synth_valu_task_blocks(spin, units)));
-        HX_TRY(launch_synth_valu(pl, spin, units, *ts, d_alms + (size_t)c0 * pl->nlm, pl->Fsyn.as<double>()));
+        HX_TRY(launch_synth_valu(pl, spin, units, *ts, d_alms + (size_t)c0 * pl->nlm, fsyn));
         ProfScope ps("ring_fft");
-        hipLaunchKernelGGL(k_synth_spectrum_v, dim3((pl->nrp + 3) / 4), dim3(256), 0, st, P, pl->Fsyn.as<double>(), nc, pl->lmax, pl->resid.as<double2>(),
-                           (const int *)nullptr, pl->nrp);
-        HX_TRY(launch_subdft_classes<1>(pl, nc, nullptr, nullptr, pl->resid.as<double2>(), pl->Y.as<double2>()));
+        hipLaunchKernelGGL(k_synth_spectrum_v, dim3((pl->nrp + 3) / 4), dim3(256), 0, st, P, fsyn, nc, pl->lmax, zc, (const int *)nullptr, pl->nrp);
+        HX_TRY(launch_subdft_classes<1>(pl, nc, nullptr, nullptr, zc, pl->Y.as<double2>()));
         hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, nc), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps + (size_t)c0 * pl->npix, d_ref ? 1 : 0,
                            d_ref ? d_ref + (size_t)c0 * pl->npix : nullptr);
         c0 += nc;

@@ -321,7 +321,7 @@ struct hx_plan {
     hx::DevBuf fft_rp_list;
     hx::DevBuf fft_desc;                 // RingDesc of every entry of fft_rp_list (one 32-byte read per work item instead of two dependent ones)
     std::vector<int> h_fft_rp_list;      // (host copy: ring pairs in DESCENDING order within a class)
-    hx::DevBuf Y, F, partial, d_dbg, resid, resid_maps, Fsyn, pw_sym;
+    hx::DevBuf Y, F, partial, d_dbg, resid_maps, pw_sym;  // (F doubles as the scratch of a synthesis: ring modes + ring spectra)
     hx::DevBuf syn_mlim0, syn_mlim2;  // per ring pair: the highest m its rows of Fv are written for (task pruning by blocks of 32 ring pairs)
     hx::DevBuf syn_tab, syn_boff0, syn_boff2;  // batched synthesis on the matrix unit (hx_synth_duo.hip): B-operand table of a sweep, first table block of every m
     const double *pw_checked = nullptr;       // the pixel-weight array of the current call that pw_mode describes
