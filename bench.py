@@ -531,6 +531,7 @@ def main():
                                 "numpy Cl blocks on the host; alms never leave HBM.  pcie_floor_ms = the maps' bytes at the 55 GB/s the "
                                 "staging sustains"}
             del h0, h2
+            plan.release_scratch()  # (the staging buffers of the streamed sweeps are 64 GB: room for the legs that follow)
 
         # ---- verification of what was timed (outside the timed region) --------------------------------------------
         verify, cpu = None, None
@@ -575,8 +576,7 @@ def main():
         # ---- the same 20-map job with the mapper's own default, healpy's iter = 3 (HipHealpixMapper(niter=3): three Jacobi iterations =
         # three batched syntheses + three more analyses per transform; the reference passes no iter, heracles/healpy.py:183-189).
         # Informational: `value` is the niter = 0 job SURVEY 8d prescribes. ----
-        niter3 = None
-        if world == 1 and not args.no_niter3:
+        def niter3_leg():
             def step3():
                 if n2:
                     plan.map2alm(maps2.view(2 * n2, npix), 2, pix_weights=pw, out=alm2.view(2 * n2, nlm), niter=3)
@@ -593,12 +593,18 @@ def main():
             for k in ("ring_fft", "fourier_combine", "legendre_analysis", "legendre_synthesis", "legendre_synth_duo", "synth_table", "alm_reduce", "alm2cl"):
                 n_, ms_ = hx._lib.profile_get(k)
                 k3[k] = {"launches": n_, "ms_per_step": ms_ / 2.0}
-            niter3 = {"value": npairs * 2 / d3, "unit": "map->Cl pairs/s", "ms_per_step": d3 / 2 * 1e3, "steps": 2, "kernels": k3,
-                      "what": "the timed job with niter = 3 (the mapper's default, healpy's iter): per transform 4 analyses + 3 syntheses; batched "
-                              "synthesis on the matrix unit (k_synth_duo, round 5), residuals formed in the scatter pass"}
-            # (restore the niter = 0 alms the verification below looks at)
-            step()
-            torch.cuda.synchronize()
+            return {"value": npairs * 2 / d3, "unit": "map->Cl pairs/s", "ms_per_step": d3 / 2 * 1e3, "steps": 2, "kernels": k3,
+                    "what": "the timed job with niter = 3 (the mapper's default, healpy's iter): per transform 4 analyses + 3 syntheses; batched "
+                            "synthesis on the matrix unit (k_synth_duo, round 5), residuals formed in the scatter pass"}
+
+        niter3 = None
+        if world == 1 and not args.no_niter3:
+            try:  # (an optional leg must not cost the line: an exception is reported in its place)
+                niter3 = niter3_leg()
+            except Exception as exc:  # noqa: BLE001
+                hx._lib.profile_enable(False)
+                niter3 = {"value": None, "error": f"{type(exc).__name__}: {exc}"[:400]}
+            plan.release_scratch()
 
         # ---- the reference's own call shape: ONE map / ONE field per transform (heracles/mapping.py:171), resident inputs; with
         # niter = 0 (weights supplied) and with healpy's default three Jacobi iterations; one alm2map.  Informational: not `value`.

@@ -26,7 +26,7 @@ SYMBOLS = (
     "hx_version", "hx_last_error", "hx_device_count", "hx_init", "hx_set_stream",
     "hx_get_stream", "hx_set_async", "hx_synchronize", "hx_timer_start", "hx_timer_stop",
     "hx_profile_enable", "hx_profile_reset", "hx_profile_get", "hx_plan_create", "hx_set_max_lds_fft",
-    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_set_scratch_budget", "hx_plan_last_chunks", "hx_plan_mfma_flops", "hx_plan_executed_flops", "hx_executed_flops", "hx_measure_peaks", "hx_measured_mfma_clock", "hx_map2alm", "hx_map2alm_multi", "hx_map2alm_list", "hx_alm2map", "hx_copy",
+    "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_plan_release_scratch", "hx_set_scratch_budget", "hx_plan_last_chunks", "hx_plan_mfma_flops", "hx_plan_executed_flops", "hx_executed_flops", "hx_measure_peaks", "hx_measured_mfma_clock", "hx_map2alm", "hx_map2alm_multi", "hx_map2alm_list", "hx_alm2map", "hx_copy",
     "hx_alm2cl_pairs", "hx_alm2cl_pairs_range", "hx_gauss_legendre", "hx_gauss_legendre_dd", "hx_wigner_d_table", "hx_mixmat",
     "hx_mixmat_eb", "hx_mixmat_batch", "hx_mixctx_create", "hx_mixctx_apply", "hx_mixctx_destroy", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_reorder", "hx_matvec", "hx_pinv", "hx_alm_resample", "hx_region_maps", "hx_alm_subtract", "hx_fits_unpack_f64", "hx_fits_pack_f64",
     "hx_pointsht_create", "hx_pointsht_destroy", "hx_pointsht_info", "hx_pointsht_adjoint",
@@ -78,6 +78,7 @@ def load():
         L.hx_plan_destroy.restype = None
         L.hx_plan_scratch_bytes.argtypes = [vp]
         L.hx_plan_scratch_bytes.restype = C.c_int64
+        L.hx_plan_release_scratch.argtypes = [vp]
         L.hx_set_scratch_budget.argtypes = [C.c_double]
         L.hx_plan_last_chunks.argtypes = [vp]
         L.hx_plan_mfma_flops.argtypes = [vp, i, i, C.POINTER(C.c_double)]

@@ -1119,6 +1119,22 @@ extern "C" void hx_plan_destroy(hx_plan *plan)
     delete plan;
 }
 
+extern "C" int hx_plan_release_scratch(hx_plan *pl)
+{
+    if (!pl) return fail(HX_ERR_ARG, "hx_plan_release_scratch: null plan");
+    if (rt().ready) {
+        HX_HIP(hipStreamSynchronize(rt().stream));
+        if (rt().copy) HX_HIP(hipStreamSynchronize(rt().copy));
+    }
+    for (int i = 0; i < hx_plan::NSTAGE; ++i) pl->stage[i].release();
+    pl->resid_maps.release();
+    pl->Y.release();
+    pl->F.release();
+    pl->partial.release();
+    pl->syn_tab.release();
+    return HX_OK;
+}
+
 extern "C" int64_t hx_plan_scratch_bytes(const hx_plan *pl)
 {
     if (!pl) return 0;

@@ -38,6 +38,11 @@ class Plan:
             _lib.load().hx_plan_destroy(self._h)
             self._h = None
 
+    def release_scratch(self):
+        """Free the plan's transient HBM scratch (hx_plan_release_scratch: up to ~200 GB after a full-size job); it is allocated again on
+        demand."""
+        _lib.check(_lib.load().hx_plan_release_scratch(self._h))
+
     def __del__(self):
         try:
             self.close()

@@ -77,6 +77,9 @@ hx_plan *hx_plan_create(int nside, int lmax, int max_comp);
 int hx_set_max_lds_fft(int points);
 void hx_plan_destroy(hx_plan *plan);
 int64_t hx_plan_scratch_bytes(const hx_plan *plan);
+/* Frees the plan's transient HBM scratch (ring spectra, Legendre operands and rows, staging buffers of host maps, residual maps,
+ * synthesis tables: up to ~200 GB after a full-size job).  Everything is allocated again on demand; the tables of the plan stay. */
+int hx_plan_release_scratch(hx_plan *plan);
 /* HBM the analysis may use for the operands and ring-group partial sums of ONE m-chunk (bytes; a chunk always
  * holds at least one m).  0 (default) = min(80 GB, half of the free HBM); the environment variable
  * HX_SCRATCH_GB sets the initial value.  The result does not depend on the chunking (tests/test_gpu_sht.py). */
