@@ -393,6 +393,7 @@ def main():
         del maps0, maps2, alm0, alm2  # (the weak-scaling job is done: room for the fixed job's buffers)
         work._buf = None
         torch.cuda.empty_cache()
+        plan.release_scratch()  # (the full-size sweeps of the first leg hold ~100 GB of operands and rows; the routes below size their own)
 
         def seeded_maps(gs):
             """maps of the fixed job's global indices gs (spin-0 first, as the routes hold them), seeded by the index: the same
