@@ -31,6 +31,17 @@
 #define HX_FFT_ABL 0  // timing experiments only (tools/fft_ablate.sh)
 #endif
 
+// HX_Y_NT=1: the ring spectra leave with non-temporal stores (round 5 experiment: see profiles/r05_fft_cycles.txt)
+#ifndef HX_Y_NT
+#define HX_Y_NT 0
+#endif
+#if HX_Y_NT
+typedef double hx_v2d __attribute__((ext_vector_type(2)));
+#define HX_YSTORE(p, v) do { const double2 v_ = (v); __builtin_nontemporal_store((hx_v2d){v_.x, v_.y}, reinterpret_cast<hx_v2d *>(p)); } while (0)
+#else
+#define HX_YSTORE(p, v) (*(p) = (v))
+#endif
+
 namespace hx {
 using namespace hxfft;
 
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
             lds_fft_dif(buf, M, twf, P.twN);
 #endif
             HX_FSTAMP(2);
-            for (int k = tid; k < n; k += nt) out[k] = buf[lds_slot(bitrev(k, p))];
+            for (int k = tid; k < n; k += nt) HX_YSTORE(out + k, buf[lds_slot(bitrev(k, p))]);
             HX_FSTAMP(5);
             continue;
         }
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
             lds_fft_dit_inv(buf, M, twf, P.twN, tid, nt);
         }
         for (int k = tid; k < n; k += nt)  // chirp exp(-i pi k^2 / n)
-            out[k] = cscale(cmul(buf[lds_slot(k)], phase(2u * mod_by_inv((unsigned)k * (unsigned)k, 2u * (unsigned)n, 2.0 * inv4n))), inv);
+            HX_YSTORE(out + k, cscale(cmul(buf[lds_slot(k)], phase(2u * mod_by_inv((unsigned)k * (unsigned)k, 2u * (unsigned)n, 2.0 * inv4n))), inv));
         HX_FSTAMP(5);
     }
 #if HX_FFT_ABL & 32
@@ -593,7 +604,7 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const Ri
             have_second = true;
         }
         double2 *out = Y + (long long)c * P.ny + sN + (long long)(rpair + 2 * half) * n;
-        for (int k = gt; k < n; k += nh) out[k] = bh[lds_slot(bitrev(k, p))];
+        for (int k = gt; k < n; k += nh) HX_YSTORE(out + k, bh[lds_slot(bitrev(k, p))]);
         HX_FSTAMP(4);
         }  // rounds
     }
