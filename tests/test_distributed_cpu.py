@@ -249,11 +249,13 @@ def _ms_map(g, spin):
     return rng.standard_normal(((2,) if spin else ()) + (12 * MS_NSIDE**2,))
 
 
-def _ms_worker(rank, world, port, outdir):
+def _ms_worker(rank, world, port, outdir, spins=None):
     import torch
     import torch.distributed as dist
 
     from heracles_amd.distributed import MShardedTwoPoint
+
+    SPINS = list(spins) if spins is not None else globals()["SPINS"]
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -305,6 +307,35 @@ def test_m_sharded_equals_single(tmp_path, world):
     m0 = np.array([_ms_map(g, 0) for g in one.local_maps if SPINS[g] == 0])
     m2 = np.array([_ms_map(g, 2) for g in one.local_maps if SPINS[g] == 2])
     np.testing.assert_allclose(one.run(torch.from_numpy(m0), torch.from_numpy(m2), pix_weights=pw), ref, rtol=1e-12, atol=1e-13 * np.abs(ref).max())
+
+
+def _spectra_of(spins):
+    from oracle import hxoracle as ho
+
+    pw = 1.0 + 0.01 * np.cos(np.arange(12 * MS_NSIDE**2))
+    alms = [np.atleast_2d(ho.map2alm(_ms_map(g, s), MS_NSIDE, MS_LMAX, spin=s, pix_weights=pw)) for g, s in enumerate(spins)]
+    return np.array([ho.alm2cl(a, b, lmax=MS_LMAX) for i in range(len(spins)) for j in range(i, len(spins)) for a in alms[i] for b in alms[j]])
+
+
+@pytest.mark.parametrize("spins", [(2, 0, 0), (2, 2, 0), (0, 0), (2, 2, 2)])
+def test_m_sharded_rank_without_a_spin(tmp_path, spins):
+    """The exchange goes out in a spin-0 and a spin-2 part: a rank that holds maps of one spin only (or a job without one of the spins)
+    sends empty blocks in the other part and still receives its share of it."""
+    import torch.multiprocessing as mp
+
+    from heracles_amd.distributed import MShardedTwoPoint
+
+    world = 2
+    nlm = (MS_LMAX + 1) * (MS_LMAX + 2) // 2
+    works = [MShardedTwoPoint(list(spins), world, r, nlm, MS_LMAX, OracleStages(MS_NSIDE, MS_LMAX), kernel=_kernel) for r in range(world)]
+    if len(set(spins)) == 2:
+        assert any(w.n0_of[w.rank] == 0 or w.n2_of[w.rank] == 0 for w in works)  # the case this test is for
+    mp.spawn(_ms_worker, args=(world, _free_port(), str(tmp_path), tuple(spins)), nprocs=world, join=True)
+    ref = _spectra_of(spins)
+    for r in range(world):
+        got = np.load(tmp_path / f"msharded_{r}.npy")
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-13 * np.abs(ref).max())
 
 
 def test_order_sets_cover_and_balance():
