@@ -825,6 +825,17 @@ __global__ __launch_bounds__(256, 1) void k_legendre_pipe(LegParams A, const dou
 #ifndef HX_DUO_ORDER
 #define HX_DUO_ORDER -1  // -1: per shape (GORDER)
 #endif
+// Step of the scaled recursion chains of k_legendre_duo: value = v 2^(SB e), live (in the sums) from 2^-SB on.  Spin 2 runs with 100: the
+// matrix work of 4 % of its blocks goes away (ten fields 321 -> 312 ms, results bit-identical: what is left out is below 2^-75 of a value
+// of lambda).  Spin 0 stays at 300: the same rule saves 3.9 % of its matrix instructions and no time (97.3 -> 98.4 ms: two chains per lane
+// to test in a kernel that already spills).
+#ifndef HX_DUO_SCALE_BITS2
+#define HX_DUO_SCALE_BITS2 100
+#endif
+#ifndef HX_DUO_SCALE_BITS0
+#define HX_DUO_SCALE_BITS0 300
+#endif
+
 #ifndef HX_DUO_ABL
 #define HX_DUO_ABL 0  // timing experiments only: 1 no matrix instructions, 2 no recursion, 4 no flush, 8 plain stores instead of atomics, 32 cycle accounting
 #endif
@@ -857,6 +868,7 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
     constexpr int NXA = NBX > 0 ? NBX : 1;
     constexpr int DQ0 = NG * 512, DSZ = NG * 512 + NBX * 128;
     constexpr bool HALFB = SPIN == 2;
+    constexpr int SB = SPIN == 2 ? HX_DUO_SCALE_BITS2 : HX_DUO_SCALE_BITS0;  // scaled chains: value = v 2^(SB e), live from 2^-SB on (sval_rebase)
     constexpr int GAPN = HX_DUO_GAP >= 0 ? HX_DUO_GAP : ((SPIN == 2 && NG == 2 && NBX == 2) ? 5 : (SPIN == 2 && NG == 2 && NBX == 1) ? 6 : (SPIN == 2 && NG == 1 && NBX == 2) ? 0 : 4);
     // where the gaps stand: 0 behind every (16 x 16 x 4, 4 x 4 x 4) pair; 1 between the two instructions of a pair (ten spin-0 maps 99.4 ->
     // 98.1 ms; ten fields 344: not there); 2 behind the 16 x 16 x 4 and behind the 4 x 4 x 4 instructions of a position (ten fields 326.5 -> 324)
@@ -980,6 +992,8 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
                 vc[0] = (lane >> 5) ? (off ? -sm.v : sm.v) : sp.v;  // the lambda- chain alternates in sign, + at even l + m
                 sc[0] = (lane >> 5) ? sm.e : sp.e;
             }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) sval_rebase<SB>(vc[c], sc[c]);
         }
 
         auto rec_step = [&](auto RMM, int c, int step, const double tq) __attribute__((always_inline)) {
@@ -987,8 +1001,8 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
             if (RM != 3 && (step & 3) == 0) {
                 const int hc = __double2hiint(vc[c]), hp = __double2hiint(vp[c]);
                 const bool up = sc[c] < 0 && (hc & 0x7ff00000) >= 0x3ff00000;
-                const int sub = up ? (300 << 20) : 0;
-                const bool pz = up && (hp & 0x7ff00000) <= (300 << 20);
+                const int sub = up ? (SB << 20) : 0;
+                const bool pz = up && (hp & 0x7ff00000) <= (SB << 20);
                 vc[c] = __hiloint2double(hc - sub, __double2loint(vc[c]));
                 vp[c] = pz ? 0.0 : __hiloint2double(hp - sub, __double2loint(vp[c]));
                 sc[c] += up ? 1 : 0;
@@ -1033,10 +1047,22 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        auto set_mode = [&]() __attribute__((always_inline)) {
-            bool dead = !valid || sc[0] < 0, live = !valid || sc[0] == 0;
+        // Mode of block b for this wave: 1 = every chain stays out of the sums for the whole block (no tile, no matrix instructions), 3 = every
+        // chain is live, 2 = mixed.  A chain is live from 2^-SB on; with SB < 300 "dead at the entry" is not enough for mode 1: near l = m a
+        // step multiplies by up to sqrt(2m / (l - m)), and a chain that enters the first block at 2^-100 can leave it at 1e-10.  So a lane
+        // counts as dead for the block only below 2^-(SB + E_b) at the entry, E_b = 60, 34, 26, 24, ... 8 for b = 0, 1, 2, 3 ... >= 11:
+        // calibrated (tools/calibrate_dead_blocks.py: both spins, m up to lmax = 6144, all rings) so that nothing above 2^-75 of a
+        // value of lambda is left out, with 8 bits to spare; the matrix work of 4 % of the blocks goes away against SB = 300.
+        auto set_mode = [&](int b) __attribute__((always_inline)) {
+            const int eb = b == 0 ? 60 : (b == 1 ? 34 : (30 - 2 * b > 8 ? 30 - 2 * b : 8));
+            auto lane_dead = [&](int c) __attribute__((always_inline)) {
+                if (SB == 300) return sc[c] < 0;
+                const int ef = (__double2hiint(vc[c]) >> 20) & 0x7ff;  // |v| < 2^(ef - 1022)
+                return sc[c] <= -2 || (sc[c] == -1 && ef <= 1022 - eb);
+            };
+            bool dead = !valid || lane_dead(0), live = !valid || sc[0] == 0;
             if (NCH == 2) {
-                dead = dead && (!valid || sc[NCH - 1] < 0);
+                dead = dead && (!valid || lane_dead(NCH - 1));
                 live = live && (!valid || sc[NCH - 1] == 0);
             }
             return __all(dead) ? 1 : (__all(live) ? 3 : 2);
@@ -1071,12 +1097,18 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
 #pragma unroll
                 for (int g = 0; g < NXA; ++g) accx[sub][g][0] = accx[sub][g][1] = 0.0;
                 if (b >= nblk) break;  // (rows are padded to whole blocks, the row span of an m to nblk blocks: nothing is stored beyond it)
-                const int rm = (HX_DUO_ABL & 2) ? 3 : set_mode();
+                int rm = (HX_DUO_ABL & 2) ? 3 : set_mode(b);
                 const double2 cl[2] = {cnext[0], cnext[1]};
                 if (HX_DUO_ABL & 2) {
                 } else if (rm == 3) recursion(I3{}, cl);
-                else if (rm == 2) recursion(I2{}, cl);
-                else recursion(I1{}, cl);
+                else if (rm == 2) {
+                    recursion(I2{}, cl);
+                    if (SB != 300) {  // a mixed block in which no chain came to life stored zeros only: nothing to multiply, nothing to flush
+                        bool lv = valid && sc[0] == 0;
+                        if (NCH == 2) lv = lv || (valid && sc[NCH - 1] == 0);
+                        if (!__any(lv)) rm = 1;
+                    }
+                } else recursion(I1{}, cl);
                 // coefficients of the next block: requested in front of this block's matrix work and of its flush (vmcnt retires in order: a load
                 // behind the atomics of the flush could not be waited for without waiting for them)
                 cnext[0] = cfm[(b + 1) * LBLK];

@@ -86,6 +86,26 @@ __device__ inline void snorm_small(SVal &s)
         }
 }
 
+// (v, e) with value = v 2^(300 e), |v| >= 2^-300  ->  value = v 2^(SB e), |v| >= 2^-SB (SB divides 300).  A chain is "live" -- its values enter
+// the matrix products -- once e = 0, i.e. from 2^-SB on: the kernels that skip the matrix work of blocks whose rings are all below that
+// threshold take SB = 100 (7.9e-31; libsharp drops what is below 2^-60 of its scaled values), which ends the lead-in of a ring earlier
+// than SB = 300 (4.9e-91) does.
+template <int SB>
+__device__ inline void sval_rebase(double &v, int &e)
+{
+    static_assert(300 % SB == 0, "the step must divide 300");
+    if (SB != 300) {
+        constexpr double big = SB == 100 ? 0x1p+100 : SB == 150 ? 0x1p+150 : SB == 75 ? 0x1p+75 : SB == 60 ? 0x1p+60 : 0x1p+50;
+        static_assert(SB == 300 || SB == 100 || SB == 150 || SB == 75 || SB == 60 || SB == 50, "unsupported step");
+        e *= 300 / SB;
+        if (v != 0.0)
+            while (fabs(v) < 1.0 / big) {
+                v *= big;
+                e -= 1;
+            }
+    }
+}
+
 // x^n for 0 <= x <= 1 with extended exponent
 __device__ inline SVal spow(double x, int n)
 {

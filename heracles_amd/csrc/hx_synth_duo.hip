@@ -38,6 +38,12 @@ constexpr int SLB = 16;  // l per block: 8 rows of (even, odd)
 #endif
 constexpr int SB = HX_SYN_SB;
 
+#ifndef HX_SYN_SCALE_BITS2
+#define HX_SYN_SCALE_BITS2 100
+#endif
+#ifndef HX_SYN_SCALE_BITS0
+#define HX_SYN_SCALE_BITS0 300
+#endif
 #ifndef HX_SYN_GAP
 #define HX_SYN_GAP -1  // s_nop (n - 1) behind every (16 x 16 x 4, 4 x 4 x 4) group of a position: lets the other group's vector work in (see HX_DUO_GAP)
 #endif
@@ -168,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void k_synth_duo(SynDuoParams A, const doub
     // gaps in the matrix stream let the other group's vector work in (HX_DUO_GAP of the analysis kernel): ten spin-0 maps 91.1 -> 87.6 ms,
     // five fields 178.4 -> 170.9 with s_nop 4; the 40-column shape is the same with and without (319-326 ms for 0, 3 ... 8)
     constexpr int GAPN = HX_SYN_GAP >= 0 ? HX_SYN_GAP : ((NG == 2 && NBX == 2) ? 0 : 5);
+    constexpr int SCB = SPIN == 2 ? HX_SYN_SCALE_BITS2 : HX_SYN_SCALE_BITS0;  // step of the scaled chains (as HX_DUO_SCALE_BITS in hx_analysis.hip)
     static_assert(NG >= 1 && NG <= 2 && NBX >= 0 && NBX <= 2 && NP <= 512, "shape");
     __shared__ double tile[NW][64 * 16];  // 8 KiB per wave
     __shared__ double tab[2][SB][RD];     // <= 40 KiB: two stages of SB blocks
@@ -207,14 +214,16 @@ __global__ __launch_bounds__(256, 2) void k_synth_duo(SynDuoParams A, const doub
             vc[0] = (lane >> 5) ? (off ? -sm.v : sm.v) : sp.v;  // the lambda- chain is carried as (-1)^(l + m) lambda-
             sc[0] = (lane >> 5) ? sm.e : sp.e;
         }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) sval_rebase<SCB>(vc[c], sc[c]);
     }
     auto rec_step = [&](auto RMM, int c, int step, const double tq) __attribute__((always_inline)) {
         constexpr int RM = decltype(RMM)::value;
-        if (RM != 3 && (step & 3) == 0) {  // promotion of scaled chains (value = v 2^(300 e), live iff e = 0), on the exponent bits
+        if (RM != 3 && (step & 3) == 0) {  // promotion of scaled chains (value = v 2^(SCB e), live iff e = 0), on the exponent bits
             const int hc = __double2hiint(vc[c]), hp = __double2hiint(vp[c]);
             const bool up = sc[c] < 0 && (hc & 0x7ff00000) >= 0x3ff00000;
-            const int sub = up ? (300 << 20) : 0;
-            const bool pz = up && (hp & 0x7ff00000) <= (300 << 20);
+            const int sub = up ? (SCB << 20) : 0;
+            const bool pz = up && (hp & 0x7ff00000) <= (SCB << 20);
             vc[c] = __hiloint2double(hc - sub, __double2loint(vc[c]));
             vp[c] = pz ? 0.0 : __hiloint2double(hp - sub, __double2loint(vp[c]));
             sc[c] += up ? 1 : 0;
@@ -253,10 +262,18 @@ __global__ __launch_bounds__(256, 2) void k_synth_duo(SynDuoParams A, const doub
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto set_mode = [&]() __attribute__((always_inline)) {
-        bool dead = !valid || sc[0] < 0, live = !valid || sc[0] == 0;
+    // (SCB < 300: a lane is dead for block b only below 2^-(SCB + E_b) at the entry -- see set_mode of k_legendre_duo; blocks of 16 l:
+    // E_b = 26, 12, 8, 8, ... from tools/calibrate_dead_blocks.py 16, eight bits to spare)
+    auto set_mode = [&](int b) __attribute__((always_inline)) {
+        const int eb = b == 0 ? 26 : (b == 1 ? 12 : 8);
+        auto lane_dead = [&](int c) __attribute__((always_inline)) {
+            if (SCB == 300) return sc[c] < 0;
+            const int ef = (__double2hiint(vc[c]) >> 20) & 0x7ff;  // |v| < 2^(ef - 1022)
+            return sc[c] <= -2 || (sc[c] == -1 && ef <= 1022 - eb);
+        };
+        bool dead = !valid || lane_dead(0), live = !valid || sc[0] == 0;
         if (NCH == 2) {
-            dead = dead && (!valid || sc[NCH - 1] < 0);
+            dead = dead && (!valid || lane_dead(NCH - 1));
             live = live && (!valid || sc[NCH - 1] == 0);
         }
         return __all(dead) ? 1 : (__all(live) ? 3 : 2);
@@ -305,11 +322,17 @@ __global__ __launch_bounds__(256, 2) void k_synth_duo(SynDuoParams A, const doub
         const double2 cl = cnext;
         if (b + SB < nblk) dma_block(b + SB, &tab[stg ^ 1][bj][0]);
         cnext = cfm[(b + 1) * SLB];
-        const int rm = (HX_SYN_ABL & 2) ? 3 : set_mode();
+        int rm = (HX_SYN_ABL & 2) ? 3 : set_mode(b);
         if (HX_SYN_ABL & 2) {
         } else if (rm == 3) recursion(I3{}, cl);
-        else if (rm == 2) recursion(I2{}, cl);
-        else recursion(I1{}, cl);
+        else if (rm == 2) {
+            recursion(I2{}, cl);
+            if (SCB != 300) {  // a mixed block in which no chain came to life stored zeros only
+                bool lv = valid && sc[0] == 0;
+                if (NCH == 2) lv = lv || (valid && sc[NCH - 1] == 0);
+                if (!__any(lv)) rm = 1;
+            }
+        } else recursion(I1{}, cl);
         if (rm >= 2 && !(HX_SYN_ABL & 1)) {
             if (HX_SYN_PRIO) __builtin_amdgcn_s_setprio(0);
             const double *tb = &tab[stg][bj][0];

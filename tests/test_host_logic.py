@@ -2,6 +2,7 @@
 mask -> field fan-out.  Arithmetic kernels are replaced by the oracle (as a checker stub)
 so the Python drivers can be compared with the reference's golden outputs on CPU."""
 
+import os
 import types
 
 import numpy as np
@@ -366,3 +367,20 @@ def test_result_array_checks_the_callers_out():
 
     with pytest.raises(TypeError):
         _lib.result_array((2, 2), Shaped())
+
+
+@pytest.mark.parametrize("blk,spin,m", [(32, 2, 2500), (16, 2, 5800), (32, 0, 4000)])
+def test_dead_block_margins_cover_the_growth_of_the_recursion(blk, spin, m):
+    """k_legendre_duo / k_synth_duo skip the matrix work of a block whose chains all enter it below 2^-(100 + E_b).  The margins E_b in the
+    kernels must cover what a skipped chain can reach inside the block (near l = m a step multiplies by up to sqrt(2m / (l - m))): the
+    long-double emulation of the normalised recursions (tools/calibrate_dead_blocks.py) gives the margin needed for nothing above 2^-75 of
+    a value of lambda to be left out; the kernels keep at least 6 bits on top of it."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("calib", os.path.join(os.path.dirname(__file__), "..", "tools", "calibrate_dead_blocks.py"))
+    calib = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(calib)
+    needed = calib.need(m, spin, blk=blk, nbmax=14, nth=1500)
+    assert needed[0] > 10  # the first block is the one that needs a margin at all
+    for b, e in enumerate(needed):
+        assert calib.kernel_margin(b, blk) >= e + 6, (b, e)
