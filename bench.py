@@ -201,6 +201,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    a2a_broken = False
     if world > 1:
         if share:
             dist.init_process_group("gloo")
@@ -210,6 +211,18 @@ def main():
         tok = torch.ones(1, dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(tok)
         assert float(tok.item()) == world
+        if not share:
+            # ... and the point-to-point channels of the all-to-all / the rings of the all-gather by their first use: one tiny call of each
+            # (not a step of the job: no map is touched)
+            a = torch.arange(world, dtype=torch.float64, device=dev) + rank * world
+            b = torch.empty_like(a)
+            dist.all_to_all_single(b, a)
+            g = torch.empty(world, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(g, a[:1].contiguous())
+            torch.cuda.synchronize(dev)
+            bad = torch.tensor([0.0 if [int(v) for v in b.tolist()] == [q * world + rank for q in range(world)] else 1.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            a2a_broken = bool(bad.item())  # (every rank holds the same verdict: the m-sharded route is then reported as failed, not run)
 
     import heracles_amd as hx
     from heracles_amd import distributed as hxd
@@ -422,6 +435,8 @@ def main():
         # route (guard=True) and an exception is raised by all of them alike and reported instead of the figure)
         cls_m = None
         try:
+            if a2a_broken:
+                raise RuntimeError("all_to_all_single over RCCL returned the wrong blocks in the priming call")
             ms = hxd.MShardedTwoPoint(per_set, world, rank, nlm, lmax, hxd.HipStages(plan, dev))
             s0, s2 = seeded_maps(ms.local_maps)
             for _ in range(args.warmup):
