@@ -265,6 +265,8 @@ def main():
     else:
         pw = hxw.expand_pixel_weights(nside, 1e-3 * np.random.default_rng(7).standard_normal(hxw.compressed_size(nside)), device=dev)
 
+    cl_host = hx.pinned_empty((work.nrows, lmax + 1)) if world == 1 else None
+
     def step():
         # N > 1: the exchange goes out in two parts -- the spin-2 shards as soon as their transform is done, the spin-0 transform runs
         # under that transfer, then the spin-0 shards; all_pairs_cl starts the spin-2 x spin-2 blocks of its tiles when the first part has
@@ -275,7 +277,7 @@ def main():
         if n0:
             plan.map2alm(maps0, 0, pix_weights=pw, out=alm0)
         work.exchange_begin(0)
-        return work.all_pairs_cl()  # rank 0: every Cl block on the host
+        return work.all_pairs_cl(out=cl_host)  # rank 0: every Cl block on the host (N = 1: in ONE page-locked array, overwritten by every step)
 
     def sync():
         torch.cuda.synchronize()
@@ -324,6 +326,7 @@ def main():
     hx._lib.profile_enable(True)
     hx._lib.profile_reset()
     dt, cls = timed(step, steps1, 0)
+    cls = None if cls is None else np.array(cls)  # (a copy for the checks below: the page-locked array belongs to the steps)
     hx._lib.profile_enable(False)
     npairs = len(work.pairs)
     value = npairs * steps1 / dt

@@ -114,7 +114,16 @@ class ShardedTwoPoint:
             r = min(range(world), key=lambda q: (load[q], q))
             load[r] += size(tiles[k])
             self.pairs_of[r] += tiles[k][2]
+        if world == 1:
+            self.pairs_of = [list(self.pairs)]  # one rank: the job's own order, so that its rows are the result as it stands
         self.rows_of = [[self.row0[p] + k for p in ps for k in range(ncomp(p[0]) * ncomp(p[1]))] for ps in self.pairs_of]
+        self._rows_in_order = world == 1 and self.rows_of[0] == list(range(len(self.rows_of[0])))
+        try:
+            import inspect
+
+            self._kernel_takes_out = "out" in inspect.signature(self.kernel).parameters
+        except (TypeError, ValueError):
+            self._kernel_takes_out = False
         self.my_pairs = self.pairs_of[rank]
         self.my_cpairs = [(a, b) for (i, j) in self.my_pairs for a in self.comps_of_map[i] for b in self.comps_of_map[j]]
         # the component pairs of this rank whose partners are both spin-2 (ready after the first part of the exchange), and the rest
@@ -212,14 +221,18 @@ class ShardedTwoPoint:
             self.exchange_wait(spin)
 
     # -- all pairs -----------------------------------------------------------------------
-    def all_pairs_cl(self):
+    def all_pairs_cl(self, out=None):
         """After the local transforms: exchange, compute this rank's tiles of map pairs, collect on rank 0.
         Returns on rank 0 the array (n_component_pairs_total, lmax+1) ordered by map pair
-        (combinations_with_replacement order) then component block; None elsewhere."""
+        (combinations_with_replacement order) then component block; None elsewhere.
+        out (one process, library kernel only): the destination, e.g. one page-locked array for every step of a loop."""
         import torch
 
         buf = self.buffer()
         comps = [buf[k] for k in range(buf.shape[0])]
+        if self.world == 1 and self._rows_in_order and self._kernel_takes_out:
+            self.exchange()
+            return self.kernel(comps, self.my_cpairs, self.lmax, out=out)  # (the rows of the one rank are the result as it stands)
         if self.world == 1 or not self._first or not self._second:
             self.exchange()
             mine = self.kernel(comps, self.my_cpairs, self.lmax) if self.my_cpairs else np.zeros((0, self.lmax + 1))

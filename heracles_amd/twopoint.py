@@ -31,12 +31,14 @@ def _is_tensor(a):
     return hasattr(a, "data_ptr") and not isinstance(a, np.ndarray)
 
 
-def alm2cl_pairs(comps, pairs, lmax_out, m_range=None):
+def alm2cl_pairs(comps, pairs, lmax_out, m_range=None, out=None):
     """All requested component-pair spectra in one launch.
 
     comps: list of 1-D complex128 arrays (numpy, or torch CUDA tensors); pairs: list of
     (i, j) indices into comps.  Returns a float64 array (npairs, lmax_out+1).
     m_range = (m0, m1[, step]): the sum over the orders m0, m0 + step, ... < m1 only (a rank's share on the m-sharded route).
+    out: the destination (C-contiguous float64 of that shape; a loop passes the same page-locked array -- ``pinned_empty`` -- every
+    time and saves the first touch and the staged copy of a fresh 23 MB result: 3 ms per call at lmax 6144 / 475 spectra).
     """
     L = _lib.load()
     _lib.ensure_init()
@@ -55,7 +57,7 @@ def alm2cl_pairs(comps, pairs, lmax_out, m_range=None):
     npairs = len(pairs)
     pi = (C.c_int * max(npairs, 1))(*[p[0] for p in pairs])
     pj = (C.c_int * max(npairs, 1))(*[p[1] for p in pairs])
-    out = np.zeros((npairs, lmax_out + 1))
+    out = _lib.result_array((npairs, lmax_out + 1), out)  # (every element is written by the call)
     if npairs and m_range is None:
         _lib.check(L.hx_alm2cl_pairs(ncomp, lmaxs, ptrs, int(lmax_out), npairs, pi, pj, _lib.ptr(out)))
     elif npairs:

@@ -159,3 +159,23 @@ def test_pairs_in_either_orientation_and_duplicates(oracle):
         else:
             first[key] = k
             np.testing.assert_allclose(out[k], oracle.alm2cl(alms[a], alms[b]), rtol=RTOL, atol=1e-14)
+
+
+@pytest.mark.gpu
+def test_alm2cl_pairs_into_the_callers_array():
+    """out=: the spectra land in the caller's array (a page-locked one in a loop), which is what the call returns; the wrong shape is refused"""
+    import heracles_amd as hx
+    from heracles_amd.twopoint import alm2cl_pairs
+
+    lmax = 40
+    nlm = (lmax + 1) * (lmax + 2) // 2
+    rng = np.random.default_rng(11)
+    comps = [rng.standard_normal(nlm) + 1j * rng.standard_normal(nlm) for _ in range(3)]
+    pairs = [(0, 0), (0, 1), (1, 2), (2, 2)]
+    ref = alm2cl_pairs(comps, pairs, lmax)
+    for out in (np.full((4, lmax + 1), np.nan), hx.pinned_empty((4, lmax + 1))):
+        got = alm2cl_pairs(comps, pairs, lmax, out=out)
+        assert got is out
+        np.testing.assert_array_equal(got, ref)
+    with pytest.raises(ValueError):
+        alm2cl_pairs(comps, pairs, lmax, out=np.empty((3, lmax + 1)))
