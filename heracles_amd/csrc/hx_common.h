@@ -116,6 +116,7 @@ int launch_gemm_tst(const double *T, int rows1_pad, const double *T2, int rows2_
 
 // hx_init on another device: drop the context hx_mixmat / hx_mixmat_eb keep between calls (hx_mixmat.hip)
 void mixmat_drop_cache();
+void alm2cl_drop_cache();  // hx_twopoint.hip: the buffers hx_alm2cl_pairs keeps between calls
 
 // Gauss-Legendre nodes/weights into device arrays (hx_mixmat.hip)
 int launch_gauss_legendre(int n, double *d_x, double *d_w, double *d_xlo = nullptr);  // d_xlo: node k = x[k] + xlo[k] (see k_gauss_legendre)

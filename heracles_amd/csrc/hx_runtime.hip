@@ -474,6 +474,7 @@ int hx_init(int device)
         if (r.order_ev) (void)hipEventDestroy(r.order_ev);
         r.order_ev = nullptr;
         mixmat_drop_cache();
+        alm2cl_drop_cache();
         stager_reset_events();
     }
     HX_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));

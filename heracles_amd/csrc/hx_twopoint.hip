@@ -109,6 +109,24 @@ __global__ __launch_bounds__(256) void k_alm2cl_finish(const double *__restrict_
 
 using namespace hx;
 
+namespace hx {
+struct Alm2clScratch {
+    DevBuf ptrs, lmax, tiles, part, out;
+};
+static Alm2clScratch *g_alm2cl_scratch = nullptr;  // heap, never destroyed at exit (the HIP runtime may be gone by then)
+static Alm2clScratch &alm2cl_scratch()
+{
+    if (!g_alm2cl_scratch) g_alm2cl_scratch = new Alm2clScratch;
+    return *g_alm2cl_scratch;
+}
+void alm2cl_drop_cache()
+{
+    if (!g_alm2cl_scratch) return;
+    g_alm2cl_scratch->ptrs.release(); g_alm2cl_scratch->lmax.release(); g_alm2cl_scratch->tiles.release();
+    g_alm2cl_scratch->part.release(); g_alm2cl_scratch->out.release();
+}
+}  // namespace hx
+
 extern "C" int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double *const *alms, int lmax_out, int npairs, const int *pair_i,
                                      const int *pair_j, int m0, int m1, int mstep, double *cls);
 
@@ -183,15 +201,24 @@ extern "C" int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double 
     (void)nb;
     // tiles of one work-group share components when they are neighbours in (i0, j0) order
     std::stable_sort(tiles.begin(), tiles.end(), [](const ClTile &x, const ClTile &y) { return x.i0 != y.i0 ? x.i0 < y.i0 : x.j0 < y.j0; });
-    DevBuf d_ptrs, d_lmax, d_tiles;
+    // tables, partial sums and the staging buffer of a host result are kept between calls (a loop over steps or jackknife regions calls with
+    // the same sizes: four hipMalloc / hipFree pairs, one of 70 MB, were 0.6 ms of every call); freed by hx_init on another device
+    Alm2clScratch &sc_ = alm2cl_scratch();
+    DevBuf &d_ptrs = sc_.ptrs, &d_lmax = sc_.lmax, &d_tiles = sc_.tiles;
     HX_TRY(d_ptrs.alloc(sizeof(void *) * ncomp));
     HX_TRY(d_lmax.alloc(sizeof(int) * ncomp));
     HX_TRY(d_tiles.alloc(sizeof(ClTile) * tiles.size()));
     HX_HIP(hipMemcpyAsync(d_ptrs.p, ptrs.data(), sizeof(void *) * ncomp, hipMemcpyHostToDevice, st));
     HX_HIP(hipMemcpyAsync(d_lmax.p, lmax_i, sizeof(int) * ncomp, hipMemcpyHostToDevice, st));
     HX_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), sizeof(ClTile) * tiles.size(), hipMemcpyHostToDevice, st));
-    OutView out;
-    HX_TRY(out.bind(cls, sizeof(double) * (size_t)npairs * (lmax_out + 1)));
+    // (OutView with the kept buffer as its staging area)
+    const size_t out_bytes = sizeof(double) * (size_t)npairs * (lmax_out + 1);
+    double *out_dev = cls;
+    const bool out_on_host = !is_device_ptr(cls);
+    if (out_on_host) {
+        HX_TRY(sc_.out.alloc(out_bytes));
+        out_dev = sc_.out.as<double>();
+    }
 
     const int nlblk = (lmax_out + CL_LB) / CL_LB;
     const int ngroups = ((int)tiles.size() + CL_TW - 1) / CL_TW;
@@ -199,7 +226,7 @@ extern "C" int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double 
     int nmsplit = (int)((2.5 * rt().cus) / ((double)nlblk * ngroups) + 0.5);
     nmsplit = std::max(1, std::min(nmsplit, 8));
     const long long nout = (long long)npairs * (lmax_out + 1);
-    DevBuf d_part;
+    DevBuf &d_part = sc_.part;
     HX_TRY(d_part.alloc(sizeof(double) * (size_t)nout * nmsplit));
     HX_HIP(hipMemsetAsync(d_part.p, 0, sizeof(double) * (size_t)nout * nmsplit, st));  // (shares without orders write nothing)
     {
@@ -208,12 +235,13 @@ extern "C" int hx_alm2cl_pairs_range(int ncomp, const int *lmax_i, const double 
                            d_ptrs.as<const double2 *>(), d_lmax.as<int>(), ncomp, d_tiles.as<ClTile>(), (int)tiles.size(), ngroups, nmsplit,
                            lmax_out, nlblk, d_part.as<double>(), nout, m0, m1, mstep);
         hipLaunchKernelGGL(k_alm2cl_finish, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, d_part.as<double>(), nout, nmsplit, nout,
-                           lmax_out, out.as<double>());
+                           lmax_out, out_dev);
     }
     HX_HIP(hipGetLastError());
-    HX_TRY(out.finish());
-    // temporaries (views, tables) are freed on return: make sure the kernel is done
+    if (out_on_host) HX_TRY(copy_d2h(cls, out_dev, out_bytes));  // synchronous on return
+    // temporaries (views of host components) are freed on return: make sure the kernel is done
     HX_HIP(hipStreamSynchronize(st));
+    if (sc_.part.bytes + sc_.out.bytes > ((size_t)512 << 20)) alm2cl_drop_cache();  // (an unusually large call does not keep its buffers)
     return HX_OK;
 }
 
