@@ -379,8 +379,8 @@ def main():
         return {"kernel": kernel, "bound": "mfma", "achieved": mfx, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": mfx / FP64_PEAK_TFLOPS,
                 "achieved_is": "EXECUTED FP64 flops of the MATRIX instructions the kernel issued, counted by the kernel itself (stages whose rings are "
-                               "all below 2^-300 skip theirs) / kernel time: the figure SQ_VALU_MFMA_BUSY_CYCLES of profiles/ gives (busy cycles x 32 flop; "
-                               "0.72 of the pipe's cycles at 2.38 GHz).  The recursion's vector flops share the same FP64 pipe and are reported beside it "
+                               "all dead -- below 2^-100 for spin 2, 2^-300 for spin 0 -- skip theirs) / kernel time: the figure SQ_VALU_MFMA_BUSY_CYCLES of profiles/ gives (busy cycles x 32 flop; "
+                               "0.71 of the pipe's cycles at 2.38 GHz).  The recursion's vector flops share the same FP64 pipe and are reported beside it "
                                "(executed_valu_tflops, frac_incl_vector), not added",
                 "frac_incl_vector": exe / FP64_PEAK_TFLOPS,
                 "task_list_mfma_tflops": mf_model * steps1 / sec / 1e12 if sec > 0 else 0.0,

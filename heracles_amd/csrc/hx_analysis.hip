@@ -189,7 +189,7 @@ __device__ inline int opaque(int v)
 // Layouts of F and the task list are those of the first kernel (a task = 16 / 8 blocks of 32 ring pairs); the rows of
 // `partial` are shared by the tasks of an m (LegParams::arow).
 // Work the Legendre kernels EXECUTE, counted by the kernels themselves (one atomic per wave at its end; wave-uniform scalar
-// counters): [0] FP64 flops of the matrix instructions actually issued (stages whose ring set is still below 2^-300 skip theirs),
+// counters): [0] FP64 flops of the matrix instructions actually issued (stages whose ring set is still dead (set_mode) skip theirs),
 // [1] FP64 vector flops of the recursions (2 FMAs per generated value).  bench.py's roofline fraction is quoted on these; they agree
 // with SQ_INSTS_VALU_MFMA_F64 of the PMC passes (profiles/).
 __device__ unsigned long long g_exec_flops[2];
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
         double *pgrp = A.partial + (orow + 2 * frow + fpos) * A.pcol + fcol;
         double *pquad = A.partial + (orow + 2 * qrow) * A.pcol + NG * NCOL + qcol;
         double2 cnext[2] = {cfm[0], cfm[16]};
-        // Lead-in of a ring group: the blocks in which every ring of all four waves is still below 2^-300 (~ 8 % of the blocks) have
+        // Lead-in of a ring group: the blocks in which every ring of all four waves is still dead (below 2^-300: ~ 8 % of the blocks; below 2^-100, spin 2: ~ 12 %) have
         // nothing to flush.  Until the first wave issues matrix instructions the waves exchange one flag per flush through LDS (one barrier,
         // one 16-byte read) and skip staging, reduction, atomics and the second barrier; from then on no flag is read or written any more
         // (read in EVERY flush the flags cost more than they saved: 357 vs 345 ms).  The first ring group of an m writes all its rows.
@@ -2002,7 +2002,7 @@ int analysis_stream_end(StreamSweep &s)
 // Executed matrix-instruction flops of one hx_map2alm(niter = 0) call with ncomp components:
 // every wave-block of the task list issues 8 (ring quads) x 2 (parities) x NOP MFMAs per full
 // 16-column group (2048 flop each) and per 4-column block (512 flop each).  Blocks whose rings
-// are all still below 2^-300 skip their MFMAs, so this is an upper bound (by < 10 %).
+// are all still dead (below 2^-100 for spin 2, 2^-300 for spin 0) skip their MFMAs, so this is an upper bound (by < 10 %).
 extern "C" int hx_plan_mfma_flops(hx_plan *pl, int spin, int ncomp, double *flops)
 {
     using namespace hx;
@@ -2027,7 +2027,7 @@ extern "C" int hx_plan_mfma_flops(hx_plan *pl, int spin, int ncomp, double *flop
 }
 
 // FP64 flops the Legendre analysis kernels EXECUTED since the last reset, counted by the kernels themselves: out2[0] matrix
-// instructions (stages that skip theirs because every ring of the set is still below 2^-300 are not counted), out2[1] vector
+// instructions (stages that skip theirs because every ring of the set is still dead are not counted), out2[1] vector
 // unit (recursions of the pipelined kernels, everything of the single-map kernels).  Synchronises the library stream.
 extern "C" int hx_executed_flops(double *out2, int reset)
 {

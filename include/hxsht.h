@@ -101,7 +101,7 @@ int hx_plan_mfma_flops(hx_plan *plan, int spin, int ncomp, double *flops);
 /* out2[0] = the same, out2[1] = FP64 vector flops of the recursions (4 per value of lambda_lm(theta) generated). */
 int hx_plan_executed_flops(hx_plan *plan, int spin, int ncomp, double *out2);
 /* What the Legendre analysis kernels of this process EXECUTED since the last reset, counted by the kernels themselves (one
- * atomic per wave): out2[0] = FP64 flops of the matrix instructions issued (stages whose rings are all still below 2^-300 issue
+ * atomic per wave): out2[0] = FP64 flops of the matrix instructions issued (stages whose rings are all still dead -- below 2^-100 (spin 2) / 2^-300 (spin 0) -- issue
  * none -- the task-list figure above counts them), out2[1] = FP64 flops on the vector unit.  reset != 0 zeroes the counters.
  * bench.py's roofline.achieved is these / the kernels' HIP-event time; it agrees with the SQ_INSTS_VALU_MFMA_F64 counter. */
 int hx_executed_flops(double *out2, int reset);
