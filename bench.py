@@ -321,16 +321,37 @@ def main():
                     n_ += 1
         return e_, n_
 
-    for _ in range(args.warmup):
-        step()
-    hx._lib.profile_enable(True)
-    hx._lib.profile_reset()
-    dt, cls = timed(step, steps1, 0)
-    cls = None if cls is None else np.array(cls)  # (a copy for the checks below: the page-locked array belongs to the steps)
-    hx._lib.profile_enable(False)
+    weak_error = None
+    try:
+        if os.environ.get("HX_BENCH_FAIL_WEAK") == "1" and world > 1:  # (test hook: the growing job fails on every rank alike)
+            raise RuntimeError("HX_BENCH_FAIL_WEAK")
+        for _ in range(args.warmup):
+            step()
+        hx._lib.profile_enable(True)
+        hx._lib.profile_reset()
+        dt, cls = timed(step, steps1, 0)
+        cls = None if cls is None else np.array(cls)  # (a copy for the checks below: the page-locked array belongs to the steps)
+        hx._lib.profile_enable(False)
+    except Exception as exc:  # noqa: BLE001
+        # N > 1 only: the job that grows with N is the side figure (`value_weak`); if it fails -- on every rank alike: its collectives have
+        # not run over RCCL before the driver's first N > 1 run -- the fixed job below still gets its line.  (A failure on ONE rank leaves
+        # the others waiting in a collective, here as anywhere.)  The per-GPU kernel figures then come from the local transforms alone.
+        if world == 1:
+            raise
+        weak_error = f"{type(exc).__name__}: {exc}"[:400]
+        hx._lib.profile_enable(True)
+        hx._lib.profile_reset()
+        for _ in range(steps1):
+            if n2:
+                plan.map2alm(maps2.view(2 * n2, npix), 2, pix_weights=pw, out=alm2.view(2 * n2, nlm))
+            if n0:
+                plan.map2alm(maps0, 0, pix_weights=pw, out=alm0)
+        torch.cuda.synchronize()
+        hx._lib.profile_enable(False)
+        dt, cls = float("nan"), None
     npairs = len(work.pairs)
-    value = npairs * steps1 / dt
-    ms_per_step = dt / steps1 * 1e3
+    value = npairs * steps1 / dt if weak_error is None else None
+    ms_per_step = dt / steps1 * 1e3 if weak_error is None else None
 
     # ---- per-family kernel times (HIP events on the library stream) ----------------------------------------------
     prof = {}
@@ -403,7 +424,7 @@ def main():
     # better one: the same 210 pairs at every N. ----
     strong, verify_multi, routes, weak_check = None, None, None, None
     if world > 1:
-        if rank == 0 and not args.no_verify:
+        if rank == 0 and not args.no_verify and cls is not None:
             e_, n_ = cl_direct_check(work, cls, [(0, 0), (0, nmaps_total - 1), (nmaps_total - 1, nmaps_total - 1), (0, nbins)])
             weak_check = {"max_err_over_max": e_, "spectra_checked": n_, "tolerance": 1e-11, "ok": bool(e_ <= 1e-11)}
         del maps0, maps2, alm0, alm2  # (the weak-scaling job is done: room for the fixed job's buffers)
@@ -520,7 +541,7 @@ def main():
 
     out = None
     if rank == 0:
-        assert cls is not None and cls.shape[0] == work.nrows
+        assert weak_error is not None or (cls is not None and cls.shape[0] == work.nrows)
         # ---- host -> host leg (SURVEY 8d's metric definition: pageable numpy maps in, Cl blocks on the host out) -------
         # (before the CPU legs, so that their working set on the host is not in its way)
         host_leg = None
@@ -729,8 +750,8 @@ def main():
             # the job that grows with N: every rank brings one set of maps; pairs grow as N^2 while the transforms per GPU stay what they are,
             # so its pairs/s is NOT a speed-up -- the per-GPU transform rate beside it is the weak-scaling figure proper
             weak = {"value": value, "unit": "map->Cl pairs/s", "ms_per_step": ms_per_step, "steps": steps1, "maps_total": nmaps_total,
-                    "pairs": npairs, "maps_per_gpu": len(per_set), "transforms_per_gpu_per_s": len(per_set) * 1e3 / ms_per_step,
-                    "cl_vs_direct_sum": weak_check, "kernels_rank0": prof,
+                    "pairs": npairs, "maps_per_gpu": len(per_set), "transforms_per_gpu_per_s": len(per_set) * 1e3 / ms_per_step if ms_per_step else None,
+                    "error": weak_error, "cl_vs_direct_sum": weak_check, "kernels_rank0": prof,
                     "what": f"every rank brings its own {set_name} ({len(per_set)} maps): transforms, in-place all-gather of the alms in two parts, "
                             f"tiled pair split over all {nmaps_total} maps; pairs = {nmaps_total} * {nmaps_total + 1} / 2"}
         if world > 1 and args.scaling == "strong":

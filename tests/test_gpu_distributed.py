@@ -226,3 +226,27 @@ def test_bench_under_torchrun_still_works(tmp_path):
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["config"]["pairs"] == 10 and out["verified"] is True
+
+
+@pytest.mark.gpu
+def test_bench_line_survives_a_failure_of_the_growing_job(tmp_path):
+    """The job that grows with N is the side figure of an N > 1 line.  If it fails on every rank alike (HX_BENCH_FAIL_WEAK=1 stands in for a
+    collective that has never run over RCCL), the fixed job -- ``value`` -- must still be timed, verified and printed; the line says what
+    happened to the other one."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HX_BENCH_SHARE_GPU="1", HX_BENCH_FAIL_WEAK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--nside", "64", "--lmax", "96", "--nbins", "2", "--no-cpu-baseline", "--no-mixmat", "--no-single", "--no-host-leg"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["pairs"] == 10 and out["value"] > 0
+    assert out["value_weak"] is None and "HX_BENCH_FAIL_WEAK" in out["weak_scaling"]["error"]
+    assert out["verify_multi"]["ok"] and out["verified"] is True
+    assert out["roofline"]["launches"] > 0  # the per-GPU kernel figures come from the local transforms
