@@ -2002,7 +2002,7 @@ int analysis_stream_end(StreamSweep &s)
 // Executed matrix-instruction flops of one hx_map2alm(niter = 0) call with ncomp components:
 // every wave-block of the task list issues 8 (ring quads) x 2 (parities) x NOP MFMAs per full
 // 16-column group (2048 flop each) and per 4-column block (512 flop each).  Blocks whose rings
-// are all still dead (below 2^-100 for spin 2, 2^-300 for spin 0) skip their MFMAs, so this is an upper bound (by < 10 %).
+// are all still dead (below 2^-100 for spin 2, 2^-300 for spin 0) skip their MFMAs, so this is an upper bound (by 9 - 13 %).
 extern "C" int hx_plan_mfma_flops(hx_plan *pl, int spin, int ncomp, double *flops)
 {
     using namespace hx;
