@@ -856,6 +856,65 @@ __device__ __forceinline__ double row_bcast_fmac(double t, double p, double x)
     return t;
 }
 
+// Rows of ONE order m (already summed over its ring groups: the pipelined kernels) -> alm layout, x alpha_l (k_legendre_duo leaves the
+// output scaling of the normalised recursion to this pass: alphan != NULL) x fl.  r0 = the first row of the m in `partial`, ncol = doubles
+// per row.  (Measured and not kept, round 5: the same pass at the end of the work-group of the m in k_legendre_duo instead of a launch of its
+// own -- bit-identical, and the Legendre kernel grows by what the launch cost: ten fields 318.2 + 3.9 ms against 322.0 fused.)
+template <int SPIN>
+__device__ __forceinline__ void alm_rows_to_layout(const PlanDev &P, int m, bool any_task, const double *__restrict__ partial, long long r0, int ncol,
+                                                   int ncomp, int ng, const double *__restrict__ fl, int add, double2 *__restrict__ alm,
+                                                   long long alm_stride, const double *__restrict__ alphan, int tid, int nt)
+{
+    const int lmax = P.lmax;
+    const int l0 = SPIN == 0 ? m : (m > 2 ? m : 2);
+    const int nl = lmax - m + 1, nc = 8 * ng;
+    // U elements per thread and round, their loads issued together (one element per round: 4.9 instead of 3.9 ms per sweep of ten fields)
+    constexpr int U = 8;
+    for (int i0 = tid; i0 < nl * nc; i0 += nt * U) {
+        double2 v[U];
+        double al[U], f[U];
+        long long dsti[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * nt;
+            const int l = m + i / nc, c = i % nc;
+            on[u] = i < nl * nc && c < ncomp;
+            v[u] = make_double2(0.0, 0.0);
+            al[u] = 1.0;
+            f[u] = 1.0;
+            dsti[u] = 0;
+            if (!on[u]) continue;
+            dsti[u] = (long long)c * alm_stride + almidx(lmax, l, m);
+            if (l >= l0 && any_task) {
+                const double *prow = partial + (r0 + (l - l0)) * ncol + (c >> 3) * NCOL;
+                v[u] = *reinterpret_cast<const double2 *>(prow + 2 * (c & 7));
+                if (SPIN == 2 && alphan && ((l + m) & 1)) {
+                    // k_legendre_duo: odd-parity rows were formed with the even-parity operand, i.e. with the four columns of every field reversed
+                    const int j = 2 * (c & 7);
+                    v[u] = make_double2(prow[j ^ 3], prow[(j + 1) ^ 3]);
+                }
+                if (SPIN == 2 && HX_HALF_F && ((l + m) & 1)) {  // odd-parity rows carry the signs (-, +, +, -) on (E_re, E_im, B_re, B_im)
+                    if (c & 1) v[u].y = -v[u].y;
+                    else v[u].x = -v[u].x;
+                }
+                if (alphan) al[u] = alphan[almidx(lmax, l, m)];
+                if (fl) f[u] = fl[l];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!on[u]) continue;
+            double2 w = v[u];
+            if (alphan) { w.x *= al[u]; w.y *= al[u]; }
+            if (fl) { w.x *= f[u]; w.y *= f[u]; }
+            double2 *dst = alm + dsti[u];
+            if (add) { const double2 o = *dst; w.x += o.x; w.y += o.y; }
+            *dst = w;
+        }
+    }
+}
+
 #if HX_DUO_ABL & 128  // diagnostic build: when and where the work-group of every m ran (100 MHz wall clock, XCC, HW_ID)
 __device__ unsigned long long g_duo_stamp[8192 * 3];
 #endif
@@ -1297,34 +1356,7 @@ __global__ __launch_bounds__(256) void k_alm_reduce(PlanDev P, const LegTask *__
     if (arow) {
         // rows of the pipelined kernel: already summed over the ring groups, one span per m (row0 = first row of the chunk
         // in that numbering); what is left is the change of layout (x fl)
-        const long long r0 = arow[m] - row0;
-        for (int i = threadIdx.x; i < nl * nc; i += blockDim.x) {
-            const int l = m + i / nc, c = i % nc;
-            if (c >= ncomp) continue;
-            double2 v = make_double2(0.0, 0.0);
-            if (l >= l0 && mt.count > 0) {
-                const double *prow = partial + (r0 + (l - l0)) * ncol + (c >> 3) * NCOL;
-                v = *reinterpret_cast<const double2 *>(prow + 2 * (c & 7));
-                if (SPIN == 2 && alphan && ((l + m) & 1)) {
-                    // k_legendre_duo: odd-parity rows were formed with the even-parity operand, i.e. with the four columns of every field reversed
-                    const int j = 2 * (c & 7);
-                    v = make_double2(prow[j ^ 3], prow[(j + 1) ^ 3]);
-                }
-                if (SPIN == 2 && HX_HALF_F && ((l + m) & 1)) {  // odd-parity rows carry the signs (-, +, +, -) on (E_re, E_im, B_re, B_im)
-                    if (c & 1) v.y = -v.y;
-                    else v.x = -v.x;
-                }
-                if (alphan) {  // k_legendre_duo leaves the output scaling alpha_l of the normalised recursion to this pass
-                    const double al = alphan[almidx(lmax, l, m)];
-                    v.x *= al;
-                    v.y *= al;
-                }
-                if (fl) { v.x *= fl[l]; v.y *= fl[l]; }
-            }
-            double2 *dst = alm + (long long)c * alm_stride + almidx(lmax, l, m);
-            if (add) { const double2 o = *dst; v.x += o.x; v.y += o.y; }
-            *dst = v;
-        }
+        alm_rows_to_layout<SPIN>(P, m, mt.count > 0, partial, arow[m] - row0, ncol, ncomp, ng, fl, add, alm, alm_stride, alphan, threadIdx.x, blockDim.x);
         return;
     }
     for (int i = threadIdx.x; i < nl * nc; i += blockDim.x) {
