@@ -34,6 +34,8 @@ for spin, ncomp in ((2, 20), (0, 10)):
         res.append(round(hx._lib.profile_get("legendre_analysis")[1], 2))
         hx._lib.profile_enable(False)
     print(f"[{tag}] spin {spin} x {ncomp} comps: legendre_analysis ms {res}; executed flops: matrix {ex[0]:.4e}, recursion {ex[1]:.4e}", flush=True)
+    bits = torch.view_as_real(alm).reshape(-1).view(torch.int64)
+    print(f"[{tag}] spin {spin}: bit pattern of ALL {bits.numel()} doubles of the result: sum {int(bits.sum())} (mod 2^64), xor-fold {int(bits[::2].bitwise_xor(bits[1::2]).sum())}", flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
     flat = alm.reshape(-1)
     # every 251st value plus whole orders near the poles' lead-in (m = 3000: the first 4000 values of its row)

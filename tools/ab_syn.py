@@ -29,6 +29,8 @@ for spin, ncomp in ((2, 20), (0, 10)):
         res.append(round(hx._lib.profile_get("legendre_synthesis")[1], 2))
         hx._lib.profile_enable(False)
     print(f"[{tag}] alm2map spin {spin} x {ncomp} comps: legendre_synthesis ms {res}", flush=True)
+    bits = out.reshape(-1).view(torch.int64)
+    print(f"[{tag}] spin {spin}: bit pattern of ALL {bits.numel()} doubles of the result: sum {int(bits.sum())} (mod 2^64), xor-fold {int(bits[::2].bitwise_xor(bits[1::2]).sum())}", flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
     # every 4099th pixel of every map plus the first 200000 pixels (the polar cap, where the lead-in of the chains is longest)
     samp = torch.cat([out[:, ::4099].reshape(-1), out[0, :200000], out[ncomp - 1, :200000]])
