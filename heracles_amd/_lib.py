@@ -28,7 +28,7 @@ SYMBOLS = (
     "hx_profile_enable", "hx_profile_reset", "hx_profile_get", "hx_plan_create", "hx_set_max_lds_fft",
     "hx_plan_destroy", "hx_plan_scratch_bytes", "hx_plan_release_scratch", "hx_set_scratch_budget", "hx_plan_last_chunks", "hx_plan_mfma_flops", "hx_plan_executed_flops", "hx_executed_flops", "hx_measure_peaks", "hx_measured_mfma_clock", "hx_map2alm", "hx_map2alm_multi", "hx_map2alm_list", "hx_alm2map", "hx_copy",
     "hx_alm2cl_pairs", "hx_alm2cl_pairs_range", "hx_gauss_legendre", "hx_gauss_legendre_dd", "hx_wigner_d_table", "hx_mixmat",
-    "hx_mixmat_eb", "hx_mixmat_batch", "hx_mixctx_create", "hx_mixctx_apply", "hx_mixctx_destroy", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_reorder", "hx_matvec", "hx_pinv", "hx_alm_resample", "hx_region_maps", "hx_alm_subtract", "hx_fits_unpack_f64", "hx_fits_pack_f64",
+    "hx_mixmat_eb", "hx_mixmat_batch", "hx_mixctx_create", "hx_mixctx_apply", "hx_mixctx_destroy", "hx_mixctx_set_bins", "hx_mixctx_apply_binned", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_reorder", "hx_matvec", "hx_pinv", "hx_alm_resample", "hx_region_maps", "hx_alm_subtract", "hx_fits_unpack_f64", "hx_fits_pack_f64",
     "hx_pointsht_create", "hx_pointsht_destroy", "hx_pointsht_info", "hx_pointsht_adjoint",
     "hx_pixel_weights_size", "hx_pixel_weights_expand",
     "hx_ring_modes_size", "hx_ring_modes", "hx_legendre_from_modes", "hx_host_alloc", "hx_host_free", "hx_mixmat_gemm_clock", "hx_mixmat_release",
@@ -103,6 +103,8 @@ def load():
         L.hx_mixctx_create.argtypes = [i, i, i]
         L.hx_mixctx_apply.argtypes = [vp, dp, i, i, dp]
         L.hx_mixctx_destroy.argtypes = [vp]
+        L.hx_mixctx_set_bins.argtypes = [vp, i, vp, dp, dp]
+        L.hx_mixctx_apply_binned.argtypes = [vp, dp, i, i, dp]
         L.hx_mixctx_destroy.restype = None
         L.hx_cl2corr.argtypes = [i, i, dp, dp]
         L.hx_corr2cl.argtypes = [i, i, dp, dp]

@@ -565,6 +565,111 @@ __global__ void k_eb_combine(long long n, double *__restrict__ o0, double *__res
     }
 }
 
+// ---- binned rows (heracles.twopoint.mixing_matrices(bins=, weights=): heracles/twopoint.py:391-397 -> heracles/result.py:124-248) ----
+// The reference bins the OUTPUT multipole of every matrix on the host, column by column (5 s per (3, 6145, 6145) matrix).  Binning is
+// linear in the rows, so with the mask-independent binned tables
+//     Tb[b][k] = sum_{l in bin b} w_l d^l(x_k)
+// the numerators of the binned matrix are the SKINNY product  sum_k Tb[b][k] s_k T[l2][k] (2 l2 + 1) / 2  --  (nbins x N)(N x L2):
+// ~200x fewer flops than the full matrix at 32 bins, one read of the table from HBM (0.46 GB at L = 6144) and nbins x (l2max + 1)
+// doubles to the host instead of 0.9 GB.
+//
+// k_bin_table: one thread per node, the rows of a bin in ascending l with a compensated sum (the terms oscillate in l and cancel).
+__global__ __launch_bounds__(256) void k_bin_table(int kpad, const int *__restrict__ start, const int *__restrict__ rows, const double *__restrict__ rw,
+                                                   const double *__restrict__ T, double *__restrict__ Tb)
+{
+#pragma clang fp contract(off)
+    const int k = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (k >= kpad) return;
+    double sum = 0.0, comp = 0.0;
+    for (int e = start[b]; e < start[b + 1]; ++e) {
+        const double v = rw[e] * T[(long long)rows[e] * kpad + k];
+        const double t = sum + v, bb = t - sum;
+        comp += (sum - (t - bb)) + (v - bb);  // two_sum
+        sum = t;
+    }
+    Tb[(long long)b * kpad + k] = sum + comp;
+}
+
+// partial[ks][b][j] = sum_{k in share ks} A[b][k] B[j][k]:  A = Tb diag(s) [nbpad][kpad], B = T [rows_pad][kpad].
+// A wave owns 16 columns j and MT tiles of 16 bins; a lane brings 32 contiguous bytes (4 nodes) of one row of each operand per
+// step, so the four matrix instructions of a step contract the nodes k + 4 (lane >> 4) + {0, 1, 2, 3} -- any order is fine as long as
+// A and B agree.  B (the big table) streams from HBM once, 128 contiguous bytes per row and step; A stays in L2.  The node range is cut
+// into gridDim.y shares (enough work-groups to fill the chip); k_binned_finish adds them in fixed order.
+template <int MT>
+__global__ __launch_bounds__(256) void k_binned_gemm(const double *__restrict__ A, const double *__restrict__ B, int kpad, int kchunk, int nbpad, int l2pad,
+                                                     double *__restrict__ partial)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    const int c0 = (blockIdx.x * 4 + w) * 16, b0 = blockIdx.z * (MT * 16);
+    const int k0 = blockIdx.y * kchunk, k1 = min(k0 + kchunk, kpad);
+    const double *pb = B + (long long)(c0 + r) * kpad + kg * 4;
+    const double *pa = A + (long long)(b0 + r) * kpad + kg * 4;
+    double4_t acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    int k = k0;
+    for (; k + 64 <= k1; k += 64) {  // four steps of B in flight
+        double4_t b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const double4_t *>(pb + k + 16 * u);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            double4_t a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const double4_t *>(pa + (long long)t * 16 * kpad + k + 16 * u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][h], b[u][h], acc[t], 0, 0, 0);
+        }
+    }
+    for (; k < k1; k += 16) {
+        const double4_t b = *reinterpret_cast<const double4_t *>(pb + k);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const double4_t a = *reinterpret_cast<const double4_t *>(pa + (long long)t * 16 * kpad + k);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h], b[h], acc[t], 0, 0, 0);
+        }
+    }
+    // D layout: row = (lane >> 4) + 4 * reg, col = lane & 15
+    double *po = partial + ((long long)blockIdx.y * nbpad + b0) * l2pad + c0 + r;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) po[(long long)(t * 16 + kg + 4 * q) * l2pad] = acc[t][q];
+}
+
+// out[b][j] = ratio(colscale[j] * sum_ks partial[ks][b][j], norm[b]), ratio(n, d) = n / d where n != 0, else 0 (the reference's rule:
+// heracles/result.py:132-135).  EB: pa = the (2,2) product, pb = the (2,-2) product -> [0] = (a + b) / 2, [1] = (a - b) / 2, [2] = b.
+template <bool EB>
+__global__ __launch_bounds__(256) void k_binned_finish(int nbins, int n2, int nbpad, int l2pad, int ksplit, const double *__restrict__ pa,
+                                                       const double *__restrict__ pb, const double *__restrict__ colscale,
+                                                       const double *__restrict__ norm, double *__restrict__ out)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (j >= n2) return;
+    const long long slab = (long long)nbpad * l2pad, at = (long long)b * l2pad + j;
+    double a = 0.0, c = 0.0;
+    for (int ks = 0; ks < ksplit; ++ks) {
+        a += pa[ks * slab + at];
+        if (EB) c += pb[ks * slab + at];
+    }
+    const double cs = colscale[j], nb = norm[b];
+    auto ratio = [nb](double v) { return v != 0.0 ? v / nb : 0.0; };
+    const long long o = (long long)b * n2 + j, sz = (long long)nbins * n2;
+    if (EB) {
+        a *= cs;
+        c *= cs;
+        out[o] = ratio(0.5 * (a + c));
+        out[o + sz] = ratio(0.5 * (a - c));
+        out[o + 2 * sz] = ratio(c);
+    } else {
+        out[o] = ratio(a * cs);
+    }
+}
+
 // ---- host helpers --------------------------------------------------------------------
 static void wigner_coefs(int lmax, int a, int b, std::vector<double4> &c)
 {
@@ -650,6 +755,11 @@ struct MixCtx {
     DevBuf T[4];            // (0,0), (2,0), (2,2), (2,-2)
     DevBuf Ts;              // T diag(s) of the product in hand (k_mixmat_gemm_dma)
     bool have[4] = {false, false, false, false};
+    // binned rows (hx_mixctx_set_bins): bin lists of the output multipole, binned tables Tb_t[nbpad][kpad] per product
+    int nbins = 0, nbpad = 0, l2pad = 0, ksplit = 1, kchunk = 0;
+    DevBuf b_start, b_rows, b_w, b_norm;
+    DevBuf Tb[4], Tbs, part[2], b_out;  // (b_out: device image of a host destination, kept between calls)
+    bool have_b[4] = {false, false, false, false};
 };
 static const int kAB[4][2] = {{0, 0}, {2, 0}, {2, 2}, {2, -2}};
 
@@ -1187,6 +1297,119 @@ extern "C" int hx_mixctx_apply(hx_mixctx *x, const double *cl, int ncl, int kind
         HX_TRY(mix_ctx_product(c, kind == 1 ? 0 : 1, vo.as<double>()));
         HX_TRY(vo.finish());
     }
+    HX_HIP(hipStreamSynchronize(rt().stream));
+    return HX_OK;
+}
+
+// ---- binned rows: heracles.twopoint.mixing_matrices(..., bins, weights) (heracles/twopoint.py:391-397) ----------------------------
+// which [l1max + 1]: bin of output multipole l (0 .. nbins - 1) or -1 (in no bin); w [l1max + 1]: its weight; norm [nbins]: the
+// divisor of bin b (the reference: the summed weight).  Host arrays.  The binned tables are built on the first product that needs them.
+extern "C" int hx_mixctx_set_bins(hx_mixctx *x, int nbins, const int *which, const double *w, const double *norm)
+{
+    HX_TRY(ensure_ready());
+    if (!x || nbins < 1 || !which || !w || !norm) return fail(HX_ERR_ARG, "hx_mixctx_set_bins: bad argument");
+    MixCtx &c = x->c;
+    const int n1 = c.l1max + 1;
+    for (int l = 0; l < n1; ++l)
+        if (which[l] < -1 || which[l] >= nbins) return fail(HX_ERR_ARG, "hx_mixctx_set_bins: which[%d] = %d outside [-1, %d)", l, which[l], nbins);
+    HX_HIP(hipStreamSynchronize(rt().stream));  // (a product of the previous bins may still be reading the lists)
+    std::vector<int> start(nbins + 1, 0), rows;
+    std::vector<double> rw;
+    for (int b = 0; b < nbins; ++b) {
+        for (int l = 0; l < n1; ++l)
+            if (which[l] == b) {
+                rows.push_back(l);
+                rw.push_back(w[l]);
+            }
+        start[b + 1] = (int)rows.size();
+    }
+    c.nbins = nbins;
+    c.nbpad = nbins <= 16 ? 16 : nbins <= 32 ? 32 : (nbins + 63) / 64 * 64;
+    c.l2pad = (c.l2max + 1 + 63) / 64 * 64;  // (<= rows_pad: the tables are zero-padded to multiples of 128 rows)
+    // enough work-groups for every CU to hold a few: the node range in shares of a multiple of 16
+    const int mt = std::min(c.nbpad / 16, 4), groups = (c.l2pad / 64) * (c.nbpad / (16 * mt));
+    int want = std::max(1, (4 * rt().cus + groups - 1) / groups);
+    c.kchunk = std::max(64, ((c.kpad + want - 1) / want + 15) / 16 * 16);
+    c.ksplit = (c.kpad + c.kchunk - 1) / c.kchunk;
+    HX_TRY(upload_vec(c.b_start, start));
+    HX_TRY(upload_vec(c.b_rows, rows));
+    HX_TRY(upload_vec(c.b_w, rw));
+    std::vector<double> nv(norm, norm + nbins);
+    HX_TRY(upload_vec(c.b_norm, nv));
+    for (bool &h : c.have_b) h = false;
+    return HX_OK;
+}
+
+namespace hx {
+static int mix_ctx_binned_table(MixCtx &c, int t)
+{
+    if (c.have_b[t]) return HX_OK;
+    HX_TRY(mix_ctx_table(c, t));
+    const size_t nel = (size_t)c.nbpad * c.kpad;
+    HX_TRY(c.Tb[t].alloc(sizeof(double) * nel));
+    HX_HIP(hipMemsetAsync(c.Tb[t].p, 0, sizeof(double) * nel, rt().stream));
+    ProfScope ps("mixmat_bin_table");
+    hipLaunchKernelGGL(k_bin_table, dim3((c.kpad + 255) / 256, c.nbins), dim3(256), 0, rt().stream, c.kpad, c.b_start.as<int>(), c.b_rows.as<int>(),
+                       c.b_w.as<double>(), c.T[t].as<double>(), c.Tb[t].as<double>());
+    HX_HIP(hipGetLastError());
+    c.have_b[t] = true;
+    return HX_OK;
+}
+
+// shares of the numerators of product t for the current mask into c.part[slot]
+static int mix_ctx_binned_product(MixCtx &c, int t, int slot)
+{
+    HX_TRY(mix_ctx_binned_table(c, t));
+    hipStream_t st = rt().stream;
+    const size_t nel = (size_t)c.nbpad * c.kpad;
+    HX_TRY(c.Tbs.alloc(sizeof(double) * nel));
+    HX_TRY(c.part[slot].alloc(sizeof(double) * (size_t)c.ksplit * c.nbpad * c.l2pad));
+    ProfScope ps("mixmat_binned");
+    hipLaunchKernelGGL(k_scale_table, dim3(256), dim3(256), 0, st, (long long)(nel / 2), c.kpad / 2, c.Tb[t].as<double2>(), c.s.as<double2>(), c.Tbs.as<double2>());
+    const int mt = std::min(c.nbpad / 16, 4);
+    const dim3 grid(c.l2pad / 64, c.ksplit, c.nbpad / (16 * mt));
+    if (mt == 1)
+        hipLaunchKernelGGL(k_binned_gemm<1>, grid, dim3(256), 0, st, c.Tbs.as<double>(), c.T[t].as<double>(), c.kpad, c.kchunk, c.nbpad, c.l2pad, c.part[slot].as<double>());
+    else if (mt == 2)
+        hipLaunchKernelGGL(k_binned_gemm<2>, grid, dim3(256), 0, st, c.Tbs.as<double>(), c.T[t].as<double>(), c.kpad, c.kchunk, c.nbpad, c.l2pad, c.part[slot].as<double>());
+    else
+        hipLaunchKernelGGL(k_binned_gemm<4>, grid, dim3(256), 0, st, c.Tbs.as<double>(), c.T[t].as<double>(), c.kpad, c.kchunk, c.nbpad, c.l2pad, c.part[slot].as<double>());
+    HX_HIP(hipGetLastError());
+    return HX_OK;
+}
+}  // namespace hx
+
+// kind as hx_mixctx_apply; out (nbins, l2max + 1) or (3, nbins, l2max + 1), host or device: the rows of the matrices binned as
+// heracles.result.binned does along axis -2 (weighted mean per bin; exactly 0 where the weighted sum is exactly 0).
+extern "C" int hx_mixctx_apply_binned(hx_mixctx *x, const double *cl, int ncl, int kind, double *out)
+{
+    HX_TRY(ensure_ready());
+    if (!x || !cl || !out || ncl < 1 || (kind != 1 && kind != 2 && kind != 4)) return fail(HX_ERR_ARG, "hx_mixctx_apply_binned: bad argument");
+    MixCtx &c = x->c;
+    if (c.nbins < 1) return fail(HX_ERR_ARG, "hx_mixctx_apply_binned: no bins set (hx_mixctx_set_bins)");
+    const int n2 = c.l2max + 1;
+    const size_t sz = (size_t)c.nbins * n2;
+    DevBuf &d_cl = mix_cache().cl;
+    HX_TRY(stage_cl(cl, ncl, c.l3max, d_cl));
+    HX_TRY(mix_ctx_mask(c, d_cl.as<double>()));
+    const size_t bytes = sizeof(double) * sz * (kind == 4 ? 3 : 1);
+    const bool to_host = !is_device_ptr(out);
+    if (to_host) HX_TRY(c.b_out.alloc(bytes));
+    double *d_out = to_host ? c.b_out.as<double>() : out;
+    hipStream_t st = rt().stream;
+    const dim3 grid((n2 + 255) / 256, c.nbins);
+    if (kind == 4) {
+        HX_TRY(mix_ctx_binned_product(c, 2, 0));
+        HX_TRY(mix_ctx_binned_product(c, 3, 1));
+        hipLaunchKernelGGL(k_binned_finish<true>, grid, dim3(256), 0, st, c.nbins, n2, c.nbpad, c.l2pad, c.ksplit, c.part[0].as<double>(), c.part[1].as<double>(),
+                           c.d_cs.as<double>(), c.b_norm.as<double>(), d_out);
+    } else {
+        HX_TRY(mix_ctx_binned_product(c, kind == 1 ? 0 : 1, 0));
+        hipLaunchKernelGGL(k_binned_finish<false>, grid, dim3(256), 0, st, c.nbins, n2, c.nbpad, c.l2pad, c.ksplit, c.part[0].as<double>(), (const double *)nullptr,
+                           c.d_cs.as<double>(), c.b_norm.as<double>(), d_out);
+    }
+    HX_HIP(hipGetLastError());
+    if (to_host) HX_TRY(copy_d2h(out, d_out, bytes));  // (complete on return)
     HX_HIP(hipStreamSynchronize(rt().stream));
     return HX_OK;
 }

@@ -16,6 +16,7 @@ from itertools import combinations_with_replacement, product
 import numpy as np
 
 from . import _lib
+from .binning import BinPlan, binned, plans_for, wrap_binned
 from .core import DeviceArray, Result, TocDict, toc_match, update_metadata
 
 logger = logging.getLogger(__name__)
@@ -253,13 +254,7 @@ def angular_power_spectra(alms, alms2=None, *, lmax=None, debias=True, bins=None
         update_metadata(cl, **md)
         res = Result(cl, spin=(s1, s2), axis=-1)
         if bins is not None:
-            from .core import HAVE_HERACLES
-
-            if not HAVE_HERACLES:
-                raise NotImplementedError("binning needs heracles.result.binned (host post-processing, out of scope)")
-            from heracles.result import binned
-
-            res = binned(res, bins, weights)
+            res = binned(res, bins, weights)  # (O(lmax) per block: on the host, heracles/twopoint.py:283-284)
         cls[k1, k2, i1, i2] = res
     logger.info("computed %d cl(s) in %.3f s", len(cls), time.monotonic() - t0)
     return cls
@@ -373,20 +368,51 @@ class MixmatContext:
             self._buffers[shape] = _lib.pinned_empty(shape)
         return self._buffers[shape]
 
-    def __call__(self, cl, spin, out=None):
+    @staticmethod
+    def _kind(spin):
         s1, s2 = (abs(int(v)) for v in spin)
         if (s1, s2) == (0, 0):
-            kind = 1
-        elif sorted((s1, s2)) == [0, 2]:
-            kind = 2
-        elif (s1, s2) == (2, 2):
-            kind = 4
-        else:
-            raise NotImplementedError(f"mixing matrix for spin {tuple(spin)} not supported")
+            return 1
+        if sorted((s1, s2)) == [0, 2]:
+            return 2
+        if (s1, s2) == (2, 2):
+            return 4
+        raise NotImplementedError(f"mixing matrix for spin {tuple(spin)} not supported")
+
+    def __call__(self, cl, spin, out=None):
+        kind = self._kind(spin)
         cl = np.ascontiguousarray(np.asarray(cl, dtype=np.float64))
         shape = (self.l1max + 1, self.l2max + 1)
         out = _lib.result_array((3,) + shape if kind == 4 else shape, out)
         _lib.check(_lib.load().hx_mixctx_apply(self._h, _lib.ptr(cl), cl.shape[0], kind, _lib.ptr(out)))
+        return out
+
+    def set_bins(self, plan):
+        """Bin the OUTPUT multipole of every matrix that ``binned`` builds from now on: ``plan`` is the ``binning.BinPlan`` of the axis
+        (``BinPlan(np.arange(l1max + 1), edges, weights)`` for what ``mixing_matrices(bins=edges, weights=weights)`` asks for).  The
+        binned Wigner-d tables are formed once per plan (hx_mixctx_set_bins)."""
+        n1 = self.l1max + 1
+        if plan.which.size != n1:
+            raise ValueError(f"bin plan for {plan.which.size} multipoles, the matrices have {n1} rows")
+        if plan.nbins < 1:
+            raise ValueError("no bins")
+        which = np.ascontiguousarray(plan.which, dtype=np.int32)
+        w = np.ascontiguousarray(plan.w, dtype=np.float64)
+        norm = np.ascontiguousarray(plan.norm, dtype=np.float64)
+        _lib.check(_lib.load().hx_mixctx_set_bins(self._h, int(plan.nbins), which.ctypes.data, _lib.ptr(w), _lib.ptr(norm)))
+        self.plan = plan
+
+    def binned(self, cl, spin, out=None):
+        """The matrices of ``self(cl, spin)`` with their rows binned by the plan of ``set_bins``: (nbins, l2max + 1), or
+        (3, nbins, l2max + 1) for spin (2, 2) -- ``heracles.result.binned(Result(M, axis=-2), edges, weights).array`` without the
+        full matrix ever being formed (hx_mixctx_apply_binned)."""
+        if getattr(self, "plan", None) is None:
+            raise ValueError("no bins set: call set_bins first")
+        kind = self._kind(spin)
+        cl = np.ascontiguousarray(np.asarray(cl, dtype=np.float64))
+        shape = (self.plan.nbins, self.l2max + 1)
+        out = _lib.result_array((3,) + shape if kind == 4 else shape, out)
+        _lib.check(_lib.load().hx_mixctx_apply_binned(self._h, _lib.ptr(cl), cl.shape[0], kind, _lib.ptr(out)))
         return out
 
     def close(self):
@@ -409,44 +435,94 @@ class MixmatContext:
             pass
 
 
+def _single_axis(value, what):
+    """bins / weights of a result with ONE angular axis: the reference takes one entry or a 1-tuple (heracles/result.py:150-163)."""
+    if isinstance(value, tuple):
+        if len(value) != 1:
+            raise ValueError(f"result and {what} have different number of ell axes")
+        return value[0]
+    return value
+
+
+def request_cost(spin):
+    """Relative cost of one mixing-matrix request: the number of (l, l') products behind it (an E/B key = 2, every other = 1)."""
+    return 2 if all(spin) else 1
+
+
+def split_requests(todo, rank, world):
+    """The share of rank ``rank`` of ``world`` in a request list (``mixing_requests``): requests are independent (one product or two
+    per key, no exchange: SURVEY section 8e, last bullet), so they are dealt by cost -- heaviest first, each to the rank with the least
+    work so far, ties to the lowest rank -- and every rank keeps its share in the order of the list.  Deterministic: all ranks compute
+    the same deal without talking to each other."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside a world of {world}")
+    load = [0] * world
+    owner = [0] * len(todo)
+    for n in sorted(range(len(todo)), key=lambda n: (-request_cost(todo[n][2]), n)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[n] = r
+        load[r] += request_cost(todo[n][2])
+    return [req for n, req in enumerate(todo) if owner[n] == rank]
+
+
 def mixing_matrices(fields, cls, *, l1max=None, l2max=None, l3max=None, bins=None, weights=None,
-                    out=None, progress=None, context=None):
+                    out=None, progress=None, context=None, rank=None, world=None):
     """Mixing matrices for fields from mask spectra (heracles/twopoint.py:316-401): same keys, order, spin dispatch and
     Result wrapping; the arithmetic goes through ONE MixmatContext per distinct (l1max, l2max, l3max), so the tables
-    are built once for the whole job instead of once per matrix.  `context` (a callable (cl, l1max, l2max, l3max, spin)
-    -> array) replaces the GPU path, e.g. to record the requests."""
+    are built once for the whole job instead of once per matrix.
+
+    ``bins`` / ``weights`` (heracles/twopoint.py:391-397, what heracles/cli.py:696-716 passes whenever the configuration has bins): the
+    rows of every matrix binned as ``heracles.result.binned`` does along axis -2.  The binned rows are built DIRECTLY on the GPU from
+    binned Wigner-d tables (``MixmatContext.set_bins`` / ``binned``): the full matrix is never formed and nbins x (l2max + 1) numbers per
+    matrix leave the device.
+    ``context`` (a callable (cl, l1max, l2max, l3max, spin) -> array) replaces the GPU path, e.g. to record the requests; its full
+    matrices are binned on the host.
+    ``rank`` / ``world``: this process computes only its share of the request list (``split_requests``: no collective; the union over the
+    ranks is the single-process result)."""
     out = TocDict() if out is None else out
     progress = _NoProgress() if progress is None else progress
     todo = mixing_requests(fields, cls)
+    if world is not None and world > 1:
+        todo = split_requests(todo, 0 if rank is None else rank, world)
     pending = {}
     for target, ck, spin in todo:
         pending.setdefault(ck, []).append((target, spin))
-    contexts = {}
+    if bins is not None:
+        bins, weights = _single_axis(bins, "bins"), _single_axis(weights, "weight")
+    contexts, plans = {}, {}
+
+    def plan_for(nrows):
+        if nrows not in plans:
+            plans[nrows] = BinPlan(np.arange(nrows), bins, weights)
+        return plans[nrows]
 
     def compute(cl, spin):
+        """the (binned) matrices of one request and the plan that binned them"""
         _, a, b, c = _mm_args(cl, l1max, l2max, l3max)
         if context is not None:
-            return context(cl, a, b, c, spin)
+            mm = context(cl, a, b, c, spin)
+            if bins is None:
+                return mm, None
+            plan = plan_for(np.shape(mm)[-2])
+            return plan.apply(mm, np.ndim(mm) - 2), plan
         if (a, b, c) not in contexts:
             contexts[a, b, c] = MixmatContext(a, b, c)
-        return contexts[a, b, c](cl, spin)
+            if bins is not None:
+                contexts[a, b, c].set_bins(plan_for(a + 1))
+        ctx = contexts[a, b, c]
+        return (ctx(cl, spin), None) if bins is None else (ctx.binned(cl, spin), ctx.plan)
 
     try:
         for n, ck in enumerate(cls, start=1):
             progress.update(n, len(cls))
             for target, spin in pending.get(ck, ()):
                 with progress.task(f"({target[0]}, {target[1]}, {target[2]}, {target[3]})"):
-                    mm = compute(np.asarray(cls[ck]), spin)
+                    mm, plan = compute(np.asarray(cls[ck]), spin)
                     # second to last axis is the OUTPUT multipole (heracles/twopoint.py:391-393)
-                    mm = Result(mm, spin=spin, ell=np.arange(mm.shape[-2]), axis=-2)
-                    if bins is not None:
-                        from .core import HAVE_HERACLES
-
-                        if not HAVE_HERACLES:
-                            raise NotImplementedError("binning needs heracles.result.binned")
-                        from heracles.result import binned
-
-                        mm = binned(mm, bins, weights)
+                    if plan is None:
+                        mm = Result(mm, spin=spin, ell=np.arange(mm.shape[-2]), axis=-2)
+                    else:
+                        mm = wrap_binned(mm, spin, (mm.ndim - 2,), [plan])
                     out[target] = mm
     finally:
         for ctx in contexts.values():

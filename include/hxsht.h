@@ -219,6 +219,17 @@ typedef struct hx_mixctx hx_mixctx;
 hx_mixctx *hx_mixctx_create(int l1max, int l2max, int l3max);
 int hx_mixctx_apply(hx_mixctx *ctx, const double *cl, int ncl, int kind, double *out);
 void hx_mixctx_destroy(hx_mixctx *ctx);
+/* The rows of those matrices BINNED, as heracles.twopoint.mixing_matrices(..., bins, weights) returns them (heracles/twopoint.py:391-397:
+ * heracles.result.binned along axis -2, heracles/result.py:124-248 -- what heracles/cli.py:696-716 asks for whenever the configuration
+ * has `bins`, e.g. `bins = 32 log 2l+1` in examples/heracles.cfg:4-6).  Binning is linear in the rows, so the numerators are formed as
+ * (binned Wigner-d tables) x diag(w xi) x (tables)^T -- an (nbins x N)(N x (l2max+1)) product instead of the full matrix followed by a
+ * host loop over its columns (5 s per (3, 6145, 6145) matrix in the reference's function), and only nbins x (l2max+1) doubles leave the GPU.
+ *   hx_mixctx_set_bins: which [l1max+1] = bin of output multipole l (0 .. nbins-1; -1: in no bin), w [l1max+1] = its weight,
+ *     norm [nbins] = the divisor of every bin (the reference: the summed weight); host arrays; the binned tables follow lazily.
+ *   hx_mixctx_apply_binned: kind as hx_mixctx_apply; out (nbins, l2max+1) or (3, nbins, l2max+1), host or device;
+ *     out[b][l2] = sum_{l in b} w_l M[l][l2] / norm[b], exactly 0 where the sum is exactly 0 (heracles/result.py:132-135). */
+int hx_mixctx_set_bins(hx_mixctx *ctx, int nbins, const int *which, const double *w, const double *norm);
+int hx_mixctx_apply_binned(hx_mixctx *ctx, const double *cl, int ncl, int kind, double *out);
 /* The same loop as ONE call over a list of masks:
  *   cls   [nmask][ncl] mask spectra; kinds [nmask] bit mask: 1 -> spin (0,0) into out00[k]; 2 -> spin (0,2)/(2,0) into
  *   out02[k]; 4 -> spin (2,2) into outeb[k] (3 matrices as hx_mixmat_eb).  Output pointers host or device. */
