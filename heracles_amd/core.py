@@ -12,7 +12,7 @@ from typing import Any
 
 import numpy as np
 
-try:  # pragma: no cover - exercised only where heracles is installed
+try:  # (the branch an installed Heracles takes; run by tests/test_production_config.py through the reference tree)
     from heracles.core import TocDict as _TocDict, toc_match as _toc_match
     from heracles.core import update_metadata as _update_metadata
     from heracles.result import Result as _Result
@@ -125,7 +125,7 @@ class Result:
         return self.array.dtype
 
 
-if HAVE_HERACLES:  # pragma: no cover
+if HAVE_HERACLES:
     TocDict = _TocDict  # noqa: F811
     toc_match = _toc_match  # noqa: F811
     update_metadata = _update_metadata  # noqa: F811
