@@ -1110,8 +1110,13 @@ __global__ __launch_bounds__(256, 2) void k_legendre_duo(LegParams A, const doub
         // chain is live, 2 = mixed.  A chain is live from 2^-SB on; with SB < 300 "dead at the entry" is not enough for mode 1: near l = m a
         // step multiplies by up to sqrt(2m / (l - m)), and a chain that enters the first block at 2^-100 can leave it at 1e-10.  So a lane
         // counts as dead for the block only below 2^-(SB + E_b) at the entry, E_b = 60, 34, 26, 24, ... 8 for b = 0, 1, 2, 3 ... >= 11:
-        // calibrated (tools/calibrate_dead_blocks.py: both spins, m up to lmax = 6144, all rings) so that nothing above 2^-75 of a
-        // value of lambda is left out, with 8 bits to spare; the matrix work of 4 % of the blocks goes away against SB = 300.
+        // calibrated (tools/calibrate_dead_blocks.py: long-double emulation of both recursions on the plan's own rings) so that nothing
+        // above 2^-75 of a value of lambda is left out.  The margin NEEDED saturates with m and lmax -- block 0 / 1 / 2: 51.8 / 25.9 / 17.6
+        // bits at lmax 6144 (m 5944), 52.0 / 26.0 / 17.9 at lmax 8000 (m 7800), 52.2 / 26.3 / 18.1 at lmax 12288 (m 12088), nside 8192:
+        // the chains that matter are those of the rings next to the pruning limit, whose growth is set by m / (l sin theta), not by m
+        // (profiles/r06_dead_block_calibration.txt) -- so these constants hold for every plan the library accepts, with >= 7.7 bits
+        // to spare (tests/test_host_logic.py holds them to >= 6 at lmax 6144, 8000 and 12288).  The matrix work of 4 % of the blocks
+        // goes away against SB = 300.
         auto set_mode = [&](int b) __attribute__((always_inline)) {
             const int eb = b == 0 ? 60 : (b == 1 ? 34 : (30 - 2 * b > 8 ? 30 - 2 * b : 8));
             auto lane_dead = [&](int c) __attribute__((always_inline)) {

@@ -263,7 +263,8 @@ __global__ __launch_bounds__(256, 2) void k_synth_duo(SynDuoParams A, const doub
         }
     };
     // (SCB < 300: a lane is dead for block b only below 2^-(SCB + E_b) at the entry -- see set_mode of k_legendre_duo; blocks of 16 l:
-    // E_b = 26, 12, 8, 8, ... from tools/calibrate_dead_blocks.py 16, eight bits to spare)
+    // E_b = 26, 12, 8, 8, ... from tools/calibrate_dead_blocks.py 16: needed 17.0 / 3.8 / 0 at lmax 12288 (m 12088, nside 8192) as at
+    // lmax 6144 (16.9 / 3.7): >= 8 bits to spare at every size, profiles/r06_dead_block_calibration.txt)
     auto set_mode = [&](int b) __attribute__((always_inline)) {
         const int eb = b == 0 ? 26 : (b == 1 ? 12 : 8);
         auto lane_dead = [&](int c) __attribute__((always_inline)) {

@@ -369,18 +369,30 @@ def test_result_array_checks_the_callers_out():
         _lib.result_array((2, 2), Shaped())
 
 
-@pytest.mark.parametrize("blk,spin,m", [(32, 2, 2500), (16, 2, 5800), (32, 0, 4000)])
-def test_dead_block_margins_cover_the_growth_of_the_recursion(blk, spin, m):
+@pytest.mark.parametrize("blk,spin,m,lmax,nside", [
+    (32, 2, 2500, 6144, None), (16, 2, 5800, 6144, None), (32, 0, 4000, 6144, None),      # round 5: lmax 6144, a grid of colatitudes
+    (32, 2, 5944, 6144, 4096), (32, 0, 5944, 6144, 4096), (16, 2, 5944, 6144, 4096),      # the plan's own rings, m up to lmax - 200
+    (32, 2, 7800, 8000, 8192), (32, 0, 7800, 8000, 8192), (16, 2, 7800, 8000, 8192),      # examples/heracles.cfg:56-62: lmax 8000
+    (32, 2, 7000, 8000, 4096), (16, 0, 7800, 8000, 4096),
+    (32, 2, 12088, 12288, 8192), (32, 0, 12088, 12288, 8192), (16, 2, 12088, 12288, 8192), (16, 0, 10500, 12288, 8192),
+    (32, 2, 9000, 12288, 8192), (32, 2, 300, 12288, 8192),
+])
+def test_dead_block_margins_cover_the_growth_of_the_recursion(blk, spin, m, lmax, nside):
     """k_legendre_duo / k_synth_duo skip the matrix work of a block whose chains all enter it below 2^-(100 + E_b).  The margins E_b in the
     kernels must cover what a skipped chain can reach inside the block (near l = m a step multiplies by up to sqrt(2m / (l - m))): the
     long-double emulation of the normalised recursions (tools/calibrate_dead_blocks.py) gives the margin needed for nothing above 2^-75 of
-    a value of lambda to be left out; the kernels keep at least 6 bits on top of it."""
+    a value of lambda to be left out; the kernels keep at least 6 bits on top of it.  Round 6: the margin needed SATURATES with m (the rings
+    that matter are those next to the pruning limit, where the growth depends on m / (l sin theta), not on m): 52.2 / 26.3 / 18.1 bits for
+    the first three 32-l blocks at lmax 12288, m 12088 against 51.8 / 25.9 / 17.6 at lmax 6144 -- the constants hold for every plan the
+    library accepts (nside <= 8192, lmax <= 3 nside / 2); on the rings of the plan itself (nside given) as on a grid of colatitudes.
+    Full record: profiles/r06_dead_block_calibration.txt."""
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("calib", os.path.join(os.path.dirname(__file__), "..", "tools", "calibrate_dead_blocks.py"))
     calib = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(calib)
-    needed = calib.need(m, spin, blk=blk, nbmax=14, nth=1500)
-    assert needed[0] > 10  # the first block is the one that needs a margin at all
+    needed = calib.need(m, spin, blk=blk, nbmax=14, nth=1500, lmax=lmax, nside=nside)
+    if m >= 1000:
+        assert needed[0] > 10  # the first block is the one that needs a margin at all
     for b, e in enumerate(needed):
         assert calib.kernel_margin(b, blk) >= e + 6, (b, e)

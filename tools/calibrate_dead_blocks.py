@@ -1,10 +1,30 @@
 """Calibration of the per-block entry thresholds of k_legendre_duo / k_synth_duo (set_mode): for every 32-l block b of an order m, the margin
 E_b (bits below 2^-100) a chain must have at the entry of the block so that no value of lambda above 2^-75 is reached inside it by a ring
-that is skipped.  Emulates the normalised recursions of hx_sht.hip (k_init_norm0 / k_init_norm2) in long double.  CPU only, ~10 min."""
+that is skipped.  Emulates the normalised recursions of hx_sht.hip (k_init_norm0 / k_init_norm2) in long double.  CPU only.
+
+    python tools/calibrate_dead_blocks.py [BLK [LMAX [NSIDE]]]      BLK: 32 (k_legendre_duo) or 16 (k_synth_duo); default 32 6144
+
+With NSIDE the rings are the plan's own: the colatitudes of the HEALPix rings of that nside that libsharp's mlim rule (ring_mlim of
+hx_analysis.hip) keeps for the order m; without it a 3000-point grid of colatitudes from the pruning limit to the equator (round 5).
+Round 6 (VERDICT r5 Next #3): run for lmax 8000 (examples/heracles.cfg:56-62) and 12288 with m up to lmax - 200; the record is
+profiles/r06_dead_block_calibration.txt and the kernels' margins E_b follow it."""
 import numpy as np, sys
 ld=np.longdouble
-LMAX=6144
+LMAX=int(sys.argv[2]) if __name__ == "__main__" and len(sys.argv)>2 else 6144
 BLK=int(sys.argv[1]) if __name__ == "__main__" and len(sys.argv)>1 else 32   # l per block: 32 (k_legendre_duo), 16 (k_synth_duo)
+def ring_mlim(lmax, spin, sth, cth):
+    """ring_mlim of hx_analysis.hip (libsharp's published sharp_get_mlim): rings with m > mlim are skipped"""
+    ofs=max(lmax*0.01,100.0)
+    b=-2*spin*np.abs(cth); t1=lmax*sth+ofs; c=float(spin)*spin-t1*t1
+    discr=b*b-4*c
+    res=np.where(discr>0,(-b+np.sqrt(np.maximum(discr,0)))/2,lmax)
+    return np.floor(np.minimum(res,lmax)+0.5).astype(np.int64)
+def healpix_rings(nside):
+    """colatitudes of the northern rings and the equator (2 nside), as long doubles"""
+    i=np.arange(1,2*nside+1,dtype=ld); ns=ld(nside)
+    z=np.where(i<ns, 1-i*i/(3*ns*ns), ld(4)/3-2*i/(3*ns))
+    s=np.sqrt((1-z)*(1+z))
+    return np.arctan2(s,z), s, z
 def chains0(m, th, nb):
     x=np.cos(th); s=np.sin(th)
     logc=0.5*(np.sum(np.log(np.arange(1,2*m+2,2,dtype=np.float64)))-np.sum(np.log(np.arange(2,2*m+1,2,dtype=np.float64)))-np.log(4*np.pi))
@@ -46,12 +66,17 @@ def chains2(m, th, nb, sign):
         prev=mu[-1]; mu.append(nxt); am1=a0; a0=a1; alpha.append(a0)
     MU=np.abs(np.array(mu)); AL=np.abs(np.array(alpha))
     return MU*AL[:,None], MU
-def need(m, spin, blk=None, nbmax=192, nth=3000):
-    global BLK
+def need(m, spin, blk=None, nbmax=192, nth=3000, lmax=None, nside=None):
+    global BLK, LMAX
     if blk: BLK=blk
+    if lmax: LMAX=lmax
     nb=min((LMAX-max(m,2))//BLK+1, nbmax)
-    smin=min(1.0,m/(1.3*LMAX)+1e-4)
-    th=np.linspace(np.arcsin(smin),np.pi/2,nth).astype(ld)
+    if nside:
+        th,s_,z_=healpix_rings(nside)
+        th=th[ring_mlim(LMAX,spin,s_.astype(np.float64),z_.astype(np.float64))>=m]
+    else:
+        smin=min(1.0,m/(1.3*LMAX)+1e-4)
+        th=np.linspace(np.arcsin(smin),np.pi/2,nth).astype(ld)
     if spin==0: sets=[chains0(m,th,nb)]
     else: sets=[chains2(m,th,nb,+1), chains2(m,th,nb,-1)]
     out=[]
@@ -76,7 +101,10 @@ def kernel_margin(b, blk):
 
 
 if __name__ == "__main__":
+    NSIDE=int(sys.argv[3]) if len(sys.argv)>3 else None
+    ms=[m for m in (30,300,1000,3000,4500,5800,7000,7800,9000,10500,11500,12088) if m<=LMAX-200]+[LMAX-200]
+    print(f"# BLK={BLK} LMAX={LMAX} rings: "+(f"HEALPix nside {NSIDE} kept by mlim" if NSIDE else "3000-point grid"),flush=True)
     for spin in (0,2):
-        for m in (30,300,1000,3000,4500,5800):
-            r=need(m,spin)
+        for m in sorted(set(ms)):
+            r=need(m,spin,nbmax=40,nside=NSIDE)
             print("spin",spin,"m",m,"E_b:",[round(float(v),1) for v in r[:10]],"| b=10..:",round(float(max(r[10:] or [0])),1), "| b=30..:",round(float(max(r[30:] or [0])),1),flush=True)
