@@ -149,6 +149,11 @@ def self_launch(ngpus):
     for r in range(ngpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: the pool's host driver supports dmabuf IPC only; with the legacy mode RCCL (and any sharing of device
+        # memory between processes) fails at hipIpcGetMemHandle with "invalid argument".  The variable is exported by the image here and on
+        # the GPU boxes (the environment contract of this build: task statement, "Environment"); setdefault only carries it into ranks that are
+        # started from a shell that lost it, and never overrides a value the caller chose.  Evidence: the contract, not a run of ours --
+        # no multi-GPU node has run this code.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     # a rank that dies leaves the others blocked in their next collective: once one has failed, the rest get a grace period and
@@ -196,7 +201,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # HX_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box only): every rank uses device 0 and the
     # collectives run over gloo on host copies, so the N > 1 code path can be exercised without N GPUs
-    share = os.environ.get("HX_BENCH_SHARE_GPU") == "1"
+    share_gpu = os.environ.get("HX_BENCH_SHARE_GPU") == "1"
+    share = share_gpu
     if share:
         local = 0
     torch.cuda.set_device(local)
@@ -226,6 +232,22 @@ def main():
 
     import heracles_amd as hx
     from heracles_amd import distributed as hxd
+
+    backend = dist.get_backend() if world > 1 else None  # "nccl" (= RCCL on ROCm) or "gloo" (the one-GPU rehearsal): named in the line as it is
+    comm = {"nccl": "RCCL", "gloo": "gloo (host copies: rehearsal on one GPU, NOT RCCL)", None: "none"}.get(backend, str(backend))
+
+    def agree_or_leave(ok, tag):
+        """after a phase that may have failed on this rank alone: the verdict of all ranks through the rendezvous store (no collective).
+        0 = all fine, world = all failed (the common fallback is safe); anything else: this process leaves the job with a non-zero code
+        (the launcher tears the other ranks down) instead of pairing up mismatched collectives"""
+        if world == 1:
+            return 0 if ok else 1
+        nfail = hxd.unanimous(ok, tag)
+        if 0 < nfail < world:
+            print(f"[bench rank {rank}] {tag}: {nfail} of {world} ranks failed -- leaving the job", file=sys.stderr, flush=True)
+            sys.stdout.flush()
+            os._exit(5)
+        return nfail
 
     hx.init(local)
     nside, lmax, nbins = args.nside, args.lmax, args.nbins
@@ -334,11 +356,14 @@ def main():
         hx._lib.profile_enable(False)
     except Exception as exc:  # noqa: BLE001
         # N > 1 only: the job that grows with N is the side figure (`value_weak`); if it fails -- on every rank alike: its collectives have
-        # not run over RCCL before the driver's first N > 1 run -- the fixed job below still gets its line.  (A failure on ONE rank leaves
-        # the others waiting in a collective, here as anywhere.)  The per-GPU kernel figures then come from the local transforms alone.
+        # not run over RCCL before the driver's first N > 1 run -- the fixed job below still gets its line.  The per-GPU kernel figures
+        # then come from the local transforms alone.
         if world == 1:
             raise
         weak_error = f"{type(exc).__name__}: {exc}"[:400]
+    # a failure on ONE rank must not go on into the collectives of the routes below while the others are elsewhere: unanimous or out
+    if agree_or_leave(weak_error is None, "weak-leg"):
+        weak_error = weak_error or "failed on every rank"
         hx._lib.profile_enable(True)
         hx._lib.profile_reset()
         for _ in range(steps1):
@@ -473,12 +498,15 @@ def main():
                                    "maps_total": len(per_set), "pairs": len(ms.pairs), "orders_first_count_step": ms.sets,
                                    "checksum": float(np.abs(cls_m).sum()), "kernels_rank0": leg_kernels(args.steps),
                                    "what": "ring Fourier stage of the rank's maps, all-to-all of the ring modes by owner of the order m (rank q: m = q, "
-                                           "q + N, ...) over RCCL, Legendre stage of ALL components on the rank's orders, partial Cl, all-reduce"}
+                                           f"q + N, ...) over {comm}, Legendre stage of ALL components on the rank's orders, partial Cl, all-reduce",
+                                   "backend": backend}
             del s0, s2, ms
         except Exception as exc:  # noqa: BLE001
             hx._lib.profile_enable(False)
             routes["m_sharded"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"[:400]}
             cls_m = None
+        # (inside run() the ranks agree before every collective; a failure around it -- set-up, the seeded maps -- may be this rank's alone)
+        agree_or_leave(routes["m_sharded"].get("value") is not None, "route-m-sharded")
         torch.cuda.empty_cache()
 
         rows, wk = None, None
@@ -506,12 +534,14 @@ def main():
                                     "maps_total": len(per_set), "pairs": len(wk.pairs), "maps_of_rank": [len(m_) for m_ in wk.maps_of],
                                     "kernels_rank0": leg_kernels(args.steps),
                                     "what": "the maps dealt to the ranks by cost (a spin-2 map = 3 units), transforms into the rank's shard of ONE buffer, "
-                                            "in-place all-gather per spin over RCCL (spin-2 part under the spin-0 transform), tiled pair split, Cl blocks gathered on rank 0"}
+                                            f"in-place all-gather per spin over {comm} (spin-2 part under the spin-0 transform), tiled pair split, Cl blocks gathered on rank 0",
+                                    "backend": backend}
             del v0, v2
         except Exception as exc:  # noqa: BLE001
             hx._lib.profile_enable(False)
             routes["all_gather"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"[:400]}
             rows = None
+        agree_or_leave(routes["all_gather"].get("value") is not None, "route-all-gather")  # (a rank that failed alone leaves; see agree_or_leave)
 
         # ---- verification at N > 1 (outside every timed region), on the results of the two timed routes -- the same seeded maps went
         # through both: (i) the m-sharded route's spectra against the all-gather route's rows, (ii) map pairs of the latter against
@@ -538,6 +568,55 @@ def main():
         torch.cuda.empty_cache()
         best = max((k for k in routes if routes[k].get("value")), key=lambda k: routes[k]["value"], default=None)
         strong = dict(routes[best], route=best) if best else {"value": None, "error": "both fixed-job routes failed", "route": None}
+
+    # ---- the mixing-matrix request list of BASELINE configs[4] (13 bins x (Positions on the visibility mask, Shears and a scalar on the
+    # weight mask): 780 keys) with the configuration file's bins (32 log 2l+1, examples/heracles.cfg:4-6) -- the loop of
+    # heracles/twopoint.py:354-397 as heracles/cli.py:696-716 runs it.  Independent per key: dealt to the ranks by cost, no collective
+    # (SURVEY 8e last bullet); every rank builds its keys through its own context; seconds = max over the ranks. ----
+    mix_list = None
+    if not args.no_mixmat:
+        import types as _types
+
+        from heracles_amd.twopoint import mixing_requests, request_cost, split_requests
+
+        Lm = args.mixmat_lmax or lmax
+        ellm = np.arange(Lm + 1)
+        nb13 = 13
+        mfields = {"POS": _types.SimpleNamespace(mask="VIS", spin=0), "SHE": _types.SimpleNamespace(mask="WHT", spin=2),
+                   "CON": _types.SimpleNamespace(mask="WHT", spin=0)}
+        mcls = {}
+        for a_, b_ in (("VIS", "VIS"), ("VIS", "WHT"), ("WHT", "WHT")):
+            for i_ in range(nb13):
+                for j_ in range(i_ if a_ == b_ else 0, nb13):
+                    mcls[a_, b_, i_, j_] = 4 * np.pi * 0.35 * np.exp(-ellm * (ellm + 1) / (3000.0 + 40.0 * i_ + 7.0 * j_)) + 1e-3 / (1.0 + ellm) ** 2
+        edges = np.unique(np.geomspace(2, Lm + 1, 33).astype(int))
+        todo_all = mixing_requests(mfields, mcls)
+        my_keys = split_requests(todo_all, rank, world)
+        try:
+            hx.mixing_matrices(mfields, {k: mcls[k] for k in list(mcls)[:2]}, l1max=Lm, l2max=Lm, l3max=Lm, bins=edges, weights="2l+1")  # warm-up
+            sync()
+            tml = time.perf_counter()
+            mine_mm = hx.mixing_matrices(mfields, mcls, l1max=Lm, l2max=Lm, l3max=Lm, bins=edges, weights="2l+1", rank=rank, world=world)
+            sync()
+            dml = time.perf_counter() - tml
+            err_ml = None if len(mine_mm) == len(my_keys) else f"{len(mine_mm)} keys built, {len(my_keys)} dealt"
+        except Exception as exc:  # noqa: BLE001
+            dml, err_ml, mine_mm = float("nan"), f"{type(exc).__name__}: {exc}"[:400], {}
+        if agree_or_leave(err_ml is None, "mixmat-list") == 0:
+            if world > 1:
+                tt_ = torch.tensor([dml], dtype=torch.float64, device="cpu" if share_gpu else dev)
+                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                dml = float(tt_.item())
+            first = next(iter(mine_mm.values())) if mine_mm else None
+            mix_list = {"keys": len(todo_all), "keys_this_rank": len(my_keys), "cost_this_rank": sum(request_cost(r_[2]) for r_ in my_keys),
+                        "seconds": dml, "keys_per_s": len(todo_all) / dml, "L": Lm, "bins": int(edges.size - 1), "weights": "2l+1",
+                        "shape_of_a_key": None if first is None else list(np.shape(first.array)),
+                        "what": f"heracles_amd.mixing_matrices(fields, cls, l1max=l2max=l3max={Lm}, bins=32 log edges, weights='2l+1', rank, world): the "
+                                f"{len(todo_all)} keys of 13 bins x (POS on VIS, SHE + CON on WHT) dealt to {world} rank(s) by cost, binned rows built on the "
+                                "GPU (no full matrix, no collective), Result objects on the host; wall seconds, max over the ranks"}
+        else:
+            mix_list = {"keys": len(todo_all), "error": err_ml or "failed on every rank"}
+        del mine_mm
 
     out = None
     if rank == 0:
@@ -740,6 +819,39 @@ def main():
                    "gemm_tflops_algorithmic_is": "SURVEY 8d's 2 (l1max + 1)(l2max + 1) N per product / kernel time: the symmetric product is computed for the "
                                                  "upper triangle of tiles only, so this exceeds what the matrix pipe executes (gemm_tflops_executed) -- not a utilisation",
                    "checksum": float(np.abs(mm[2] - (mm[0] - mm[1])).max())}
+            # the production call: the rows binned (bins = 32 log 2l+1), built directly from binned Wigner-d tables -- seconds per key, host -> host
+            from heracles_amd.binning import BinPlan
+
+            edges_b = np.unique(np.geomspace(2, L + 1, 33).astype(int))
+            plan_b = BinPlan(ell, edges_b, "2l+1")
+            with hx.MixmatContext(L, L, L) as cx:
+                tb0 = time.perf_counter()
+                cx.set_bins(plan_b)
+                cx.binned(wl, (2, 2))
+                t_first = time.perf_counter() - tb0
+                per_kind = {}
+                for nm_, sp_ in (("mixmat_eb_22", (2, 2)), ("mixmat_02", (0, 2)), ("mixmat_00", (0, 0))):
+                    cx.binned(wl, sp_)
+                    ts_ = []
+                    for _ in range(7):
+                        tb = time.perf_counter()
+                        rb = cx.binned(wl, sp_)
+                        ts_.append(time.perf_counter() - tb)
+                    per_kind[nm_] = {"seconds": float(np.median(ts_)), "seconds_all": ts_, "shape": list(rb.shape)}
+                # against the host binning of the full matrices of the same context (outside every timed region)
+                full_b = cx(wl, (2, 2), out=pin)
+                want_b = plan_b.apply(full_b, 1)
+                err_b = float(np.abs(cx.binned(wl, (2, 2)) - want_b).max() / np.abs(want_b).max())
+            t_host = time.perf_counter()
+            plan_b.apply(mm, 1)
+            t_host = time.perf_counter() - t_host
+            mix["binned"] = {"L": L, "bins": int(plan_b.nbins), "weights": "2l+1", "seconds_per_key": per_kind["mixmat_eb_22"]["seconds"],
+                             "per_kind": per_kind, "seconds_first_key_incl_tables": t_first,
+                             "max_err_vs_binned_full_matrix_over_max": err_b, "host_binning_of_a_full_matrix_seconds": t_host,
+                             "what": "MixmatContext.set_bins + binned(cl, spin): rows of the mixing matrices binned as heracles.result.binned does "
+                                     "(heracles/twopoint.py:391-397), numerators = (binned Wigner-d tables) diag(w xi) (tables)^T on the matrix unit, host -> host "
+                                     "(cl on the host in, (3, bins, L + 1) numpy array out), median of 7; the reference bins the full matrix on the host "
+                                     "column by column; host_binning_of_a_full_matrix_seconds is THIS repository's vectorised host rule on the same matrix"}
         peaks = hx._lib.measure_peaks()
         ncomp_set = sum(2 if s_ else 1 for s_ in per_set)
         set_name = f"{nbins} bins x ({'2 spin-0 + 1 spin-2' if args.workload == 'euclid' else 'spin-0, spin-2'}) maps"
@@ -760,15 +872,15 @@ def main():
             cfg_maps, cfg_pairs, cfg_mine = len(per_set), len(per_set) * (len(per_set) + 1) // 2, None
             workload = (f"{set_name} in all = {len(per_set)} maps / {ncomp_set} components sharded over {world} GPU(s), {common}; "
                         f"{cfg_pairs} auto+cross map pairs: the same job at every N")
-            par = {"m_sharded": f"sharded by the order m over {world} GPUs: ring modes all-to-all (RCCL), full-batch Legendre stage on m = rank mod {world}, Cl all-reduce",
-                   "all_gather": f"maps dealt to {world} GPUs by cost, RCCL all-gather of alms, tiled pair split",
+            par = {"m_sharded": f"sharded by the order m over {world} GPUs: ring modes all-to-all ({comm}), full-batch Legendre stage on m = rank mod {world}, Cl all-reduce",
+                   "all_gather": f"maps dealt to {world} GPUs by cost, all-gather of alms over {comm}, tiled pair split",
                    None: "both fixed-job routes failed"}[strong.get("route")]
             prof_line = strong.get("kernels_rank0") or {}
         else:
             cfg_maps, cfg_pairs, cfg_mine = nmaps_total, npairs, len(mine)
             workload = (f"{set_name} {'per GPU' if world > 1 else 'in all'} = {nmaps_total} maps / {sum(2 if s_ else 1 for s_ in spins)} components "
                         f"over {world} GPU(s), {common}; {npairs} auto+cross map pairs")
-            par = f"maps dealt to {world} GPUs by cost, RCCL all-gather of alms, tiled pair split" if world > 1 else "1 GPU"
+            par = f"maps dealt to {world} GPUs by cost, all-gather of alms over {comm}, tiled pair split" if world > 1 else "1 GPU"
             prof_line = prof
         out = {
             "metric": "map->Cl pairs/sec + mixing-matrix build sec, nside=%d lmax=%d" % (nside, lmax),
@@ -778,7 +890,7 @@ def main():
             "config": {"workload": workload,
                        "nside": nside, "lmax": lmax, "maps_total": cfg_maps, "maps_this_rank": cfg_mine, "pairs": cfg_pairs,
                        "pix_weights": ("synthetic array without symmetry (generic path)" if args.generic_weights else "synthetic weights in healpy's compressed format, expanded to the full sky (symmetric like healpy's)") + ", applied in the timed path",
-                       "parallelism": par},
+                       "parallelism": par, "backend": backend},
             "verified": (None if verify is None and verify_multi is None
                          else bool((verify is None or verify.get("ok")) and (world == 1 or (verify_multi or {}).get("ok"))
                                    and (weak_check is None or weak_check["ok"]))),
@@ -795,6 +907,7 @@ def main():
             "single_map_transforms": single,
             "mixmat_build_sec": mix["seconds"] if mix else None,
             "mixmat": mix,
+            "mixmat_list": mix_list,
             "roofline": roofline,
             "roofline_spin0_kernel": roofline_s0,
             "cpu_baseline": cpu,

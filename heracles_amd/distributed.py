@@ -305,8 +305,16 @@ class HipStages:
 
         return int(_lib.load().hx_ring_modes_size(self.plan._h, int(count)))
 
-    def ring_modes(self, maps, sets, pix_weights=None, ring_weights=None):
-        """maps (ncomp, npix) -> one float64 device tensor per set of orders (first, count, step): (ncomp * modes_size(count),)."""
+    def send_buffer(self, ncomp, sets):
+        """One flat float64 device tensor that holds the blocks of ``ring_modes(maps of ncomp components, sets)`` side by side, set after
+        set: the send buffer of the exchange (``ring_modes(..., out=)`` writes into it, no copy in between)."""
+        import torch
+
+        return torch.empty(ncomp * sum(self.modes_size(c) for (_, c, _) in sets), dtype=torch.float64, device=self.device)
+
+    def ring_modes(self, maps, sets, pix_weights=None, ring_weights=None, out=None):
+        """maps (ncomp, npix) -> one float64 device tensor per set of orders (first, count, step): (ncomp * modes_size(count),).
+        ``out`` (``send_buffer(ncomp, sets)``): the blocks are views of it, written in place by hx_ring_modes (per-set output pointers)."""
         import ctypes as C
 
         import torch
@@ -315,7 +323,16 @@ class HipStages:
 
         ncomp = maps.shape[0]
         ns = len(sets)
-        outs = [torch.empty(ncomp * self.modes_size(c), dtype=torch.float64, device=self.device) for (_, c, _) in sets]
+        if out is None:
+            outs = [torch.empty(ncomp * self.modes_size(c), dtype=torch.float64, device=self.device) for (_, c, _) in sets]
+        else:
+            sizes = [ncomp * self.modes_size(c) for (_, c, _) in sets]
+            if out.numel() != sum(sizes) or out.dtype != torch.float64 or not out.is_contiguous():
+                raise ValueError("ring_modes: out is not the send buffer of these sets")
+            outs, o = [], 0
+            for n_ in sizes:
+                outs.append(out[o : o + n_])
+                o += n_
         if ncomp == 0:
             return outs
         step = sets[0][2]
@@ -402,6 +419,7 @@ class MShardedTwoPoint:
         self.sets = order_sets(lmax, world)      # (first, count, step) of every rank: the same for both spins
         self.orders = self.sets[rank]
         self._alm = None
+        self._send = {}  # per part (spin 0 / spin 2): (ncomp, the send buffer of the exchange)
         import inspect
 
         try:  # (a kernel without the keyword sums over all orders: the alms are zero outside this rank's)
@@ -420,10 +438,16 @@ class MShardedTwoPoint:
             self._alm = self.stages.zeros_alm(self.nc0 + self.nc2, self.nlm)
         return self._alm
 
-    def _all_to_all_begin(self, send_blocks, ncomp_of):
+    def _all_to_all_begin(self, send_blocks, ncomp_of, flat=None):
         """Start the all-to-all of one part (the blocks of ``ncomp_of[s]`` components from every rank s); returns a token for
         ``_all_to_all_end``.  Over RCCL the transfer runs asynchronously on the communicator's stream; over gloo device blocks go through
-        host copies (complete on return)."""
+        host copies (complete on return).  ``flat``: the one buffer the blocks are views of, side by side (``HipStages.send_buffer``) -- it is
+        sent as it is; without it the blocks are concatenated first (stage objects that return separate blocks: the CPU tests').
+        A part that is empty on EVERY rank (no map of that spin in the job) is not a collective at all.  ``HX_MSHARD_BLOCKING=1``: the
+        blocking exchange of round 4 instead of the asynchronous one (an A/B switch for the first run over RCCL: the asynchronous path
+        has only run over gloo and in one-GPU rehearsals -- RCCL parity of it is unpinned)."""
+        import os
+
         import torch
         import torch.distributed as dist
 
@@ -431,9 +455,11 @@ class MShardedTwoPoint:
         sizes_out = [ncomp_of[s] * size for s in range(self.world)]
         if self.world == 1:
             return (send_blocks[0], None, sizes_out, None)
+        if sum(ncomp_of) == 0:  # (identical on all ranks: everybody skips)
+            return (torch.empty(0, dtype=torch.float64, device=send_blocks[0].device), None, sizes_out, None)
         gloo = dist.get_backend(self.group) == "gloo"
         on_dev = send_blocks[0].is_cuda
-        send = torch.cat([b.reshape(-1) for b in send_blocks])
+        send = flat if flat is not None else torch.cat([b.reshape(-1) for b in send_blocks])
         if gloo and on_dev:
             send = send.cpu()
         recv = torch.empty(sum(sizes_out), dtype=torch.float64, device=send.device)
@@ -441,6 +467,11 @@ class MShardedTwoPoint:
         if gloo and on_dev:
             dist.all_to_all_single(recv, send, output_split_sizes=sizes_out, input_split_sizes=sizes_in, group=self.group)
             return (recv.to(send_blocks[0].device), None, sizes_out, None)
+        if os.environ.get("HX_MSHARD_BLOCKING") == "1":
+            dist.all_to_all_single(recv, send, output_split_sizes=sizes_out, input_split_sizes=sizes_in, group=self.group)
+            if recv.is_cuda:
+                torch.cuda.current_stream(recv.device).synchronize()
+            return (recv, None, sizes_out, None)
         h = dist.all_to_all_single(recv, send, output_split_sizes=sizes_out, input_split_sizes=sizes_in, group=self.group, async_op=True)
         return (recv, h, sizes_out, send)  # (send is kept alive until the transfer has finished)
 
@@ -488,30 +519,39 @@ class MShardedTwoPoint:
         n0, n2 = self.n0_of[self.rank], self.n2_of[self.rank]
         c2_of = [2 * v for v in self.n2_of]
 
-        def modes_of(maps, ncomp, npix):
+        def modes_of(maps, ncomp, npix, slot):
+            """the blocks of this rank's maps of one spin, one per destination rank, and the flat buffer they are views of (or None)"""
             if ncomp == 0:  # (a rank without maps of this spin still takes part in the exchange, with empty blocks)
                 import torch
 
-                return [torch.empty(0, dtype=torch.float64, device=getattr(self.stages, "device", "cpu")) for _ in self.sets]
-            return self.stages.ring_modes(maps.reshape(ncomp, npix), self.sets, pix_weights=pix_weights, ring_weights=ring_weights)
+                return [torch.empty(0, dtype=torch.float64, device=getattr(self.stages, "device", "cpu")) for _ in self.sets], None
+            flat = None
+            if hasattr(self.stages, "send_buffer"):
+                # ONE send buffer per part, kept between steps: hx_ring_modes writes the blocks of all destinations into it side by side
+                # and the all-to-all sends it as it is (round 5 concatenated them first: 5.3 GB per rank read and written once more at N = 8)
+                if self._send.get(slot) is None or self._send[slot][0] != ncomp:
+                    self._send[slot] = (ncomp, self.stages.send_buffer(ncomp, self.sets))
+                flat = self._send[slot][1]
+                return self.stages.ring_modes(maps.reshape(ncomp, npix), self.sets, pix_weights=pix_weights, ring_weights=ring_weights, out=flat), flat
+            return self.stages.ring_modes(maps.reshape(ncomp, npix), self.sets, pix_weights=pix_weights, ring_weights=ring_weights), None
 
         npix = maps0.shape[-1] if n0 else maps2.shape[-1]
         # ---- part 1: spin 0 ----
-        err, send0 = None, None
+        err, send0, flat0 = None, None, None
         try:
-            send0 = modes_of(maps0, n0, npix)
+            send0, flat0 = modes_of(maps0, n0, npix, 0)
         except Exception as exc:  # noqa: BLE001
             err = exc
         self._agree(err, guard)
-        tok0 = self._all_to_all_begin(send0, self.n0_of)
+        tok0 = self._all_to_all_begin(send0, self.n0_of, flat0)
         # ---- part 2: spin 2 (its ring Fourier stage runs under the first transfer) ----
-        err, send2 = None, None
+        err, send2, flat2 = None, None, None
         try:
-            send2 = modes_of(maps2, 2 * n2, npix)
+            send2, flat2 = modes_of(maps2, 2 * n2, npix, 2)
         except Exception as exc:  # noqa: BLE001
             err = exc
         self._agree(err, guard)
-        tok2 = self._all_to_all_begin(send2, c2_of)
+        tok2 = self._all_to_all_begin(send2, c2_of, flat2)
         size = self.stages.modes_size(self.orders[1])
         alm = self.buffer()
         # ---- Legendre stage of the spin-0 components on this rank's orders (under the second transfer) ----
@@ -552,3 +592,44 @@ class MShardedTwoPoint:
             dist.all_reduce(t, group=self.group)  # alm2cl is a sum over m: the partial spectra add up
             part = t.cpu().numpy()
         return part
+
+
+# ---- agreement between ranks WITHOUT a collective -----------------------------------------------------------------------------------
+def unanimous(ok, tag, timeout=120.0):
+    """How many ranks of the default process group report failure at the point ``tag`` -- through the rendezvous key-value store, not
+    through a collective: a rank that has FAILED inside a phase must not enter collectives that the others are not in (collectives of
+    different type and size would pair up over RCCL: a hang or undefined results).  Every rank calls this with the same tag once;
+    returns the number of failed ranks (0 .. world).  A rank that does not arrive within ``timeout`` seconds counts as failed.
+    Callers act on the verdict the same way everywhere: all ok -> go on; all failed -> the common fallback; mixed -> leave the job
+    (``sys.exit`` non-zero, so that the launcher tears it down)."""
+    import time
+
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    if world == 1:
+        return 0 if ok else 1
+    store = dist.distributed_c10d._get_default_store()
+    store.add(f"hx/{tag}/failed", 0 if ok else 1)
+    store.add(f"hx/{tag}/seen", 1)
+    t0 = time.monotonic()
+    while store.add(f"hx/{tag}/seen", 0) < world:
+        if time.monotonic() - t0 > timeout:
+            return max(1, store.add(f"hx/{tag}/failed", 0))
+        time.sleep(0.01)
+    return int(store.add(f"hx/{tag}/failed", 0))
+
+
+def mixing_matrices_sharded(fields, cls, rank=None, world=None, **kwargs):
+    """``heracles_amd.mixing_matrices`` on the ranks of the default process group: the request list of heracles/twopoint.py:354-397 is
+    dealt to the ranks by cost (``twopoint.split_requests``), every rank builds its own keys -- replicas only, no collective (SURVEY
+    section 8e, last bullet).  Returns this rank's share; the union over the ranks is the single-process result."""
+    import torch.distributed as dist
+
+    from .twopoint import mixing_matrices
+
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    return mixing_matrices(fields, cls, rank=rank, world=world, **kwargs)

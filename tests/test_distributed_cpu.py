@@ -405,3 +405,71 @@ def test_bench_self_launch_starts_n_ranks_and_propagates_failure():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--launch-check"], env=dict(env, HX_LAUNCH_CHECK_FAIL="2"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode == 3
+
+
+# ---- mixing-matrix request list split across ranks (SURVEY 8e last bullet; heracles/twopoint.py:354-397) ----------------------------
+def _mm_job():
+    """config-5-like: 2 scalar fields + 1 spin-2 field on two masks, 3 bins"""
+    import types
+
+    fields = {"POS": types.SimpleNamespace(mask="VIS", spin=0), "CON": types.SimpleNamespace(mask="VIS", spin=0),
+              "SHE": types.SimpleNamespace(mask="WHT", spin=2), "NOM": types.SimpleNamespace(mask=None, spin=0)}
+    l = np.arange(25)
+    cls = {}
+    for a, b in (("VIS", "VIS"), ("VIS", "WHT"), ("WHT", "WHT")):
+        for i in range(3):
+            for j in range(i if a == b else 0, 3):
+                cls[a, b, i, j] = 1.0 / (1.0 + l + i + 2 * j) ** 2
+    return fields, cls
+
+
+def _mm_context(cl, l1max, l2max, l3max, spin):
+    from oracle import hxoracle as ho
+
+    return (ho.mixmat_eb if all(spin) else ho.mixmat)(cl, l1max=l1max, l2max=l2max, l3max=l3max, spin=spin)
+
+
+def _mm_worker(rank, world, port, outdir, bins):
+    import torch.distributed as dist
+
+    from heracles_amd.distributed import mixing_matrices_sharded, unanimous
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fields, cls = _mm_job()
+    kw = dict(l1max=12, l2max=16, l3max=24, context=_mm_context)
+    if bins:
+        kw.update(bins=np.array([2, 4, 8, 13]), weights="2l+1")
+    mine = mixing_matrices_sharded(fields, cls, **kw)  # (rank / world from the process group; no collective inside)
+    np.savez(os.path.join(outdir, f"mm_{rank}.npz"), **{"|".join(map(str, k)): np.asarray(v.array) for k, v in mine.items()})
+    # agreement without a collective: everybody ok -> 0; rank 1 reports a failure -> every rank sees exactly one
+    assert unanimous(True, "mm-ok") == 0
+    assert unanimous(rank != 1, "mm-one-failed") == 1
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bins", [(2, False), (2, True), (3, True)])
+def test_mixing_matrix_requests_split_across_ranks(tmp_path, world, bins):
+    import torch.multiprocessing as mp
+
+    import heracles_amd as hx
+
+    mp.spawn(_mm_worker, args=(world, _free_port(), str(tmp_path), bins), nprocs=world, join=True)
+    fields, cls = _mm_job()
+    kw = dict(l1max=12, l2max=16, l3max=24, context=_mm_context)
+    if bins:
+        kw.update(bins=np.array([2, 4, 8, 13]), weights="2l+1")
+    single = hx.mixing_matrices(fields, cls, **kw)
+    got = {}
+    counts = []
+    for r in range(world):
+        with np.load(os.path.join(tmp_path, f"mm_{r}.npz")) as z:
+            counts.append(len(z.files))
+            for k in z.files:
+                assert k not in got, f"{k} computed twice"
+                got[k] = z[k]
+    assert set(got) == {"|".join(map(str, k)) for k in single}  # the union is the single-process dictionary
+    for k, v in single.items():
+        np.testing.assert_array_equal(got["|".join(map(str, k))], np.asarray(v.array))
+    assert max(counts) - min(counts) <= 2 and min(counts) > 0, counts

@@ -302,7 +302,7 @@ def test_nside_8192_batched_sweeps_on_the_matrix_unit(oracle):
     """nside 8192 / lmax 8000 (examples/heracles.cfg:56-62) through the BATCHED kernels: three spin-2 fields and five spin-0 maps per
     call, so that k_legendre_duo<2,*> / <0,*> and k_synth_duo run beyond the lmax 6144 their dead-block margins were first calibrated
     at (VERDICT r5 Next #3; tools/calibrate_dead_blocks.py shows the margins needed saturate: profiles/r06_dead_block_calibration.txt).
-    map2alm: the first and the last unit of each batch against the oracle on every 1000th m (2e-10 of the largest alm), every unit
+    map2alm: the last unit of each batch against the oracle on every 1000th m (2e-10 of the largest alm), every unit
     against its own single-unit call (the vector-unit kernels: no dead-block rule, oracle-checked above) at 1e-12; alm2map: every unit
     of the batch against its single-unit sweep at 1e-12 of the largest pixel."""
     import torch
@@ -329,7 +329,7 @@ def test_nside_8192_batched_sweeps_on_the_matrix_unit(oracle):
                 plan.map2alm(x[u * nc : (u + 1) * nc], spin, out=one, niter=0)
                 assert float((one - b[u * nc : (u + 1) * nc]).abs().max()) <= 1e-12 * scale, (spin, u)
             del one
-            for u in (0, units - 1):
+            for u in (units - 1,):  # (the oracle's ring stage of an nside-8192 component takes ~10 s on the box's cores: one unit per batch)
                 oracle.set_mstride(stride)
                 try:
                     ref = oracle.map2alm(x[u * nc : (u + 1) * nc].cpu().numpy(), nside, lmax, spin=spin)
