@@ -154,6 +154,11 @@ def cpu_baseline_vectorised(nside, lmax, nmaps0, nmaps2, t_map, qu_map, pix_weig
 
     if not hf.supported():
         return None, None, None
+    # threads = the CPUs this process may really use: a one-GPU lease sees all 256 logical CPUs of the host but is throttled to its
+    # share by the cgroup (cpu.max: 16 here); with 128 threads on a 16-CPU quota the ring stage took 13 s instead of 0.3
+    # (profiles/r06_cpu_baseline_threads.txt)
+    threads, quota = hf.cpu_quota()
+    hf.set_threads(threads)
     a0, tim0 = hf.map2alm(t_map, nside, lmax, spin=0, pix_weights=pix_weights)
     a2, tim2 = hf.map2alm(qu_map, nside, lmax, spin=2, pix_weights=pix_weights)
     t2 = time.perf_counter()
@@ -167,7 +172,6 @@ def cpu_baseline_vectorised(nside, lmax, nmaps0, nmaps2, t_map, qu_map, pix_weig
     total = nmaps0 * s0 + nmaps2 * s2 + tcl * ncs / 6.0
     nlm = (lmax + 1) * (lmax + 2) // 2
     F0 = 8.0 * 2 * nside * nlm
-    threads = hf.num_threads()
     peak, ghz, how = host_fp64_peak(threads)
     gf = 4.0 * F0 / (tim0[1] + tim2[1]) / 1e9
     cpu_model = "unknown"
@@ -178,7 +182,8 @@ def cpu_baseline_vectorised(nside, lmax, nmaps0, nmaps2, t_map, qu_map, pix_weig
         pass
     rec = {
         "value": npairs / total, "unit": "map->Cl pairs/s", "cores": threads, "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(),
-        "kind": "port-vectorised", "engines": cpu_engines(),
+        "cgroup_cpu_quota": quota, "kind": "port-vectorised", "engines": cpu_engines(),
+        "legendre_gflops_per_core": gf / threads,
         "seconds_spin0_transform": s0, "seconds_spin2_transform": s2,
         "legendre_gflops_algorithmic": gf, "legendre_gflops_is": "SURVEY 8d's F0 (spin 0) + 3 F0 (spin 2) / the two Legendre-stage times; ring pruning and "
                                                                 "north/south symmetry remove about half of it, as on the GPU",
@@ -728,6 +733,12 @@ def main():
             t_host = maps0[:1].cpu().numpy()
             qu_host = maps2[0].cpu().numpy()
             pw_host = pw.cpu().numpy()
+            try:  # (the oracle's OpenMP regions run on the CPUs the cgroup grants, not on every logical CPU of the host)
+                from oracle import hxfast as _hf
+
+                _hf.set_threads(_hf.cpu_quota()[0])
+            except Exception:  # noqa: BLE001
+                pass
             oa0, oa2, tim = oracle_sample(nside, lmax, t_host, qu_host, stride, pix_weights=pw_host)
             osample = (oa0, oa2, tim, stride)
             if not args.no_cpu_baseline:

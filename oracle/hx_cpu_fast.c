@@ -637,6 +637,17 @@ int hxf_map2alm(int nside, int lmax, int spin, int ncomp, const double *maps, co
     const int per = spin == 0 ? 1 : 2;
     double *planes = malloc(sizeof(double) * 4 * plane * per);
     if (!planes) { free_geom(&g); return -2; }
+    /* first touch in contiguous per-thread chunks: the ring tasks write one cache line per (m, plane) each, so without this every page
+     * is faulted in by whichever of ~64 tasks gets there first while the others wait on it (16 threads: 2x SLOWER than 8) */
+    {
+        const size_t nbytes = sizeof(double) * 4 * plane * per, chunk = (size_t)2 << 20;
+        const int64_t nchunks = (int64_t)((nbytes + chunk - 1) / chunk);
+#pragma omp parallel for schedule(static)
+        for (int64_t c = 0; c < nchunks; ++c) {
+            const size_t o = (size_t)c * chunk;
+            memset((char *)planes + o, 0, o + chunk <= nbytes ? chunk : nbytes - o);
+        }
+    }
     int Mmax = 1;
     while (Mmax < 8 * nside - 1) Mmax <<= 1;
     twid t = make_twid(Mmax);
@@ -690,4 +701,14 @@ void hxf_alm2cl(const cplx *a, const cplx *b, int lmax, double *cl)
         cl[l] = s / (2.0 * l + 1.0);
     }
     free(part);
+}
+
+/* threads of the OpenMP regions from now on (this library and any other in the process that shares the OpenMP runtime) */
+void hxf_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }

@@ -61,3 +61,34 @@ def alm2cl(a, b):
     lib().hxf_alm2cl.restype = None
     lib().hxf_alm2cl(a.ctypes.data, b.ctypes.data, lmax, cl.ctypes.data)
     return cl
+
+
+def set_threads(n: int):
+    """OpenMP threads from now on (shared with the oracle's library: one OpenMP runtime per process)."""
+    lib().hxf_set_threads(int(n))
+
+
+def cpu_quota():
+    """CPUs this process may actually use: the cgroup CPU quota (cpu.max / cfs_quota_us) if one is set, capped by the affinity mask.
+    A one-GPU lease of an 8-GPU host sees all 256 logical CPUs but is throttled to its share: more OpenMP threads than that only burn
+    the quota in spin-waits."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+            if q != "max":
+                quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = float(f.read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
