@@ -51,18 +51,12 @@ HX_HD int ilog2(unsigned v)
     return p;
 }
 
-/* smallest power of two >= 2n-1 (Bluestein convolution length); n itself if n is 2^k.
- * HX_FFT_FAKE_CAP (timing experiment, WRONG results): Bluestein lengths above it are cut to it -- what a ring of the M = 8192 class
- * costs at M = 4096, the lower end of what shorter (mixed-radix) lengths could give (profiles/r05_fft_cycles.txt) */
-#ifndef HX_FFT_FAKE_CAP
-#define HX_FFT_FAKE_CAP 0
-#endif
+/* smallest power of two >= 2n-1 (Bluestein convolution length); n itself if n is 2^k */
 HX_HD int fft_size_for(int n)
 {
     if ((n & (n - 1)) == 0) return n;
     int m = 1;
     while (m < 2 * n - 1) m <<= 1;
-    if (HX_FFT_FAKE_CAP && m > HX_FFT_FAKE_CAP && n < HX_FFT_FAKE_CAP) m = HX_FFT_FAKE_CAP;
     return m;
 }
 

@@ -27,16 +27,14 @@ namespace hx {
 using namespace hxfft;
 
 // tuning knobs (tools/build_valu_variants.sh)
-#ifndef HX_VALU_R0
-#define HX_VALU_R0 8
-#define HX_VALU_R2 6
-#define HX_VALU_LB0 8
-#define HX_VALU_LB2 4
-#endif
+constexpr int VALU_R0 = 8;
+constexpr int VALU_R2 = 6;
+constexpr int VALU_LB0 = 8;
+constexpr int VALU_LB2 = 4;
 template <int SPIN>
 struct ValuCfg {
-    static constexpr int R = SPIN == 0 ? HX_VALU_R0 : HX_VALU_R2;     // ring pairs per lane
-    static constexpr int LB = SPIN == 0 ? HX_VALU_LB0 : HX_VALU_LB2;  // l values per accumulator block (even)
+    static constexpr int R = SPIN == 0 ? VALU_R0 : VALU_R2;     // ring pairs per lane
+    static constexpr int LB = SPIN == 0 ? VALU_LB0 : VALU_LB2;  // l values per accumulator block (even)
     static constexpr int NA = SPIN == 0 ? 2 : 4;    // accumulators per l: (re, im) / (G_re, G_im, K_re, K_im)
     static constexpr int NF = SPIN == 0 ? 4 : 8;    // operand doubles per (m, ring pair)
     static constexpr int NRB = 2 * R;               // 32-ring-pair blocks per task
@@ -174,17 +172,10 @@ __device__ __forceinline__ void wave_reduce(double (&v)[N], int lane)
 // =====================================================================================
 // the kernel: one wave per task (m, ring group)
 // =====================================================================================
-#ifndef HX_VALU_WAVES
-#define HX_VALU_WAVES 1  // waves per SIMD the register allocation is made for (tuning knob of tools/build_valu_variants.sh)
-#endif
-#ifndef HX_VALU_CHK
-#define HX_VALU_CHK 64  // l between two promotion / liveness checks of a wave (a multiple of LB)
-#endif
-#ifndef HX_VALU_NODEAD
-#define HX_VALU_NODEAD 0  // 1: no recursion-only path for blocks whose chains are all scaled (they accumulate zeros)
-#endif
+constexpr int VALU_WAVES = 1;  // waves per SIMD the register allocation is made for (tuning knob of tools/build_valu_variants.sh)
+constexpr int VALU_CHK = 64;  // l between two promotion / liveness checks of a wave (a multiple of LB)
 template <int SPIN>
-__global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_valu(ValuParams A, const double2 *__restrict__ coefn, const double *__restrict__ alphan)
+__global__ __launch_bounds__(64, VALU_WAVES) void k_legendre_valu(ValuParams A, const double2 *__restrict__ coefn, const double *__restrict__ alphan)
 {
     using C = ValuCfg<SPIN>;
     constexpr int R = C::R, LB = C::LB, NA = C::NA, NF = C::NF, NCH = 2;
@@ -323,7 +314,7 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_valu(ValuParams 
     // as a block of recursions.  A chain grows by less than ~2^7 per step (lambda_{m+1,m} / lambda_mm = sqrt(2m+3) x at worst), i.e.
     // by far less than 2^300 between two checks, and what it would have contributed between passing 2^-300 and its promotion is
     // below 2^-80 of the sum.
-    constexpr int CHK = HX_VALU_CHK / LB > 0 ? HX_VALU_CHK / LB : 1;  // blocks between two checks
+    constexpr int CHK = VALU_CHK / LB > 0 ? VALU_CHK / LB : 1;  // blocks between two checks
     int bk = 0, n_dead = 0, n_acc = 0;  // blocks of recursions only / of recursions + accumulation (executed-work counter)
     // ---- phase 0: every chain of the wave is still scaled -- recursions only, rows of zeros.  (A loop of its own: as a branch
     // inside the main loop it costs the register allocator 126 AGPRs and ~50 copies per block of the main path.) ----
@@ -336,7 +327,7 @@ __global__ __launch_bounds__(64, HX_VALU_WAVES) void k_legendre_valu(ValuParams 
                 promote(r, 1);
                 dead = dead && (sc[r][0] < 0 && sc[r][1] < 0);  // (lanes without a ring carry -100)
             }
-            if (HX_VALU_NODEAD || !__all(dead)) break;
+            if (!__all(dead)) break;
         }
         stage_begin();
         const double2 *cf = cfs[buf] + sb * LB;
@@ -465,7 +456,7 @@ struct SynValuParams {
 // (four spin-0 maps: 294 registers if the compiler may -- copies in AGPRs around the checks and hand-overs; held to 256, i.e. two
 // waves per SIMD like the other shapes, the copies become a few scratch accesses outside the steady loop)
 template <int SPIN, int NB>
-__global__ __launch_bounds__(64, (SPIN == 0 && NB == 4) ? 2 : HX_VALU_WAVES) void k_legendre_synth_valu(SynValuParams A, const double2 *__restrict__ coefn, const double *__restrict__ alphan)
+__global__ __launch_bounds__(64, (SPIN == 0 && NB == 4) ? 2 : VALU_WAVES) void k_legendre_synth_valu(SynValuParams A, const double2 *__restrict__ coefn, const double *__restrict__ alphan)
 {
     using C = SynValuCfg<SPIN, NB>;
     constexpr int R = C::R, LB = C::LB, NAV = C::NAV, NV = C::NV, NA1 = C::NA1, NV1 = C::NV1, NCH = 2;
@@ -617,7 +608,7 @@ __global__ __launch_bounds__(64, (SPIN == 0 && NB == 4) ? 2 : HX_VALU_WAVES) voi
             buf ^= 1;
         }
     };
-    constexpr int CHK = HX_VALU_CHK / LB > 0 ? HX_VALU_CHK / LB : 1;
+    constexpr int CHK = VALU_CHK / LB > 0 ? VALU_CHK / LB : 1;
     int bk = 0, n_dead = 0, n_acc = 0;
     // ---- phase 0: every chain of the wave still scaled: recursions only ----
     const double zero_av[NAV] = {};
@@ -630,7 +621,7 @@ __global__ __launch_bounds__(64, (SPIN == 0 && NB == 4) ? 2 : HX_VALU_WAVES) voi
                 promote(r, 1);
                 dead = dead && (sc[r][0] < 0 && sc[r][1] < 0);
             }
-            if (HX_VALU_NODEAD || !__all(dead)) break;
+            if (!__all(dead)) break;
         }
         stage_begin();
         const double2 *cf = cfs[buf] + sb * LB;

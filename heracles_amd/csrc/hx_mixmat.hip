@@ -80,37 +80,8 @@ __global__ void k_gauss_legendre(int n, double *__restrict__ x, double *__restri
     if (xlo) { xlo[i] = -tl; xlo[n - 1 - i] = tl; }
 }
 
-// ---- Wigner-d table: out[l*sl + k*sk] = d^l_{ab}(x_k), l = 0..lmax ----------------------
-// coef[l] = (c1x, c1c, c2): d^{l+1} = (c1x x + c1c) d^l - c2 d^{l-1}
-__global__ void k_wigner_table(int lmax, int a, int b, int n, const double *__restrict__ x,
-                               const double4 *__restrict__ coef, double *__restrict__ out,
-                               long long sl, long long sk)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const double xx = x[k];
-    const int l0 = max(abs(a), abs(b));
-    double d0;
-    if (a == 0 && b == 0) d0 = 1.0;
-    else if (a == 2 && b == 0) d0 = 0.61237243569579452455 * (1.0 - xx) * (1.0 + xx);
-    else if (a == 2 && b == 2) d0 = 0.25 * (1.0 + xx) * (1.0 + xx);
-    else if (a == 1 && b == 1) d0 = 0.5 * (1.0 + xx);                    // d^1_{11}   (transforms.py:68-73)
-    else if (a * b == -1) d0 = 0.5 * (1.0 - xx);                         // d^1_{-1,1} = d^1_{1,-1}
-    else d0 = 0.25 * (1.0 - xx) * (1.0 - xx);  // (2,-2)
-    for (int l = 0; l < l0 && l <= lmax; ++l) out[l * sl + k * sk] = 0.0;
-    if (l0 > lmax) return;
-    double dp = 0.0, dc = d0;
-    out[l0 * sl + k * sk] = dc;
-    for (int l = l0; l < lmax; ++l) {
-        const double4 c = coef[l];
-        const double dn = fma(fma(c.x, xx, c.y), dc, -c.z * dp);
-        dp = dc;
-        dc = dn;
-        out[(l + 1) * sl + k * sk] = dc;
-    }
-}
-
-// ---- the same tables in double-double arithmetic (the mixing-matrix contexts) -----------------------------------------
+// ---- Wigner-d tables: out[l * sl + k * sk] = d^l_{ab}(x_k), l = 0 .. lmax, in double-double arithmetic -------------------------------
+// coef[l]: d^{l+1} = (c1x x + c1c) d^l - c2 d^{l-1}
 // At l ~ 4000-6000 a table value next to the poles carries ~l^1.5 x 1e-16 of rounding noise from the upward recurrence (every
 // step's rounding error is carried on by a solution that grows like l there), and the noise is alike for the ~100 polar nodes,
 // which carry the whole integrand when the mask's correlation function peaks at theta = 0: 5e-11 on a diagonal element of 10.8 at
@@ -160,6 +131,8 @@ __global__ void k_wigner_table_dd(int lmax, int a, int b, int n, const double *_
     if (a == 0 && b == 0) d0 = one;
     else if (a == 2 && b == 0) d0 = dd_mul(DD{s6h, s6l}, dd_mul(om, op));
     else if (a == 2 && b == 2) { d0 = dd_mul(op, op); d0.h *= 0.25; d0.l *= 0.25; }
+    else if (a == 1 && b == 1) { d0 = op; d0.h *= 0.5; d0.l *= 0.5; }     // d^1_{11}   (heracles/transforms.py:68-73)
+    else if (a * b == -1) { d0 = om; d0.h *= 0.5; d0.l *= 0.5; }          // d^1_{-1,1} = d^1_{1,-1}
     else { d0 = dd_mul(om, om); d0.h *= 0.25; d0.l *= 0.25; }  // (2,-2)
     for (int l = 0; l < l0 && l <= lmax; ++l) out[l * sl + k * sk] = 0.0;
     if (l0 > lmax) return;
@@ -215,24 +188,19 @@ __global__ void k_weight_xi_dd(int l3max, int n, const double *__restrict__ x, c
 //     8 q + 2 (lane >> 4) + h); rows are padded to 18 doubles, which spreads the 16 rows of a read over all 64 banks.
 constexpr int GKT = 16;          // nodes per k tile of the GEMM (GK = 32 stays the padding unit of the tables)
 constexpr int GLT = GKT + 2;     // LDS row stride in doubles
-// Where this kernel stands (round 4, work-group timelines of the HX_GEMM_STAMP build, tools/analyse_gemm_stamps.py; L = 6144: 1225 tiles
+// Where this kernel stands (round 4, work-group timelines of a stamped build, tools/analyse_gemm_stamps.py; L = 6144: 1225 tiles
 // on 512 resident groups): a tile takes 2.41 ms when two groups share a CU (1.9-2.9; 2.20 would be the matrix pipe's rate at the 2.15 GHz
-// the part holds here: 0.92) and 2.24 ms ALONE on a CU (HX_GEMM_HOG build: 10.0 ms per product, 0.55 of the pipe -- its loads run ONE k
+// the part holds here: 0.92) and 2.24 ms ALONE on a CU (a build with ONE group per CU: 10.0 ms per product, 0.55 of the pipe -- its loads run ONE k
 // tile = 4096 cycles ahead, less than a trip to memory under load, its LDS reads wait behind every barrier with no other wave to cover
 // them, and 243 registers leave no room for a second tile in flight); the launch is two full rounds, to 4.3-4.8 ms, and a last round of
 // 20-28 tiles per XCD, most of them alone on their CU, to 6.75 ms: matrix pipe busy 0.78.  k_mixmat_gemm_dma below is the answer to the
-// lone group (1.44 ms); this kernel stays for products whose A side is scaled on the way (hx_pinv) and as the A/B reference
-// (HX_GEMM_DMA=0).  Measured and not kept on either kernel: the tiles of the last round as two 128 x 64 halves (6.8 ms) and as the two
+// lone group (1.44 ms); this kernel stays for products whose A side is scaled on the way (hx_pinv).  Measured and not kept on either kernel: the tiles of the last round as two 128 x 64 halves (6.8 ms) and as the two
 // halves of the NODES added into a zeroed G (two addends commute: repeatable bit for bit; 6.55 ms here, 13.0-13.2 against 12.9-13.0 ms per
 // two products on the other kernel: the rounds are blurred by the spread of the tile times, the memset and the atomics cost what the
 // halves gain).  Equal ranges of k tiles dealt to persistent groups (stream-K) would end every group together, but groups that stand
 // at different nodes of their tiles no longer share the rows of T through their XCD's L2, which is what the tile order is for.
-// SYM: T2 == T, only tiles bi <= bj are listed and both halves are written (the mixing matrices); !SYM: G[i][j] = sum_k T[i][k] s[k] T2[j][k]
-// for every listed tile, colscale may be null (the last product of hx_pinv: V diag(1 / sigma^2) W^T).
-#ifdef HX_GEMM_STAMP  // diagnostic build: when and where every work-group ran
-__device__ unsigned long long g_gemm_stamp[4096 * 4];
-#endif
-template <bool SYM>
+// G[i][j] = sum_k T[i][k] s[k] T2[j][k] for every listed tile, colscale may be null (the last product of hx_pinv: V diag(1 / sigma^2) W^T).
+// (Until round 6 a symmetric instantiation of this kernel was the A/B reference of the mixing-matrix product: tools/patches/r05_switches.patch.)
 __global__ __launch_bounds__(256, 2) void k_mixmat_gemm(const double *__restrict__ T, const double *__restrict__ T2, int kpad,
                                                         const double *__restrict__ s,
                                                         const int2 *__restrict__ tiles, int n1, int n2,
@@ -240,17 +208,9 @@ __global__ __launch_bounds__(256, 2) void k_mixmat_gemm(const double *__restrict
                                                         double *__restrict__ G, long long ldg)
 {
     __shared__ double As[2][GB][GLT], Bs[2][GB][GLT];
-#ifdef HX_GEMM_HOG  // diagnostic build (tools/build_variant.sh): ONE work-group per CU
-    __shared__ double hog[2048];
-    if (kpad < 0) { hog[threadIdx.x] = 1.0; G[0] = hog[threadIdx.x ^ 1]; }
-#endif
     const int2 tl = tiles[blockIdx.x];
     const int bi = tl.x, bj = tl.y;
     if (bi < 0) return;
-#ifdef HX_GEMM_STAMP
-    const unsigned long long t_begin = __builtin_readcyclecounter();
-    const unsigned long long r_begin = wall_clock64();
-#endif
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1;
     double4_t acc[4][4];
@@ -265,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void k_mixmat_gemm(const double *__restrict
     // quarter and the k tile is the scalar offset -- no address arithmetic on the vector unit (as 64-bit per-thread addresses every load
     // cost a vector instruction in the matrix stream: ~12 cycles of pipe time each)
     const __amdgpu_buffer_rsrc_t Ra = __builtin_amdgcn_make_buffer_rsrc((void *)(T + (long long)bi * GB * kpad), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Rb = __builtin_amdgcn_make_buffer_rsrc((void *)((SYM ? T : T2) + (long long)bj * GB * kpad), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Rb = __builtin_amdgcn_make_buffer_rsrc((void *)(T2 + (long long)bj * GB * kpad), 0, 0x7fffffff, 0x00020000);
     const int so = (int)(((long long)srow * kpad + sc2) * sizeof(double)), sq = (int)((long long)32 * kpad * sizeof(double));
     const int so1 = so + sq, so2 = so + 2 * sq, so3 = so + 3 * sq;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -342,19 +302,7 @@ __global__ __launch_bounds__(256, 2) void k_mixmat_gemm(const double *__restrict
                 const int gj = bj * GB + wc * 64 + j * 16 + (lane & 15);
                 const double v = acc[i][j][r];
                 if (gi < n1 && gj < n2) G[(long long)gi * ldg + gj] = colscale ? v * colscale[gj] : v;
-                if (SYM && bi != bj && gj < n1 && gi < n2) G[(long long)gj * ldg + gi] = v * colscale[gi];
             }
-#ifdef HX_GEMM_STAMP
-    if (threadIdx.x == 0 && blockIdx.x < 4096) {
-        unsigned xcc, hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        g_gemm_stamp[blockIdx.x * 4 + 0] = r_begin;
-        g_gemm_stamp[blockIdx.x * 4 + 1] = wall_clock64();
-        g_gemm_stamp[blockIdx.x * 4 + 2] = ((unsigned long long)xcc << 32) | hwid;
-        g_gemm_stamp[blockIdx.x * 4 + 3] = ((unsigned long long)(__builtin_readcyclecounter() - t_begin) << 24) | (bi << 10) | bj;
-    }
-#endif
 }
 
 // ---- the same product with the k tiles brought in by loads that write LDS directly (round 4, second session) ---------------------
@@ -395,17 +343,9 @@ __global__ __launch_bounds__(256, 2) void k_mixmat_gemm_dma(const double *__rest
     // (s_waitcnt vmcnt(0) in front of the reads: nothing left in flight); distinct LDS variables it can
     // (one array per STAGE, both operands in it: with eight arrays the compiler runs out of slots to track them and one stage gets its vmcnt(0) back)
     __shared__ double S0[2][GB][DK], S1[2][GB][DK], S2[2][GB][DK], S3[2][GB][DK];
-#ifdef HX_GEMM_HOG  // diagnostic build (tools/build_variant.sh): ONE work-group per CU
-    __shared__ double hog[6144];
-    if (kpad < 0) { hog[threadIdx.x] = 1.0; G[0] = hog[threadIdx.x ^ 1]; }
-#endif
     const int2 tl = tiles[blockIdx.x];
     const int bi = tl.x, bj = tl.y;
     if (bi < 0) return;
-#ifdef HX_GEMM_STAMP
-    const unsigned long long t_begin = __builtin_readcyclecounter();
-    const unsigned long long r_begin = wall_clock64();
-#endif
     const bool sample_clk = (blockIdx.x & 63) == 33;
     unsigned long long clk_t0 = 0, clk_r0 = 0;
     if (sample_clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -511,17 +451,6 @@ __global__ __launch_bounds__(256, 2) void k_mixmat_gemm_dma(const double *__rest
         atomicAdd(&g_gemm_clk[0], (unsigned long long)__builtin_amdgcn_s_memtime() - clk_t0);
         atomicAdd(&g_gemm_clk[1], (unsigned long long)__builtin_amdgcn_s_memrealtime() - clk_r0);
     }
-#ifdef HX_GEMM_STAMP
-    if (threadIdx.x == 0 && blockIdx.x < 4096) {
-        unsigned xcc, hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        g_gemm_stamp[blockIdx.x * 4 + 0] = r_begin;
-        g_gemm_stamp[blockIdx.x * 4 + 1] = wall_clock64();
-        g_gemm_stamp[blockIdx.x * 4 + 2] = ((unsigned long long)xcc << 32) | hwid;
-        g_gemm_stamp[blockIdx.x * 4 + 3] = ((unsigned long long)(__builtin_readcyclecounter() - t_begin) << 24) | (bi << 10) | bj;
-    }
-#endif
 }
 
 // Ts[r][k] = T[r][k] s[k]
@@ -545,7 +474,7 @@ int launch_gemm_tst(const double *T, int rows1_pad, const double *T2, int rows2_
     DevBuf d_tiles;
     HX_TRY(d_tiles.alloc(sizeof(int2) * tiles.size()));
     HX_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice, rt().stream));
-    hipLaunchKernelGGL(k_mixmat_gemm<false>, dim3((unsigned)tiles.size()), dim3(256), 0, rt().stream, T, T2, kpad, s, d_tiles.as<int2>(), n1, n2,
+    hipLaunchKernelGGL(k_mixmat_gemm, dim3((unsigned)tiles.size()), dim3(256), 0, rt().stream, T, T2, kpad, s, d_tiles.as<int2>(), n1, n2,
                        (const double *)nullptr, G, ldg);
     HX_HIP(hipGetLastError());
     HX_HIP(hipStreamSynchronize(rt().stream));  // the tile list dies with this scope
@@ -671,21 +600,6 @@ __global__ __launch_bounds__(256) void k_binned_finish(int nbins, int n2, int nb
 }
 
 // ---- host helpers --------------------------------------------------------------------
-static void wigner_coefs(int lmax, int a, int b, std::vector<double4> &c)
-{
-    c.assign(lmax + 1, make_double4(0, 0, 0, 0));
-    for (int l = 0; l <= lmax; ++l) {
-        if (l == 0) { c[l] = make_double4(1.0, 0.0, 0.0, 0.0); continue; }
-        long double dl = l, lp = l + 1.0L;
-        long double den = dl * sqrtl((lp * lp - (long double)a * a) * (lp * lp - (long double)b * b));
-        if (den == 0.0L) continue;
-        long double c1x = (2 * dl + 1) * dl * lp / den;
-        long double c1c = -(2 * dl + 1) * (long double)a * b / den;
-        long double c2 = lp * sqrtl((dl * dl - (long double)a * a) * (dl * dl - (long double)b * b)) / den;
-        c[l] = make_double4((double)c1x, (double)c1c, (double)c2, 0.0);
-    }
-}
-
 static void wigner_coefs_dd(int lmax, int a, int b, std::vector<WigCoefDD> &c)
 {
     c.assign(lmax + 1, WigCoefDD{0, 0, 0, 0, 0, 0});
@@ -718,13 +632,6 @@ static int upload_vec(DevBuf &b, const std::vector<T> &v)
     HX_TRY(b.alloc(sizeof(T) * (v.empty() ? 1 : v.size())));
     if (!v.empty()) HX_HIP(hipMemcpy(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
     return HX_OK;
-}
-
-// HX_GEMM_DMA=0: the register-staged kernel of the first half of round 4 (A/B on one device)
-static bool gemm_dma()
-{
-    static const bool on = !(getenv("HX_GEMM_DMA") && getenv("HX_GEMM_DMA")[0] == '0');
-    return on;
 }
 
 struct GLCache {
@@ -847,33 +754,14 @@ static int mix_ctx_product(MixCtx &c, int t, double *d_out)
 {
     HX_TRY(mix_ctx_table(c, t));
     ProfScope ps("mixmat_gemm");
-    if (gemm_dma()) {
-        const size_t nel = (size_t)c.rows_pad * c.kpad;
-        if (!c.Ts.p) HX_TRY(c.Ts.alloc(sizeof(double) * nel));
-        hipLaunchKernelGGL(k_scale_table, dim3(2048), dim3(256), 0, rt().stream, (long long)(nel / 2), c.kpad / 2, c.T[t].as<double2>(), c.s.as<double2>(),
-                           c.Ts.as<double2>());
-        ProfScope pk("mixmat_gemm_kernel");  // (the matrix kernel alone; "mixmat_gemm" includes the scaling pass)
-        hipLaunchKernelGGL(k_mixmat_gemm_dma<true>, dim3((unsigned)c.ntiles), dim3(256), 0, rt().stream, c.Ts.as<double>(), c.T[t].as<double>(), c.kpad,
-                           c.d_tiles.as<int2>(), c.l1max + 1, c.l2max + 1, c.d_cs.as<double>(), d_out, (long long)(c.l2max + 1));
-    } else {
-    ProfScope pk("mixmat_gemm_kernel");
-    hipLaunchKernelGGL(k_mixmat_gemm<true>, dim3((unsigned)c.ntiles), dim3(256), 0, rt().stream, c.T[t].as<double>(), c.T[t].as<double>(), c.kpad,
-                       c.s.as<double>(), c.d_tiles.as<int2>(), c.l1max + 1, c.l2max + 1, c.d_cs.as<double>(), d_out,
-                       (long long)(c.l2max + 1));
-    }
+    const size_t nel = (size_t)c.rows_pad * c.kpad;
+    if (!c.Ts.p) HX_TRY(c.Ts.alloc(sizeof(double) * nel));
+    hipLaunchKernelGGL(k_scale_table, dim3(2048), dim3(256), 0, rt().stream, (long long)(nel / 2), c.kpad / 2, c.T[t].as<double2>(), c.s.as<double2>(),
+                       c.Ts.as<double2>());
+    ProfScope pk("mixmat_gemm_kernel");  // (the matrix kernel alone; "mixmat_gemm" includes the scaling pass)
+    hipLaunchKernelGGL(k_mixmat_gemm_dma<true>, dim3((unsigned)c.ntiles), dim3(256), 0, rt().stream, c.Ts.as<double>(), c.T[t].as<double>(), c.kpad,
+                       c.d_tiles.as<int2>(), c.l1max + 1, c.l2max + 1, c.d_cs.as<double>(), d_out, (long long)(c.l2max + 1));
     HX_HIP(hipGetLastError());
-#ifdef HX_GEMM_STAMP
-    if (const char *fn = getenv("HX_GEMM_STAMP_FILE")) {
-        HX_HIP(hipStreamSynchronize(rt().stream));
-        std::vector<unsigned long long> h(4096 * 4);
-        HX_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_gemm_stamp), sizeof(unsigned long long) * h.size()));
-        if (FILE *f = fopen(fn, "w")) {
-            for (size_t k = 0; k < std::min<size_t>(c.ntiles, 4096); ++k)
-                fprintf(f, "%zu %llu %llu %llu %llu %llu\n", k, h[4 * k], h[4 * k + 1], h[4 * k + 2] >> 32, h[4 * k + 2] & 0xffffffffull, h[4 * k + 3]);
-            fclose(f);
-        }
-    }
-#endif
     return HX_OK;
 }
 
@@ -955,35 +843,6 @@ static int mix_bind_out(OutView &vo, double *out, size_t bytes)
     vo.host = out;
     return HX_OK;
 }
-// HX_MIXMAT_TRACE=1: wall-clock phases of a build on stderr (synchronises between phases: diagnostic only)
-static bool mix_trace()
-{
-    static const bool on = getenv("HX_MIXMAT_TRACE") && getenv("HX_MIXMAT_TRACE")[0] == '1';
-    return on;
-}
-struct MixTrace {
-    double t0;
-    const char *what;
-    static double now()
-    {
-        timespec ts;
-        clock_gettime(CLOCK_MONOTONIC, &ts);
-        return ts.tv_sec + 1e-9 * ts.tv_nsec;
-    }
-    explicit MixTrace(const char *w) : t0(0.0), what(w)
-    {
-        if (mix_trace()) t0 = now();
-    }
-    void lap(const char *phase)
-    {
-        if (!mix_trace()) return;
-        (void)hipStreamSynchronize(rt().stream);
-        const double t = now();
-        fprintf(stderr, "[hx mixmat trace] %s: %s %.2f ms\n", what, phase, (t - t0) * 1e3);
-        t0 = t;
-    }
-};
-
 // The three spin-2 x spin-2 matrices of one mask (context c, node weights set) into vo = [3][n1][n2].
 // b = G^{(2,-2)} first: it IS the third matrix, so a host destination receives it (second stream, ~5 ms at L = 6144) while the
 // product a = G^{(2,2)} is computed; then [0] = (a + b) / 2, [1] = (a - b) / 2.  Complete on return for a host destination.
@@ -1065,15 +924,19 @@ extern "C" int hx_wigner_d_table(int lmax, int a, int b, int n, const double *x,
     OutView vo;
     HX_TRY(vx.bind(x, sizeof(double) * n));
     HX_TRY(vo.bind(out, sizeof(double) * (size_t)n * (lmax + 1)));
-    std::vector<double4> coef;
-    wigner_coefs(lmax, a, b, coef);
-    DevBuf d_coef;
-    HX_TRY(d_coef.alloc(sizeof(double4) * (lmax + 1)));
-    HX_HIP(hipMemcpy(d_coef.p, coef.data(), sizeof(double4) * (lmax + 1), hipMemcpyHostToDevice));
+    // the double-double kernel of the mixing-matrix tables at the caller's nodes (no low part: xlo = 0)
+    std::vector<WigCoefDD> coef;
+    wigner_coefs_dd(lmax, a, b, coef);
+    DevBuf d_coef, d_zero;
+    HX_TRY(upload_vec(d_coef, coef));
+    HX_TRY(d_zero.alloc(sizeof(double) * n));
+    HX_HIP(hipMemsetAsync(d_zero.p, 0, sizeof(double) * n, rt().stream));
     {
         ProfScope ps("wigner_tables");
-        hipLaunchKernelGGL(k_wigner_table, dim3((n + 63) / 64), dim3(64), 0, rt().stream, lmax, a, b, n, vx.as<double>(),
-                           d_coef.as<double4>(), vo.as<double>(), 1LL, (long long)(lmax + 1));
+        const long double s6 = sqrtl(6.0L) / 4.0L;
+        const double s6h = (double)s6, s6l = (double)(s6 - (long double)s6h);
+        hipLaunchKernelGGL(k_wigner_table_dd, dim3((n + 63) / 64), dim3(64), 0, rt().stream, lmax, a, b, n, vx.as<double>(), d_zero.as<double>(),
+                           d_coef.as<WigCoefDD>(), vo.as<double>(), 1LL, (long long)(lmax + 1), s6h, s6l);
     }
     HX_HIP(hipGetLastError());
     HX_TRY(vo.finish());
@@ -1096,20 +959,16 @@ extern "C" int hx_mixmat(const double *cl, int ncl, int l1max, int l2max, int l3
     if (s1 == 0 && s2 == 0) { ab[0][0] = 0; ab[0][1] = 0; }
     else if ((abs(s1) == 2 && s2 == 0) || (s1 == 0 && abs(s2) == 2)) { ab[0][0] = 2; ab[0][1] = 0; }
     else return fail(HX_ERR_UNSUPPORTED, "hx_mixmat: spin (%d,%d) not supported (use hx_mixmat_eb for (2,2))", s1, s2);
-    MixTrace tr("hx_mixmat");
     MixCtx *c = nullptr;
     HX_TRY(mix_cached_ctx(l1max, l2max, l3max, &c));
     DevBuf &d_cl = mix_cache().cl;
     HX_TRY(stage_cl(cl, ncl, l3max, d_cl));
     OutView vo;
     HX_TRY(mix_bind_out(vo, out, sizeof(double) * (size_t)(l1max + 1) * (l2max + 1)));
-    tr.lap("context + staging");
     HX_TRY(mix_ctx_mask(*c, d_cl.as<double>()));
     HX_TRY(mix_ctx_product(*c, ab[0][0] == 0 ? 0 : 1, vo.as<double>()));
-    tr.lap("node weights + product");
     HX_TRY(vo.finish());
     HX_HIP(hipStreamSynchronize(rt().stream));
-    tr.lap("copy out");
     return HX_OK;
 }
 
@@ -1118,18 +977,15 @@ extern "C" int hx_mixmat_eb(const double *cl, int ncl, int l1max, int l2max, int
     HX_TRY(ensure_ready());
     HX_TRY(mixmat_args(cl, ncl, l1max, l2max, l3max, out));
     const size_t sz = (size_t)(l1max + 1) * (l2max + 1);
-    MixTrace tr("hx_mixmat_eb");
     MixCtx *c = nullptr;
     HX_TRY(mix_cached_ctx(l1max, l2max, l3max, &c));
     DevBuf &d_cl = mix_cache().cl;
     HX_TRY(stage_cl(cl, ncl, l3max, d_cl));
     OutView vo;
     HX_TRY(mix_bind_out(vo, out, sizeof(double) * 3 * sz));
-    tr.lap("context + staging");
     HX_TRY(mix_ctx_mask(*c, d_cl.as<double>()));
     HX_TRY(mix_eb_into(*c, vo));
     HX_HIP(hipStreamSynchronize(rt().stream));
-    tr.lap("node weights + products + copy out");
     return HX_OK;
 }
 

@@ -27,20 +27,8 @@
 #include <type_traits>
 
 #include "hx_sht_common.h"
-#ifndef HX_FFT_ABL
-#define HX_FFT_ABL 0  // timing experiments only (tools/fft_ablate.sh)
-#endif
 
-// HX_Y_NT=1: the ring spectra leave with non-temporal stores (round 5 experiment: see profiles/r05_fft_cycles.txt)
-#ifndef HX_Y_NT
-#define HX_Y_NT 0
-#endif
-#if HX_Y_NT
-typedef double hx_v2d __attribute__((ext_vector_type(2)));
-#define HX_YSTORE(p, v) do { const double2 v_ = (v); __builtin_nontemporal_store((hx_v2d){v_.x, v_.y}, reinterpret_cast<hx_v2d *>(p)); } while (0)
-#else
-#define HX_YSTORE(p, v) (*(p) = (v))
-#endif
+// (measured and not kept, round 5: the ring spectra leaving with non-temporal stores -- profiles/r05_fft_cycles.txt)
 
 namespace hx {
 using namespace hxfft;
@@ -152,12 +140,6 @@ __global__ __launch_bounds__(512) void k_init_bhat(PlanDev P, const int *__restr
 // filter values of a thread's butterfly are requested before the forward passes.  Every phase factor exp(-i pi q / 2n) (load
 // phase, Bluestein chirps) is hi[q >> 6] lo[q & 63] from two small tables built per item in LDS: (4n / 64 + 65) sincos per
 // item instead of one per pixel.
-#if HX_FFT_ABL & 32  // cycle accounting of the ring kernel (diagnostic build): phases summed over thread 0 of every work-group
-__device__ unsigned long long g_fft_cyc[8];
-#define HX_FSTAMP(i) do { if (tid == 0) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); fcyc[i] += tn_ - flast; flast = tn_; } } while (0)
-#else
-#define HX_FSTAMP(i) do { } while (0)
-#endif
 __host__ __device__ inline int ring_ph_hi(int M) { return (4 * M) / 64 + 1; }  // entries of the coarse phase table: q >> 6 for q < 4n, n <= M
 constexpr int RING_NTMAX = 512;  // threads per group: M / 16 (one radix-16 butterfly per thread and pass), 64 at least
 constexpr int RING_FB = 8;       // values of j per thread whose pixel loads are in flight together (64 loads)
@@ -182,9 +164,6 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
     const int nitems = ((nrings + 7) >> 3) * nb * 32;  // sets of 8 ring pairs (one per XCD) x components x 4 sub-DFTs
     const TwFactored twf = load_tw_factored(tw_hi, tw_lo, P.tw, P.twN);  // visible after the first barrier below
     int tid = threadIdx.x;
-#if HX_FFT_ABL & 32
-    unsigned long long fcyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flast = __builtin_amdgcn_s_memtime();
-#endif
     // What an item needs to know about its ring pair is ONE 32-byte record (RingDesc; it was rp_list[ring], then P.nsub / startN / startS /
     // bhat_off [rp]: two dependent trips to memory in front of the pixel loads, a third one -- cycle accounting, profiles/r04_fft_cycles.txt:
     // "load + tables" 24k cycles per item whatever the length of its ring), and the record of the NEXT item is requested behind the first
@@ -252,9 +231,6 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
                 for (int q = 0; q < 4; ++q) {
                     const int i = jj + q * n;
                     if (MODE == 0) {
-#if HX_FFT_ABL & 16
-                        z[u][q] = make_double2(1.0 + j, 2.0 + q); z[u + 1][q] = z[u][q]; continue;
-#endif
                         Pair fn, fs;
                         if (WIDE) {
                             fn = *reinterpret_cast<const Pair *>(mpN + i);
@@ -313,19 +289,12 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
         };
-        HX_FSTAMP(6);
         lds_barrier();  // the previous item's last readers of the phase tables and of the buffer
-        HX_FSTAMP(7);
         for (int a = tid; a <= (4 * n) >> 6; a += nt) ph_hi[a] = expipi(-(double)(a << 6) / (2.0 * n));
         if (tid < 64) ph_lo[tid] = expipi(-(double)tid / (2.0 * n));
         lds_barrier();
-        HX_FSTAMP(0);
         auto phase = [&](unsigned q) __attribute__((always_inline)) {  // exp(-i pi q / 2n), q < 4n
-#if HX_FFT_ABL & 1
-            return make_double2(0.5, (double)q);
-#else
             return cmul(ph_hi[q >> 6], ph_lo[q & 63]);
-#endif
         };
         // ---- fill: t_r[j] x load phase.  t_r = (a, c)[r & 1] +- (b, d)[r & 1] with a = z0 + z2, b = z1 + z3, c = z0 - z2,
         // d = -i (z1 - z3) ----
@@ -351,7 +320,6 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
                 for (int j = n + tid; j < M; j += nt) buf[lds_slot(j)] = make_double2(0.0, 0.0);  // Bluestein padding
         }
         __syncthreads();
-        HX_FSTAMP(1);
         if (nextv) {
             auto sc = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
             cur.sN = ((long long)sc(nd0.y) << 32) | (unsigned)sc(nd0.x);
@@ -362,12 +330,8 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
         }
         double2 *out = Y + (long long)c * P.ny + sN + (long long)r * n;
         if (!blu) {
-#if !(HX_FFT_ABL & 2)
             lds_fft_dif(buf, M, twf, P.twN);
-#endif
-            HX_FSTAMP(2);
-            for (int k = tid; k < n; k += nt) HX_YSTORE(out + k, buf[lds_slot(bitrev(k, p))]);
-            HX_FSTAMP(5);
+            for (int k = tid; k < n; k += nt) *(out + k) = buf[lds_slot(bitrev(k, p))];
             continue;
         }
         if (M >= 16) {
@@ -377,10 +341,7 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
             const int nbf = M >> 4;
 #pragma unroll
             for (int j = 0; j < 16; ++j) bq[j] = bh[j * nbf + (tid < nbf ? tid : 0)];
-#if !(HX_FFT_ABL & 2)
             lds_fft_dif(buf, M, twf, P.twN, tid, nt, true);
-#endif
-            HX_FSTAMP(2);
             // last forward pass (h = 1: no twiddles), filter, first inverse pass on the thread's 16 consecutive elements
 #pragma unroll 1
             for (int i = tid; i < nbf; i += nt) {
@@ -390,11 +351,7 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
                 dif_regs<4>(x);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-#if HX_FFT_ABL & 4
-                    x[j] = cmul(x[j], make_double2(0.5, (double)j));
-#else
                     x[j] = cmul(x[j], bq[j]);
-#endif
                 }
                 if (i + nt < nbf) {  // (groups of fewer than M / 16 threads: tiny rings only)
 #pragma unroll
@@ -405,11 +362,7 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
                 for (int j = 0; j < 16; ++j) buf[lds_slot(16 * i) + j] = x[j];
             }
             __syncthreads();
-            HX_FSTAMP(3);
-#if !(HX_FFT_ABL & 8)
             lds_fft_dit_inv(buf, M, twf, P.twN, tid, nt, true);
-#endif
-            HX_FSTAMP(4);
         } else {
             lds_fft_dif(buf, M, twf, P.twN, tid, nt);
             for (int j = tid; j < M; j += nt) buf[lds_slot(j)] = cmul(buf[lds_slot(j)], bh[j]);
@@ -417,13 +370,8 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
             lds_fft_dit_inv(buf, M, twf, P.twN, tid, nt);
         }
         for (int k = tid; k < n; k += nt)  // chirp exp(-i pi k^2 / n)
-            HX_YSTORE(out + k, cscale(cmul(buf[lds_slot(k)], phase(2u * mod_by_inv((unsigned)k * (unsigned)k, 2u * (unsigned)n, 2.0 * inv4n))), inv));
-        HX_FSTAMP(5);
+            *(out + k) = cscale(cmul(buf[lds_slot(k)], phase(2u * mod_by_inv((unsigned)k * (unsigned)k, 2u * (unsigned)n, 2.0 * inv4n))), inv);
     }
-#if HX_FFT_ABL & 32
-    if (tid == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_fft_cyc[i], fcyc[i]);
-#endif
 }
 
 // =====================================================================================
@@ -447,23 +395,10 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const Ri
     const int MP = lds_fft_slots(M), n = M, p = ilog2(M);
     double2 *ph_hi = buf + 2 * MP, *ph_lo = ph_hi + ring_ph_hi(M);
     const int nt = blockDim.x, nh = nt >> 1;  // threads of the group / of one transform
-    // HX_PAIR_ROUNDS 1: two work items per (ring pair, component), on one XCD side by side; 2: one work item runs both rounds from ONE
-    // read, its pixels (128 registers) kept across the transforms -- 46 registers spilled: 18.9 vs 19.4 ms per 8 components with
-    // pixel weights, 15.1 vs 14.3 without, same device: not the default
-#ifndef HX_PAIR_ROUNDS
-#define HX_PAIR_ROUNDS 1
-#endif
-#ifndef HX_PAIR_EARLY2
-// 1: the second half of the next item's batch is requested in front of this item's read-out instead of at the next item's start.
-// Round 5's answer to "why do the belt's items still wait 18k cycles at issue + barrier" (VERDICT r4 #6a): NOT the loads -- with them
-// requested early the figure is the same (17.2k against 16.7k cycles per two items, cycle-accounting builds on one device) and the
-// 136 registers held across the read-out spill 47-104 (ring FFT of ten maps 19.8 against 17.4 ms).  What the waves wait for at that
-// barrier is the acceptance of their own 16 stores per thread: the read-out of an item is a 128 KiB burst per CU, the stores and
-// the loads behind them enter one in-order queue, and with one work-group per CU (139 KiB of LDS for the two transforms) nothing else
-// runs while it drains.  Kept as a build switch; off.
-#define HX_PAIR_EARLY2 0
-#endif
-    const int nitems = HX_PAIR_ROUNDS == 2 ? nrings * nb : ((nrings + 7) >> 3) * nb * 16;
+    // Two work items per (ring pair, component), one per round, side by side on one XCD.  (Measured and not kept: one work item that runs
+    // both rounds from ONE read, its pixels -- 128 registers -- kept across the transforms: 46 registers spilled, 18.9 vs 19.4 ms per 8
+    // components with pixel weights, 15.1 vs 14.3 without, same device.)
+    const int nitems = ((nrings + 7) >> 3) * nb * 16;
     const TwFactored twf = load_tw_factored(tw_hi, tw_lo, P.tw, P.twN);
     const double inv4n = 0.25 / (double)n;
     int tid = threadIdx.x;
@@ -472,13 +407,9 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const Ri
     if (tid < 64) ph_lo[tid] = expipi(-(double)tid / (2.0 * n));
     __syncthreads();
     auto phase = [&](unsigned q) __attribute__((always_inline)) { return cmul(ph_hi[q >> 6], ph_lo[q & 63]); };  // exp(-i pi q / 2n), q < 4n
-#if HX_FFT_ABL & 32
-    unsigned long long fcyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flast = __builtin_amdgcn_s_memtime();
-#endif
     // (the record of the next item's ring pair is requested behind this item's pixel loads: see k_ring_subdft)
-    static_assert(HX_PAIR_ROUNDS == 1 || HX_PAIR_ROUNDS == 2, "one or two rounds per item");
-    auto ring_of = [&](int item) __attribute__((always_inline)) { return HX_PAIR_ROUNDS == 2 ? item / nb : ((item >> 4) / nb) * 8 + (item & 7); };
-    auto comp_of = [&](int item) __attribute__((always_inline)) { return HX_PAIR_ROUNDS == 2 ? item % nb : (item >> 4) % nb; };
+    auto ring_of = [&](int item) __attribute__((always_inline)) { return ((item >> 4) / nb) * 8 + (item & 7); };
+    auto comp_of = [&](int item) __attribute__((always_inline)) { return (item >> 4) % nb; };
     RingDesc cur = RingDesc{0, 0, 0, 1, 0};
     if ((int)blockIdx.x < nitems && ring_of(blockIdx.x) < nrings) cur = desc[ring_of(blockIdx.x)];
     // Pixels: pairs of neighbouring j: 2 (tid + k nt), k < 4 (n / 2 pairs over nt = n / 8 threads, or 128 threads for n <= 1024).  A batch is
@@ -539,39 +470,29 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const Ri
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, RING_FB / 2>;
     bool have_half = false;  // the first half of this item's batch was requested by the item before it
-    bool have_second = false;  // ... and so was the second half (HX_PAIR_EARLY2 builds only)
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         // one round per item: item = 8 (2 s + rpair) + x -- the two items of set s = (ring set s / nb, component s % nb) on XCD x
-        const int rfirst = HX_PAIR_ROUNDS == 2 ? 0 : (item >> 3) & 1;
+        const int rpair = (item >> 3) & 1;  // round 0 = sub-DFTs 0 and 2, round 1 = sub-DFTs 1 and 3
         const int ring = ring_of(item), c = comp_of(item);
         const int itn = item + gridDim.x, ringn = itn < nitems ? ring_of(itn) : nrings;
         const bool nextv = ringn < nrings;
         if (ring >= nrings) {
             if (nextv) cur = desc[ringn];
             have_half = false;
-            have_second = false;
             continue;
         }
         const long long sN = cur.sN, sS = cur.sS;
         asm volatile("; item" : "+v"(tid));
         const bool haveS = sS >= 0;
         if (!have_half) request(H0{}, cur, c);
-        if (!have_second) request(H1{}, cur, c);
-        have_second = false;
+        request(H1{}, cur, c);
         int4 nd0 = make_int4(0, 0, 0, 0);
         if (nextv) nd0 = *(reinterpret_cast<const int4 *>(desc + ringn) + (tid >> 30));
-        // round 0 = sub-DFTs 0 and 2, round 1 = sub-DFTs 1 and 3 (one round per work item by default: HX_PAIR_ROUNDS)
-#pragma unroll 1
-        for (int rpair = rfirst; rpair < rfirst + HX_PAIR_ROUNDS; ++rpair) {
+        {
         // (the previous round's read-out has to be over before the buffers are filled again)
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
-        HX_FSTAMP(0);
-#if HX_FFT_ABL & 32
-        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the pixels have landed
-        HX_FSTAMP(1);
-#endif
-        if (rpair == rfirst) finish(haveS);
+        finish(haveS);
 #pragma unroll
         for (int u = 0; u < RING_FB; ++u) {
             const int j = 2 * (tid + (u >> 1) * nt) + (u & 1);
@@ -585,11 +506,10 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const Ri
             buf[MP + lds_slot(j)] = cmul(csub(e0, e1), phase(q1));
         }
         __syncthreads();
-        HX_FSTAMP(2);
         // the next item's record: taken HERE, in front of this item's stores -- waited for behind them (their number is not known to
         // the compiler) it is s_waitcnt vmcnt(0), and the next item's loads are issued when the last store has been acknowledged
         have_half = false;
-        if (nextv && rpair == rfirst + HX_PAIR_ROUNDS - 1) {
+        if (nextv) {
             cur.sN = ((long long)__builtin_amdgcn_readfirstlane(nd0.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(nd0.x);
             cur.sS = ((long long)__builtin_amdgcn_readfirstlane(nd0.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(nd0.z);
             request(H0{}, cur, comp_of(itn));  // (z is free behind the last fill of the item)
@@ -598,20 +518,10 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const Ri
         const int half = tid >= nh ? 1 : 0, gt = tid - half * nh;
         double2 *bh = buf + half * MP;
         lds_fft_dif(bh, M, twf, P.twN, gt, nh);
-        HX_FSTAMP(3);
-        if (HX_PAIR_EARLY2 && have_half && rpair == rfirst + HX_PAIR_ROUNDS - 1) {  // (the registers of the passes are free again)
-            request(H1{}, cur, comp_of(itn));
-            have_second = true;
-        }
         double2 *out = Y + (long long)c * P.ny + sN + (long long)(rpair + 2 * half) * n;
-        for (int k = gt; k < n; k += nh) HX_YSTORE(out + k, bh[lds_slot(bitrev(k, p))]);
-        HX_FSTAMP(4);
-        }  // rounds
+        for (int k = gt; k < n; k += nh) *(out + k) = bh[lds_slot(bitrev(k, p))];
+        }
     }
-#if HX_FFT_ABL & 32
-    if (tid == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_fft_cyc[i], fcyc[i]);
-#endif
 }
 
 // =====================================================================================
@@ -1189,7 +1099,7 @@ static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, cons
             const int threads = 2 * std::max(64, c.M / 16);
             const size_t lds = (size_t)(2 * lds_fft_slots(c.M) + ring_ph_hi(c.M) + 64) * sizeof(double2);
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(512 / threads, (160 * 1024) / (lds + 3 * 1024 + 256)));
-            const long long items = HX_PAIR_ROUNDS == 2 ? (long long)c.count * nb : ((long long)c.count + 7) / 8 * nb * 16;
+            const long long items = ((long long)c.count + 7) / 8 * nb * 16;
             const unsigned groups = (unsigned)std::min<long long>(items, (long long)rt().cus * per_cu);
             if (MODE == 0 && d_pw && pl->pw_mode == 2) {
                 hipLaunchKernelGGL((k_ring_pairfft<MODE, MODE == 0>), dim3(groups), dim3(threads), lds, rt().stream,
@@ -1198,17 +1108,6 @@ static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, cons
                 hipLaunchKernelGGL((k_ring_pairfft<MODE, false>), dim3(groups), dim3(threads), lds, rt().stream,
                                    pl->dev(), pl->fft_desc.as<RingDesc>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
             }
-#if HX_FFT_ABL & 32
-            {
-                unsigned long long hc[8], z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                (void)hipStreamSynchronize(rt().stream);
-                (void)hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_fft_cyc), sizeof(hc));
-                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fft_cyc), z8, sizeof(z8));
-                const double units = (double)c.count * nb;
-                fprintf(stderr, "[hx] pair fft class M %5d rings %5d: shader cycles per (ring pair, component) = two items: issue+barrier %.0f  wait for pixels %.0f  fill %.0f  transforms %.0f  read-out %.0f\n",
-                        c.M, c.count, hc[0] / units, hc[1] / units, hc[2] / units, hc[3] / units, hc[4] / units);
-            }
-#endif
             continue;
         }
         if (c.M > pl->fft_cap || c.big) {  // Bluestein convolution of 2 x cap points in two halves / plain FFT of > 4096 points
@@ -1231,18 +1130,6 @@ static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, cons
             hipLaunchKernelGGL((k_ring_subdft<MODE, false>), dim3(groups), dim3(threads), lds, rt().stream,
                                pl->dev(), pl->fft_desc.as<RingDesc>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
         }
-#if HX_FFT_ABL & 32
-        {
-            unsigned long long hc[8], z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            (void)hipStreamSynchronize(rt().stream);
-            (void)hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_fft_cyc), sizeof(hc));
-            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fft_cyc), z8, sizeof(z8));
-            const double items = (double)c.count * nb;
-            fprintf(stderr, "[hx] fft class M %5d rings %5d: item start + load issue %.0f  barrier %.0f  tables + barrier:\n", c.M, c.count, hc[6] / ((double)c.count * nb), hc[7] / ((double)c.count * nb));
-            fprintf(stderr, "[hx] fft class M %5d rings %5d: shader cycles per (ring pair, component): load+tables %.0f  fill %.0f  fwd %.0f  middle %.0f  inv %.0f  out %.0f\n", c.M, c.count,
-                    hc[0] / items, hc[1] / items, hc[2] / items, hc[3] / items, hc[4] / items, hc[5] / items);
-        }
-#endif
     }
     HX_HIP(hipGetLastError());
     return HX_OK;
@@ -1295,13 +1182,6 @@ int classify_pixel_weights(hx_plan *pl, const double *d_pw)
 // ---- one synthesis pass over a batch (device pointers): one sweep of the vector-unit kernel per map / field (the round-1 matrix
 // kernel it replaces took 100 / 217 ms for one spin-0 map / spin-2 field at nside 4096 against 19 / 57, and 201 / 653 ms for ten
 // against 187 / 570).  If d_ref != NULL the output is the residual ref - synth (Jacobi iteration). ----
-// HX_SYNTH_KERNEL=valu: every batch on the vector-unit kernel (A/B reference of the matrix-unit synthesis of round 5)
-static bool synth_duo_enabled()
-{
-    static const bool on = !(getenv("HX_SYNTH_KERNEL") && !strcmp(getenv("HX_SYNTH_KERNEL"), "valu"));
-    return on;
-}
-
 // small batches: one sweep of the vector-unit kernel per four maps / two fields (they share the recursion), then the rest
 static int synthesis_batch_valu(hx_plan *pl, int spin, int nb, const double2 *d_alms, double *d_maps, const double *d_ref)
 {
@@ -1344,7 +1224,7 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
     // modes (Fv) and ring spectra (conj Z) live in the analysis' operand buffer F, which is idle during a synthesis: a Jacobi iteration
     // of ten fields needs no HBM beyond what its analysis passes hold (F 64 GB >= 32 + 32).
     const int nunits_all = nb / cpu;
-    if (synth_duo_enabled() && nunits_all >= (spin ? 3 : 5)) {
+    if (nunits_all >= (spin ? 3 : 5)) {
         const int umax = synth_duo_max_units(spin);
         hx_plan::TaskSet *ts = nullptr;
         HX_TRY(synth_duo_tasks(pl, spin, &ts));
@@ -1386,9 +1266,7 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
                 // ring pairs whose rings hold every order in a bin of its own go through the transposing pass, the polar ones through the gather
                 const int *ml = (spin ? pl->syn_mlim2 : pl->syn_mlim0).as<int>();
                 int rp_t = pl->nrp;
-                static const bool use_t = !(getenv("HX_SYNTH_SPECTRUM") && !strcmp(getenv("HX_SYNTH_SPECTRUM"), "gather"));
-                if (use_t)
-                    while (rp_t > 0 && 4 * pl->h_nsub[rp_t - 1] >= 2 * pl->lmax + 2) --rp_t;
+                while (rp_t > 0 && 4 * pl->h_nsub[rp_t - 1] >= 2 * pl->lmax + 2) --rp_t;
                 if (rp_t > 0)
                     hipLaunchKernelGGL(k_synth_spectrum_v, dim3((rp_t + 3) / 4), dim3(256), 0, st, P, fv, nc, pl->lmax, zc, ml, rp_t);
                 if (rp_t < pl->nrp) {

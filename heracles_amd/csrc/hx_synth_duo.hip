@@ -33,33 +33,16 @@ constexpr int SLB = 16;  // l per block: 8 rows of (even, odd)
 // into the OTHER stage's buffer (global_load_lds_dwordx4: no register, no vector or LDS-store instruction, and -- unlike loads into
 // registers, which the compiler made the matrix block wait for -- nothing waits for them before the barrier that closes the stage:
 // vmcnt(0), barrier, once per SB blocks)
-#ifndef HX_SYN_SB
-#define HX_SYN_SB 4
-#endif
-constexpr int SB = HX_SYN_SB;
+constexpr int SYN_SB = 4;
+constexpr int SB = SYN_SB;
 
-#ifndef HX_SYN_SCALE_BITS2
-#define HX_SYN_SCALE_BITS2 100
-#endif
-#ifndef HX_SYN_SCALE_BITS0
-#define HX_SYN_SCALE_BITS0 300
-#endif
-#ifndef HX_SYN_GAP
-#define HX_SYN_GAP -1  // s_nop (n - 1) behind every (16 x 16 x 4, 4 x 4 x 4) group of a position: lets the other group's vector work in (see HX_DUO_GAP)
-#endif
-#ifndef HX_SYN_PRIO
-#define HX_SYN_PRIO 1
-#endif
-#ifndef HX_SYN_QLDS
-// 1: the additive recursion coefficient q' of a step comes from a wave-private LDS table (a broadcast read instead of the row-broadcast
-// move: 2 vector instructions per step instead of 3).  Measured and not kept (same device, two runs each): ten fields 330.6 against
-// 319.8 ms, eight 281 / 269, five 175 / 172, ten spin-0 maps 90.1 / 88.1 -- the recursion is bound by the latency of its dependent
-// chain, not by the number of vector instructions, and an LDS trip per step lengthens the chain
-#define HX_SYN_QLDS 0
-#endif
-#ifndef HX_SYN_ABL
-#define HX_SYN_ABL 0  // timing experiments only: 1 no matrix instructions, 2 no recursion
-#endif
+constexpr int SYN_SCALE_BITS2 = 100;
+constexpr int SYN_SCALE_BITS0 = 300;
+constexpr int SYN_GAP = -1;  // s_nop (n - 1) behind every (16 x 16 x 4, 4 x 4 x 4) group of a position: lets the other group's vector work in (see HX_DUO_GAP)
+constexpr int SYN_PRIO = 1;
+// (Measured and not kept, round 5: the additive recursion coefficient q' of a step from a wave-private LDS table -- a broadcast read
+// instead of the row-broadcast move, 2 vector instructions per step instead of 3: ten fields 330.6 against 319.8 ms; the recursion is
+// bound by the latency of its dependent chain, and an LDS trip per step lengthens the chain.)
 
 template <int K>
 __device__ __forceinline__ double syn_row_bcast(double v)
@@ -173,12 +156,11 @@ __global__ __launch_bounds__(256, 2) void k_synth_duo(SynDuoParams A, const doub
     constexpr int NP = RD / 2;               // its 16-byte pieces: thread t stages piece t (and t + 256)
     // gaps in the matrix stream let the other group's vector work in (HX_DUO_GAP of the analysis kernel): ten spin-0 maps 91.1 -> 87.6 ms,
     // five fields 178.4 -> 170.9 with s_nop 4; the 40-column shape is the same with and without (319-326 ms for 0, 3 ... 8)
-    constexpr int GAPN = HX_SYN_GAP >= 0 ? HX_SYN_GAP : ((NG == 2 && NBX == 2) ? 0 : 5);
-    constexpr int SCB = SPIN == 2 ? HX_SYN_SCALE_BITS2 : HX_SYN_SCALE_BITS0;  // step of the scaled chains (as HX_DUO_SCALE_BITS in hx_analysis.hip)
+    constexpr int GAPN = SYN_GAP >= 0 ? SYN_GAP : ((NG == 2 && NBX == 2) ? 0 : 5);
+    constexpr int SCB = SPIN == 2 ? SYN_SCALE_BITS2 : SYN_SCALE_BITS0;  // step of the scaled chains (as HX_DUO_SCALE_BITS in hx_analysis.hip)
     static_assert(NG >= 1 && NG <= 2 && NBX >= 0 && NBX <= 2 && NP <= 512, "shape");
     __shared__ double tile[NW][64 * 16];  // 8 KiB per wave
     __shared__ double tab[2][SB][RD];     // <= 40 KiB: two stages of SB blocks
-    __shared__ double qtab[NW][SLB];      // HX_SYN_QLDS: q' of the block's 16 steps, per wave
     const PlanDev &P = A.P;
     const LegTask task = A.tasks[blockIdx.x];
     const int m = task.m, lmax = P.lmax;
@@ -238,7 +220,6 @@ __global__ __launch_bounds__(256, 2) void k_synth_duo(SynDuoParams A, const doub
     // the 16 steps of a block; cl = this lane's coefficient pair (p', q') of step (lane & 15): wave-uniform per step, taken by row broadcast
     auto recursion = [&](auto RMM, const double2 cl) __attribute__((always_inline)) {
         constexpr int RM = decltype(RMM)::value;
-        if (HX_SYN_QLDS && lane < SLB) qtab[w][lane] = cl.y;  // (read back by this wave only: LDS operations of a wave execute in order)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             double cur[8];
@@ -247,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void k_synth_duo(SynDuoParams A, const doub
                 const int kk = 8 * h + k;
                 double tq = 0.0;
                 switch (kk) {
-#define HX_BC(K) case K: tq = syn_row_bcast_fmac<K>(HX_SYN_QLDS ? qtab[w][K] : syn_row_bcast<K>(cl.y), cl.x, xx); break;
+#define HX_BC(K) case K: tq = syn_row_bcast_fmac<K>(syn_row_bcast<K>(cl.y), cl.x, xx); break;
                     HX_BC(0) HX_BC(1) HX_BC(2) HX_BC(3) HX_BC(4) HX_BC(5) HX_BC(6) HX_BC(7)
                     HX_BC(8) HX_BC(9) HX_BC(10) HX_BC(11) HX_BC(12) HX_BC(13) HX_BC(14) HX_BC(15)
 #undef HX_BC
@@ -316,16 +297,15 @@ __global__ __launch_bounds__(256, 2) void k_synth_duo(SynDuoParams A, const doub
     double2 cnext = cfm[0];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
-    if (HX_SYN_PRIO) __builtin_amdgcn_s_setprio(3);
+    if (SYN_PRIO) __builtin_amdgcn_s_setprio(3);
     for (int b = 0; b < nblk; ++b) {
         // block b + SB belongs to the next stage: its pieces are requested now and stored behind this block's matrix work
         const int stg = (b / SB) & 1, bj = b % SB;
         const double2 cl = cnext;
         if (b + SB < nblk) dma_block(b + SB, &tab[stg ^ 1][bj][0]);
         cnext = cfm[(b + 1) * SLB];
-        int rm = (HX_SYN_ABL & 2) ? 3 : set_mode(b);
-        if (HX_SYN_ABL & 2) {
-        } else if (rm == 3) recursion(I3{}, cl);
+        int rm = set_mode(b);
+        if (rm == 3) recursion(I3{}, cl);
         else if (rm == 2) {
             recursion(I2{}, cl);
             if (SCB != 300) {  // a mixed block in which no chain came to life stored zeros only
@@ -334,8 +314,8 @@ __global__ __launch_bounds__(256, 2) void k_synth_duo(SynDuoParams A, const doub
                 if (!__any(lv)) rm = 1;
             }
         } else recursion(I1{}, cl);
-        if (rm >= 2 && !(HX_SYN_ABL & 1)) {
-            if (HX_SYN_PRIO) __builtin_amdgcn_s_setprio(0);
+        if (rm >= 2) {
+            if (SYN_PRIO) __builtin_amdgcn_s_setprio(0);
             const double *tb = &tab[stg][bj][0];
             auto a_fetch = [&](int mt, int ks) __attribute__((always_inline)) {
                 return *reinterpret_cast<const double2 *>(tw + syn_tile_idx(16 * mt + ai, 4 * ks + ak));
@@ -379,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void k_synth_duo(SynDuoParams A, const doub
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (HX_SYN_PRIO) __builtin_amdgcn_s_setprio(3);
+            if (SYN_PRIO) __builtin_amdgcn_s_setprio(3);
         }
         if (bj == SB - 1) {  // the next stage's table is complete (every wave has waited for its own pieces); this stage's buffer may be refilled
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
