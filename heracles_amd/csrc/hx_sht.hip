@@ -155,7 +155,8 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
                                                             const double *__restrict__ maps,
                                                             const double *__restrict__ pixw,
                                                             const double2 *__restrict__ zin,
-                                                            double2 *__restrict__ Y)
+                                                            double2 *__restrict__ Y, double *__restrict__ pixout = nullptr,
+                                                            const double *__restrict__ ref = nullptr)
 {
     extern __shared__ double2 buf[];  // the padded transform buffer of the class's M, then the phase tables (4 M / 64 + 1 and 64 entries)
     __shared__ double2 tw_hi[TW_HI_MAX], tw_lo[64];
@@ -329,9 +330,35 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
             cur.rp = sc(nd1.w);
         }
         double2 *out = Y + (long long)c * P.ny + sN + (long long)r * n;
+        // MODE 1 with `pixout` (synthesis, round 6): the value of bin k of sub-DFT r IS the pixel pair 4 k + r of the two rings --
+        // Y_r[k] = conj(z[4 k + r]), f_N = Re, f_S = -Im -- so it goes straight to the maps (or, with `ref`, the residual ref - synthesised of
+        // a Jacobi iteration) instead of through Y and a scatter pass of its own (16 B written + 16 B read + 16 B written per pixel pair
+        // before; the four items of a ring pair run side by side on one XCD, whose L2 merges their interleaved 8-byte stores)
+        double *pxN = nullptr, *pxS = nullptr;
+        const double *rfN = nullptr, *rfS = nullptr;
+        if (MODE == 1 && pixout) {
+            pxN = pixout + (long long)c * P.npix + sN + r;
+            pxS = pixout + (long long)c * P.npix + (haveS ? sS : sN) + r;
+            if (ref) { rfN = ref + (long long)c * P.npix + sN + r; rfS = ref + (long long)c * P.npix + (haveS ? sS : sN) + r; }
+        }
+        // MODE 0: bins 4 k + r that no order m <= lmax falls on (neither as m nor as 4n - m) are not written: a ring of 4n > 2 lmax + 1
+        // pixels leaves lmax < bin < 4n - lmax out -- a quarter of the belt's stores at nside 4096 / lmax 6144, half at nside 8192 / lmax 8000
+        // (the read-out is a burst of stores into the in-order memory pipeline: what the item waits for at its end)
+        const int kdrop0 = MODE == 0 ? (P.lmax - r) / 4 + 1 : n, kdrop1 = (4 * n - P.lmax - r + 3) / 4;
+        auto emit = [&](int k, double2 v) __attribute__((always_inline)) {
+            if (MODE == 0 && k >= kdrop0 && k < kdrop1) return;
+            if (MODE == 1 && pxN) {
+                double fn = v.x, fs = -v.y;
+                if (rfN) { fn = rfN[4 * k] - fn; fs = rfS[4 * k] - fs; }
+                pxN[4 * k] = fn;
+                if (haveS) pxS[4 * k] = fs;
+            } else {
+                out[k] = v;
+            }
+        };
         if (!blu) {
             lds_fft_dif(buf, M, twf, P.twN);
-            for (int k = tid; k < n; k += nt) *(out + k) = buf[lds_slot(bitrev(k, p))];
+            for (int k = tid; k < n; k += nt) emit(k, buf[lds_slot(bitrev(k, p))]);
             continue;
         }
         if (M >= 16) {
@@ -370,7 +397,7 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
             lds_fft_dit_inv(buf, M, twf, P.twN, tid, nt);
         }
         for (int k = tid; k < n; k += nt)  // chirp exp(-i pi k^2 / n)
-            *(out + k) = cscale(cmul(buf[lds_slot(k)], phase(2u * mod_by_inv((unsigned)k * (unsigned)k, 2u * (unsigned)n, 2.0 * inv4n))), inv);
+            emit(k, cscale(cmul(buf[lds_slot(k)], phase(2u * mod_by_inv((unsigned)k * (unsigned)k, 2u * (unsigned)n, 2.0 * inv4n))), inv));
     }
 }
 
@@ -388,7 +415,8 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
 template <int MODE, bool WSYM = false>
 __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const RingDesc *__restrict__ desc, int nrings, int nb, int M,
                                                              const double *__restrict__ maps, const double *__restrict__ pixw,
-                                                             const double2 *__restrict__ zin, double2 *__restrict__ Y)
+                                                             const double2 *__restrict__ zin, double2 *__restrict__ Y,
+                                                             double *__restrict__ pixout = nullptr, const double *__restrict__ ref = nullptr)
 {
     extern __shared__ double2 buf[];  // two padded buffers of M points, then the phase tables (4 M / 64 + 1 and 64 entries)
     __shared__ double2 tw_hi[TW_HI_MAX], tw_lo[64];
@@ -518,8 +546,30 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const Ri
         const int half = tid >= nh ? 1 : 0, gt = tid - half * nh;
         double2 *bh = buf + half * MP;
         lds_fft_dif(bh, M, twf, P.twN, gt, nh);
-        double2 *out = Y + (long long)c * P.ny + sN + (long long)(rpair + 2 * half) * n;
-        for (int k = gt; k < n; k += nh) *(out + k) = bh[lds_slot(bitrev(k, p))];
+        const int r = rpair + 2 * half;
+        if (MODE == 1 && pixout) {  // straight to the pixels 4 k + r of the two rings, or to the residual (see k_ring_subdft)
+            double *pxN = pixout + (long long)c * P.npix + sN + r, *pxS = pixout + (long long)c * P.npix + (haveS ? sS : sN) + r;
+            if (ref) {
+                const double *rfN = ref + (long long)c * P.npix + sN + r, *rfS = ref + (long long)c * P.npix + (haveS ? sS : sN) + r;
+                for (int k = gt; k < n; k += nh) {
+                    const double2 v = bh[lds_slot(bitrev(k, p))];
+                    pxN[4 * k] = rfN[4 * k] - v.x;
+                    if (haveS) pxS[4 * k] = rfS[4 * k] + v.y;
+                }
+            } else {
+                for (int k = gt; k < n; k += nh) {
+                    const double2 v = bh[lds_slot(bitrev(k, p))];
+                    pxN[4 * k] = v.x;
+                    if (haveS) pxS[4 * k] = -v.y;
+                }
+            }
+        } else {
+            double2 *out = Y + (long long)c * P.ny + sN + (long long)r * n;
+            // (MODE 0: bins between lmax and 4n - lmax are not written, see k_ring_subdft)
+            const int kdrop0 = MODE == 0 ? (P.lmax - r) / 4 + 1 : n, kdrop1 = (4 * n - P.lmax - r + 3) / 4;
+            for (int k = gt; k < n; k += nh)
+                if (k < kdrop0 || k >= kdrop1) *(out + k) = bh[lds_slot(bitrev(k, p))];
+        }
         }
     }
 }
@@ -562,7 +612,8 @@ __global__ __launch_bounds__(512) void k_init_bhat_split(PlanDev P, const int *_
 template <int MODE>
 __global__ __launch_bounds__(512) void k_ring_subdft_split(PlanDev P, const int *__restrict__ rp_list, int C,
                                                             const double *__restrict__ maps, const double *__restrict__ pixw,
-                                                            const double2 *__restrict__ zin, double2 *__restrict__ Y)
+                                                            const double2 *__restrict__ zin, double2 *__restrict__ Y,
+                                                            double *__restrict__ pixout = nullptr, const double *__restrict__ ref = nullptr)
 {
     extern __shared__ double2 buf[];
     const int rp = rp_list[blockIdx.y];
@@ -592,59 +643,76 @@ __global__ __launch_bounds__(512) void k_ring_subdft_split(PlanDev P, const int 
         }
         return zp[j + (long long)q * n];
     };
-    for (int r = 0; r < 4; ++r) {
-        // a0[j] = t_r[j] exp(-i pi (j r + 2 j^2) / 2n), kept in registers for both halves
-        double2 a0[SPLIT_JMAX], ye[SPLIT_JMAX];
-#pragma unroll
-        for (int u = 0; u < SPLIT_JMAX; ++u) {
-            const int j = threadIdx.x + u * blockDim.x;
-            a0[u] = make_double2(0.0, 0.0);
-            if (j < n) {
-                const double2 t = dif4_combine(z_at(j, 0), z_at(j, 1), z_at(j, 2), z_at(j, 3), r);
-                const unsigned qn = load_phase_num(j, r, n, !plain);
-                a0[u] = qn ? cmul(t, expipi(-(double)qn / (2.0 * n))) : t;
+    // Nothing is carried in registers across the transforms (round 6): until then the 16 input values a0[j] and the 16 results of the even
+    // half sat in registers under the radix-16 passes -- 256 registers, 1 050 more in scratch (3.2 KB per lane), 35 ms for the cap rings of
+    // two maps at nside 8192, two thirds of their ring stage.  Now the input of the odd half is formed again from the pixels (L2) and the
+    // even half's result waits where it belongs -- in Y, or in the pixels -- for the odd half to be ADDED to it by the same thread.
+    // (MODE 1 with pixout: bin k of sub-DFT r goes straight to the pixel pair 4 k + r of the two rings, see k_ring_subdft.)
+    auto emit = [&](int r, int k, double2 v, bool add) __attribute__((always_inline)) {
+        if (MODE == 1 && pixout) {
+            const long long iN = (long long)c * P.npix + sN + 4 * k + r, iS = (long long)c * P.npix + sS + 4 * k + r;
+            if (add) {  // (what is there is ref - first part, or the first part: subtract / add the second)
+                pixout[iN] += ref ? -v.x : v.x;
+                if (sS >= 0) pixout[iS] += ref ? v.y : -v.y;
+            } else {
+                double fn = v.x, fs = -v.y;
+                if (ref) { fn = ref[iN] - fn; if (sS >= 0) fs = ref[iS] - fs; }
+                pixout[iN] = fn;
+                if (sS >= 0) pixout[iS] = fs;
             }
+        } else {
+            double2 *o = Y + (long long)c * P.ny + sN + (long long)r * n + k;
+            *o = add ? cadd(*o, v) : v;
         }
+    };
+    // t_r[j] exp(-i pi (j r + 2 j^2 [Bluestein]) / 2n)
+    auto input = [&](int r, int j) __attribute__((always_inline)) {
+        const double2 t = dif4_combine(z_at(j, 0), z_at(j, 1), z_at(j, 2), z_at(j, 3), r);
+        const unsigned qn = load_phase_num(j, r, n, !plain);
+        return qn ? cmul(t, expipi(-(double)qn / (2.0 * n))) : t;
+    };
+    for (int r = 0; r < 4; ++r) {
         if (plain) {
             __syncthreads();
-#pragma unroll
+#pragma unroll 4
             for (int u = 0; u < SPLIT_JMAX; ++u) {
                 const int j = threadIdx.x + u * blockDim.x;
-                if (j < n) buf[lds_slot(j)] = a0[u];
+                if (j < n) buf[lds_slot(j)] = input(r, j);
             }
             __syncthreads();
             lds_fft_dif(buf, n, twf, P.twN);
-            double2 *outp = Y + (long long)c * P.ny + sN + (long long)r * n;
             const int pbits = ilog2(n);
-            for (int k = threadIdx.x; k < n; k += blockDim.x) outp[k] = buf[lds_slot(bitrev(k, pbits))];
+            for (int k = threadIdx.x; k < n; k += blockDim.x) emit(r, k, buf[lds_slot(bitrev(k, pbits))], false);
             continue;
         }
         for (int half = 0; half < 2; ++half) {
             __syncthreads();  // the previous pass has been read out of buf
-#pragma unroll
+#pragma unroll 4
             for (int u = 0; u < SPLIT_JMAX; ++u) {
                 const int j = threadIdx.x + u * blockDim.x;
-                if (j < C) buf[lds_slot(j)] = (j < n) ? (half == 0 ? a0[u] : cmul(a0[u], twf[j])) : make_double2(0.0, 0.0);
+                if (j < C) {
+                    double2 v = make_double2(0.0, 0.0);
+                    if (j < n) {
+                        v = input(r, j);
+                        if (half) v = cmul(v, twf[j]);
+                    }
+                    buf[lds_slot(j)] = v;
+                }
             }
             __syncthreads();
             lds_fft_dif(buf, C, twf, P.twN);
             for (int j = threadIdx.x; j < C; j += blockDim.x) buf[lds_slot(j)] = cmul(buf[lds_slot(j)], bh[half * C + j]);
             __syncthreads();
             lds_fft_dit_inv(buf, C, twf, P.twN);
-#pragma unroll
+#pragma unroll 4
             for (int u = 0; u < SPLIT_JMAX; ++u) {
                 const int k = threadIdx.x + u * blockDim.x;
                 if (k < n) {
-                    if (half == 0) ye[u] = buf[lds_slot(k)];
-                    else ye[u] = cadd(ye[u], cmulc(buf[lds_slot(k)], twf[k]));  // + W_M^-k y_odd[k]
+                    double2 y = buf[lds_slot(k)];
+                    if (half) y = cmulc(y, twf[k]);  // W_M^-k y_odd[k]
+                    emit(r, k, cscale(cmul(y, expipi(-(double)chirp_num(k, n) / (double)n)), inv), half != 0);
                 }
             }
-        }
-        double2 *out = Y + (long long)c * P.ny + sN + (long long)r * n;
-#pragma unroll
-        for (int u = 0; u < SPLIT_JMAX; ++u) {
-            const int k = threadIdx.x + u * blockDim.x;
-            if (k < n) out[k] = cscale(cmul(ye[u], expipi(-(double)chirp_num(k, n) / (double)n)), inv);
         }
     }
 }
@@ -752,45 +820,9 @@ __global__ __launch_bounds__(256) void k_synth_spectrum_t(PlanDev P, const doubl
     }
 }
 
-// Y_r[k] = DFT(conj Z)[4k+r] = conj(z[4k+r]) -> f_N = Re, f_S = -Im.  One thread per k gathers its four
-// sub-spectra values (coalesced along k) and writes four consecutive pixels of each ring (32 B per lane).
-__global__ __launch_bounds__(256) void k_synth_scatter(PlanDev P, const double2 *__restrict__ Y,
-                                                       double *__restrict__ maps, int accumulate_neg,
-                                                       const double *__restrict__ ref)
-{
-    const int rp = blockIdx.x, c = blockIdx.y;
-    const int n = P.nsub[rp];
-    const long long sN = P.startN[rp], sS = P.startS[rp];
-    const double2 *y = Y + (long long)c * P.ny + sN;
-    double *mp = maps + (long long)c * P.npix;
-    const double *rf = ref ? ref + (long long)c * P.npix : nullptr;
-    for (int k = threadIdx.x; k < n; k += blockDim.x) {
-        double fn[4], fs[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double2 v = y[(long long)r * n + k];
-            fn[r] = v.x;
-            fs[r] = -v.y;
-        }
-        const long long jN = sN + 4 * k, jS = sS + 4 * k;  // even offsets: 16-byte aligned pairs
-        if (accumulate_neg) {  // residual: ref - synthesised
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                fn[r] = rf[jN + r] - fn[r];
-                if (sS >= 0) fs[r] = rf[jS + r] - fs[r];
-            }
-        }
-        double2 *dn = reinterpret_cast<double2 *>(mp + jN);
-        dn[0] = make_double2(fn[0], fn[1]);
-        dn[1] = make_double2(fn[2], fn[3]);
-        if (sS >= 0) {
-            double2 *ds = reinterpret_cast<double2 *>(mp + jS);
-            ds[0] = make_double2(fs[0], fs[1]);
-            ds[1] = make_double2(fs[2], fs[3]);
-        }
-    }
-}
-
+// (Until round 6 the inverse sub-DFTs wrote their spectra to Y and a pass of its own, k_synth_scatter, turned Y_r[k] = conj(z[4k + r]) into
+// pixels: 20 ms per ten fields.  The read-out of the sub-DFT kernels writes the pixels itself now -- MODE 1 with `pixout`: ten fields
+// 62.7 -> 52.7 ms of ring stage, ten maps 31.0 -> 25.9, same device -- and a synthesis holds no Y buffer.)
 }  // namespace hx
 
 using namespace hx;
@@ -1082,7 +1114,7 @@ int ensure_rec2(hx_plan *pl)
 // (a 4096-point ring must not reserve the 128 KiB of an 8192-point Bluestein ring).
 template <int MODE>
 static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, const double *d_pw, const double2 *zin, double2 *Y, int rp_lo = 0,
-                                 int rp_hi = 0x7fffffff)
+                                 int rp_hi = 0x7fffffff, double *pixout = nullptr, const double *ref = nullptr)
 {
     for (const auto &cls : pl->fft_classes) {
         // the ring pairs of the class that lie in [rp_lo, rp_hi): its list is in descending order, so they are one run of it
@@ -1103,17 +1135,17 @@ static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, cons
             const unsigned groups = (unsigned)std::min<long long>(items, (long long)rt().cus * per_cu);
             if (MODE == 0 && d_pw && pl->pw_mode == 2) {
                 hipLaunchKernelGGL((k_ring_pairfft<MODE, MODE == 0>), dim3(groups), dim3(threads), lds, rt().stream,
-                                   pl->dev(), pl->fft_desc.as<RingDesc>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+                                   pl->dev(), pl->fft_desc.as<RingDesc>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y, pixout, ref);
             } else {
                 hipLaunchKernelGGL((k_ring_pairfft<MODE, false>), dim3(groups), dim3(threads), lds, rt().stream,
-                                   pl->dev(), pl->fft_desc.as<RingDesc>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+                                   pl->dev(), pl->fft_desc.as<RingDesc>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y, pixout, ref);
             }
             continue;
         }
         if (c.M > pl->fft_cap || c.big) {  // Bluestein convolution of 2 x cap points in two halves / plain FFT of > 4096 points
             const int C = std::min(c.M, pl->fft_cap), threads = std::min(512, std::max(64, C / SPLIT_JMAX));
             hipLaunchKernelGGL(k_ring_subdft_split<MODE>, dim3(1, c.count, nb), dim3(threads), (size_t)lds_fft_slots(C) * sizeof(double2), rt().stream,
-                               pl->dev(), pl->fft_rp_list.as<int>() + c.first, C, d_maps, d_pw, zin, Y);
+                               pl->dev(), pl->fft_rp_list.as<int>() + c.first, C, d_maps, d_pw, zin, Y, pixout, ref);
             continue;
         }
         // M / 16 threads per group (one radix-16 butterfly per thread and pass); persistent groups, as many as the CUs hold at
@@ -1125,10 +1157,10 @@ static int launch_subdft_classes(hx_plan *pl, int nb, const double *d_maps, cons
         const unsigned groups = (unsigned)std::min<long long>(items, (long long)rt().cus * per_cu);
         if (MODE == 0 && d_pw && pl->pw_mode == 2) {
             hipLaunchKernelGGL((k_ring_subdft<MODE, MODE == 0>), dim3(groups), dim3(threads), lds, rt().stream,
-                               pl->dev(), pl->fft_desc.as<RingDesc>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+                               pl->dev(), pl->fft_desc.as<RingDesc>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y, pixout, ref);
         } else {
             hipLaunchKernelGGL((k_ring_subdft<MODE, false>), dim3(groups), dim3(threads), lds, rt().stream,
-                               pl->dev(), pl->fft_desc.as<RingDesc>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y);
+                               pl->dev(), pl->fft_desc.as<RingDesc>() + c.first, c.count, nb, c.M, d_maps, d_pw, zin, Y, pixout, ref);
         }
     }
     HX_HIP(hipGetLastError());
@@ -1189,7 +1221,6 @@ static int synthesis_batch_valu(hx_plan *pl, int spin, int nb, const double2 *d_
     const int cpu = spin ? 2 : 1;
     PlanDev P = pl->dev();
     const int umax = synth_valu_max_units(spin);
-    HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * cpu * umax));
     // ring modes and ring spectra live in the analysis' operand buffer F, as in the batched path (F is idle during a synthesis, and a plan
     // that has run a batched synthesis holds most of the HBM in it already: separate buffers failed to allocate at nside 8192)
     const size_t fv_pad = (sizeof(double) * (size_t)(pl->lmax + 1) * pl->nrp_pad * 4 * cpu * umax + 255) & ~(size_t)255;
@@ -1205,9 +1236,9 @@ static int synthesis_batch_valu(hx_plan *pl, int spin, int nb, const double2 *d_
         HX_TRY(launch_synth_valu(pl, spin, units, *ts, d_alms + (size_t)c0 * pl->nlm, fsyn));
         ProfScope ps("ring_fft");
         hipLaunchKernelGGL(k_synth_spectrum_v, dim3((pl->nrp + 3) / 4), dim3(256), 0, st, P, fsyn, nc, pl->lmax, zc, (const int *)nullptr, pl->nrp);
-        HX_TRY(launch_subdft_classes<1>(pl, nc, nullptr, nullptr, zc, pl->Y.as<double2>()));
-        hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, nc), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps + (size_t)c0 * pl->npix, d_ref ? 1 : 0,
-                           d_ref ? d_ref + (size_t)c0 * pl->npix : nullptr);
+        // inverse sub-DFTs whose read-out writes the pixels (or the residual ref - synthesised of a Jacobi iteration) itself
+        HX_TRY(launch_subdft_classes<1>(pl, nc, nullptr, nullptr, zc, nullptr, 0, 0x7fffffff, d_maps + (size_t)c0 * pl->npix,
+                                        d_ref ? d_ref + (size_t)c0 * pl->npix : nullptr));
         c0 += nc;
     }
     HX_HIP(hipGetLastError());
@@ -1228,10 +1259,10 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
         const int umax = synth_duo_max_units(spin);
         hx_plan::TaskSet *ts = nullptr;
         HX_TRY(synth_duo_tasks(pl, spin, &ts));
-        // what a sweep of `units` holds: ring modes + ring spectra (in F), Y, the B-operand table
+        // what a sweep of `units` holds: ring modes + ring spectra (in F), the B-operand table
         auto sweep_bytes = [&](int units) {
             const double nc = (double)units * cpu;
-            return sizeof(double) * (double)(pl->lmax + 1) * pl->nrp_pad * synth_duo_rowlen(spin, units) + 2.0 * sizeof(double2) * (double)pl->ny * nc +
+            return sizeof(double) * (double)(pl->lmax + 1) * pl->nrp_pad * synth_duo_rowlen(spin, units) + sizeof(double2) * (double)pl->ny * nc +
                    (double)synth_duo_table_bytes(pl, spin, units);
         };
         size_t fr = 0, tot = 0;
@@ -1256,7 +1287,6 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
             const size_t zc_bytes = sizeof(double2) * (size_t)pl->ny * nc;
             const size_t fv_pad = (fv_bytes + 255) & ~(size_t)255;
             HX_TRY(pl->F.alloc(fv_pad + zc_bytes));
-            HX_TRY(pl->Y.alloc(sizeof(double2) * (size_t)pl->ny * nc));
             HX_TRY(pl->syn_tab.alloc(synth_duo_table_bytes(pl, spin, units)));
             double *fv = pl->F.as<double>();
             double2 *zc = reinterpret_cast<double2 *>(reinterpret_cast<char *>(pl->F.p) + fv_pad);
@@ -1275,9 +1305,8 @@ static int synthesis_batch(hx_plan *pl, int spin, int nb, const double2 *d_alms,
                     hipLaunchKernelGGL(k_synth_spectrum_t, grid, dim3(256), sizeof(double2) * 2 * nc * SPT_M, st, P, fv, nc, pl->lmax, zc, ml, rp_t);
                 }
             }
-            HX_TRY(launch_subdft_classes<1>(pl, nc, nullptr, nullptr, zc, pl->Y.as<double2>()));
-            hipLaunchKernelGGL(k_synth_scatter, dim3(pl->nrp, nc), dim3(256), 0, st, P, pl->Y.as<double2>(), d_maps + (size_t)u0 * cpu * pl->npix, d_ref ? 1 : 0,
-                               d_ref ? d_ref + (size_t)u0 * cpu * pl->npix : nullptr);
+            HX_TRY(launch_subdft_classes<1>(pl, nc, nullptr, nullptr, zc, nullptr, 0, 0x7fffffff, d_maps + (size_t)u0 * cpu * pl->npix,
+                                            d_ref ? d_ref + (size_t)u0 * cpu * pl->npix : nullptr));
             u0 += units;
         }
         HX_HIP(hipGetLastError());
