@@ -6,7 +6,8 @@ include/hxsht.h).  There is no CPU fallback.
 """
 
 from . import _lib
-from ._lib import HxError, device_count, init, pinned_empty, synchronize
+from ._lib import HxError, device_count, init, pinned_empty, release_caches, synchronize
+from .binning import BinPlan, binned
 from .core import DeviceArray, Result, TocDict, toc_match, update_metadata
 from .discrete import HipDiscreteMapper, PointSHT, alm_resample, get_point_sht
 from .jackknife import RegionAlms, jackknife_cls, region_alms
@@ -27,6 +28,8 @@ from .twopoint import (
     mixing_matrices,
     mixmat,
     mixmat_eb,
+    mixmat_release,
+    split_requests,
 )
 from .unmixing import naturalspice
 
@@ -35,5 +38,5 @@ __all__ = [
     "alm2cl", "alm2cl_pairs", "alm2lmax", "angular_power_spectra", "debias_cls",
     "mixing_matrices", "mixmat", "mixmat_eb", "cl2corr", "corr2cl", "gauss_legendre",
     "wigner_d_table", "naturalspice", "Result", "TocDict", "toc_match", "update_metadata", "DeviceArray",
-    "pinned_empty", "MixmatContext", "jackknife_cls", "region_alms", "RegionAlms", "transform", "read_vmap", "apply_mixing_matrix", "invert_mixing_matrix",
+    "pinned_empty", "release_caches", "mixmat_release", "split_requests", "binned", "BinPlan", "MixmatContext", "jackknife_cls", "region_alms", "RegionAlms", "transform", "read_vmap", "apply_mixing_matrix", "invert_mixing_matrix",
 ]

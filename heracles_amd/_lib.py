@@ -31,7 +31,7 @@ SYMBOLS = (
     "hx_mixmat_eb", "hx_mixmat_batch", "hx_mixctx_create", "hx_mixctx_apply", "hx_mixctx_destroy", "hx_mixctx_set_bins", "hx_mixctx_apply_binned", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_reorder", "hx_matvec", "hx_pinv", "hx_alm_resample", "hx_region_maps", "hx_alm_subtract", "hx_fits_unpack_f64", "hx_fits_pack_f64",
     "hx_pointsht_create", "hx_pointsht_destroy", "hx_pointsht_info", "hx_pointsht_adjoint",
     "hx_pixel_weights_size", "hx_pixel_weights_expand",
-    "hx_ring_modes_size", "hx_ring_modes", "hx_legendre_from_modes", "hx_host_alloc", "hx_host_free", "hx_mixmat_gemm_clock", "hx_mixmat_release",
+    "hx_ring_modes_size", "hx_ring_modes", "hx_legendre_from_modes", "hx_host_alloc", "hx_host_free", "hx_mixmat_gemm_clock", "hx_mixmat_release", "hx_release_caches",
 )
 
 
@@ -204,6 +204,12 @@ def measure_peaks():
 
 def synchronize():
     check(load().hx_synchronize())
+
+
+def release_caches():
+    """Hand back the HBM the library keeps between calls outside plans and contexts: the cache of ``mixmat`` / ``mixmat_eb`` (tables of
+    the last sizes + host-staging buffer, ~3 GB at L = 6144) and the buffers of ``alm2cl_pairs`` (<= 512 MB): hx_release_caches."""
+    check(load().hx_release_caches())
 
 
 def copy(dst, src):

@@ -1002,6 +1002,17 @@ extern "C" double hx_mixmat_gemm_clock(void)
     return h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
 }
 
+// Everything the library keeps in HBM between calls outside a plan or a context: the one-shot mixing-matrix cache above (tables of the
+// last (l1max, l2max, l3max), the staging buffer of a host destination -- which hx_mixctx_apply shares --, the staged mask spectrum:
+// ~3 GB at L = 6144) and the buffers of hx_alm2cl_pairs (tables, partial sums, staging: up to 512 MB).  The next call allocates again.
+extern "C" int hx_release_caches(void)
+{
+    if (rt().ready) (void)hipStreamSynchronize(rt().stream);
+    mix_cache_drop();
+    alm2cl_drop_cache();
+    return HX_OK;
+}
+
 // Frees what hx_mixmat / hx_mixmat_eb / hx_mixmat_batch keep between calls (the tables of the last (l1max, l2max, l3max) and the
 // staging buffer of a host destination: ~3 GB at L = 6144).  The next build allocates them again.
 extern "C" int hx_mixmat_release(void)

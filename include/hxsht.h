@@ -183,6 +183,11 @@ int hx_mixmat_eb(const double *cl, int ncl, int l1max, int l2max, int l3max, dou
  * build of that size allocates nothing; this frees them.  (The reference rebuilds everything per convolvecl call,
  * heracles/twopoint.py:378-388.) */
 int hx_mixmat_release(void);
+/* Everything the library keeps in HBM between calls OUTSIDE a plan or a context -- none of it is counted by hx_plan_scratch_bytes: the
+ * cache of hx_mixmat / hx_mixmat_eb / hx_mixmat_batch (above; its staging buffer of a host destination also serves hx_mixctx_apply and
+ * outlives hx_mixctx_destroy) and the tables, partial sums and staging buffer hx_alm2cl_pairs keeps (<= 512 MB).  A long-lived host
+ * process of the reference's loops (heracles/twopoint.py:173-299, :316-401) calls this between stages to hand the HBM back. */
+int hx_release_caches(void);
 /* ---- FITS wire format of maps and alms (heracles/io.py:128-218, "next" row) ------------------------------------
  * Payload conversion between a FITS binary table of 'D' columns (row-major, big-endian) and the component-major
  * native arrays of the path, one pass on the GPU; `table` / `array` host or device.

@@ -209,3 +209,26 @@ def test_gpu_angular_power_spectra_bins(gold):
         assert [key_str(k) for k in cls] == list(gold[f"aps/{wn}/keys"])
         for k, v in cls.items():
             check(gold, f"aps/{wn}/{key_str(k)}", v, rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_gpu_release_caches_between_stages():
+    """hx_release_caches hands back what the one-shot mixing-matrix entry points and hx_alm2cl_pairs keep in HBM between calls (ADVICE r5:
+    none of it is counted by a plan); the next call builds the same result again"""
+    import torch
+
+    l = np.arange(301)
+    cl = 1.0 / (1.0 + l) ** 2
+    a = hx.mixmat_eb(cl)
+    rng = np.random.default_rng(1)
+    alm = rng.standard_normal((2, 51 * 52 // 2, 2)) @ [1, 1j]
+    c1 = hx.alm2cl(alm[0], alm[1])
+    torch.cuda.synchronize()
+    before = torch.cuda.mem_get_info()[0]
+    hx.release_caches()
+    after = torch.cuda.mem_get_info()[0]
+    assert after >= before  # (tables of L = 300 and the staging buffer are small, but they are gone)
+    np.testing.assert_array_equal(hx.mixmat_eb(cl), a)
+    np.testing.assert_array_equal(hx.alm2cl(alm[0], alm[1]), c1)
+    hx.mixmat_release()
+    hx.release_caches()  # (twice in a row: nothing left to free)

@@ -272,3 +272,15 @@ def test_read_vmap_transform_equals_mapper_transform_with_a_weight_file(tmp_path
     alm = hx.read_vmap(path, transform=True, lmax=lmax, pixwin=pw, datapath=tmp_path, niter=niter)
     mapper = hx.HipHealpixMapper(nside, lmax, deconvolve=True, niter=niter, datapath=tmp_path, pixwin=pw)
     np.testing.assert_array_equal(alm, np.asarray(mapper.transform(m, spin=0)))
+    # ... and the iteration rule itself is pinned on an independent path: the oracle's weighted analysis with its explicit
+    # Jacobi loop -- residual = map - synthesis(alm) against the UNWEIGHTED map, every analysis pass with the pixel weights -- then the
+    # window.  (What healpy does for use_pixel_weights=True with iter > 0 stays parity-unpinned: healpy is absent from this image.)
+    from oracle import hxoracle as ho
+
+    full = ho.expand_full_weights(nside, hxw.read_compressed_weights(tmp_path / hxw.weights_filename(nside), nside))
+    ref = ho.map2alm(m[None], nside, lmax, spin=0, pix_weights=full, niter=niter)[0]
+    fl = 1.0 / pw[0]
+    for mm in range(lmax + 1):
+        b = mm * (2 * lmax + 1 - mm) // 2
+        ref[b + mm : b + lmax + 1] *= fl[mm:]
+    assert np.abs(alm - ref).max() <= 1e-11 * np.abs(ref).max()
