@@ -38,7 +38,7 @@ if ROOT not in sys.path:
 
 FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 matrix (= vector) peak
 HBM_PEAK_GBS = 8000.0
-PROFILE_ROUND = "r05"    # profiles/<round>_traffic.json holds the committed PMC passes of THIS round's kernels
+PROFILE_ROUND = "r06"    # profiles/<round>_traffic.json holds the committed PMC passes of THIS round's kernels
 
 
 def parse():

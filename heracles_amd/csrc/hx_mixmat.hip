@@ -87,7 +87,7 @@ __global__ void k_gauss_legendre(int n, double *__restrict__ x, double *__restri
 // which carry the whole integrand when the mask's correlation function peaks at theta = 0: 5e-11 on a diagonal element of 10.8 at
 // L = 4096 (with exact nodes and weights; tests/test_gpu_mixmat.py::test_mixmat_blocks_at_high_l_vs_3j).  In double-double the noise is
 // ~1e-32 l^1.5; the coefficients come as (hi, lo) pairs from the host's long doubles, the node as x + xlo.  One thread per node, a
-// dependent chain of ~16 operations per step: ~0.4 ms per table at L = 6144, once per context; the weights xi(x_k) ~0.4 ms per mask.
+// dependent chain of ~16 operations per step: ~0.4 ms per table at L = 6144, once per context (measured: 2.1 ms per table under rocprofv3, profiles/r06_kernel_stats.csv).
 struct DD {
     double h, l;
 };
@@ -148,31 +148,48 @@ __global__ void k_wigner_table_dd(int lmax, int a, int b, int n, const double *_
     }
 }
 
-// s_k = w_k xi(x_k + xlo_k), xi = sum_l (2 l + 1) / (4 pi) W_l P_l, P_l and the sum in double-double (the integer coefficients of
-// l P_l = (2 l - 1) x P_{l-1} - (l - 1) P_{l-2} are exact)
-__global__ void k_weight_xi_dd(int l3max, int n, const double *__restrict__ x, const double *__restrict__ xlo, const double *__restrict__ w,
-                               const double *__restrict__ cl, double *__restrict__ s)
+// ---- node weights s_k = w_k xi(x_k + xlo_k), xi = sum_l (2 l + 1) / (4 pi) W_l P_l --------------------------------------------------
+// (Round 5: k_weight_xi_dd, one thread per node running the P_l recurrence and the sum in double-double: 1.6 ms per mask at L = 6144.)
+// As a matrix-vector product over the (0,0) table (round 6): T0[l][k] = P_l(x_k + xlo_k) is in HBM anyway (built in
+// double-double, rounded once), so  s_k = w_k sum_l (2 l + 1) / (4 pi) W_l T0[l][k]  needs no recurrence -- that kernel ran ONE
+// dependent chain of 6144 double-double steps per node, 1.6 ms per mask at L = 6144 whatever the GPU could do beside it (9217 nodes:
+// 145 waves), three quarters of a binned mixing-matrix key.  Here a block takes 64 nodes x a slice of the multipoles (4 sub-slices
+// of it across its waves), every partial sum is compensated (two_sum) and the slices are added in fixed order: the rounding of the table
+// entries is random from l to l (1e-16 of each term), unlike the node errors the double-double tables exist for.
+constexpr int XI_SLICES = 8;
+__global__ __launch_bounds__(256) void k_xi_partial(int l3max, int kpad, const double *__restrict__ cl, const double *__restrict__ T0,
+                                                    double2 *__restrict__ part)
+{
+#pragma clang fp contract(off)
+    __shared__ double2 red[4][64];
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const int nl = l3max + 1, per = (nl + XI_SLICES * 4 - 1) / (XI_SLICES * 4);
+    const int l0 = (blockIdx.y * 4 + sub) * per, l1 = min(l0 + per, nl);
+    double sum = 0.0, comp = 0.0;
+    if (k < kpad) {
+        for (int l = l0; l < l1; ++l) {
+            const double v = ((2.0 * l + 1.0) / (4.0 * M_PI) * cl[l]) * T0[(long long)l * kpad + k];
+            const double t = sum + v, bb = t - sum;
+            comp += (sum - (t - bb)) + (v - bb);
+            sum = t;
+        }
+    }
+    red[sub][threadIdx.x & 63] = make_double2(sum, comp);
+    __syncthreads();
+    if (sub == 0 && k < kpad) {
+        DD a = dd_quick(red[0][threadIdx.x].x, red[0][threadIdx.x].y);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) a = dd_add(a, dd_quick(red[q][threadIdx.x].x, red[q][threadIdx.x].y));
+        part[(long long)blockIdx.y * kpad + k] = make_double2(a.h, a.l);
+    }
+}
+__global__ void k_xi_finish(int n, int kpad, const double *__restrict__ w, const double2 *__restrict__ part, double *__restrict__ s)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const DD xx = dd_quick(x[k], xlo[k]);
-    DD p0 = DD{1.0, 0.0}, p1 = xx;
-    DD xi = DD{cl[0] * (1.0 / (4.0 * M_PI)), 0.0};
-    if (l3max >= 1) xi = dd_add(xi, dd_mul(DD{3.0 / (4.0 * M_PI) * cl[1], 0.0}, p1));
-    for (int l = 2; l <= l3max; ++l) {
-        const DD num = dd_add(dd_mul(DD{2.0 * l - 1.0, 0.0}, dd_mul(xx, p1)), dd_neg(dd_mul(DD{l - 1.0, 0.0}, p0)));
-        // num / l: quotient of the high part, exact remainder, quotient of the rest
-        DD p2;
-        {
-#pragma clang fp contract(off)
-            const double q1 = num.h / l, r = fma(-q1, (double)l, num.h), q2 = (r + num.l) / l;
-            p2 = dd_quick(q1, q2);
-        }
-        p0 = p1;
-        p1 = p2;
-        xi = dd_add(xi, dd_mul(DD{(2.0 * l + 1.0) / (4.0 * M_PI) * cl[l], 0.0}, p2));
-    }
-    s[k] = w[k] * (xi.h + xi.l);
+    DD a = DD{part[k].x, part[k].y};
+    for (int q = 1; q < XI_SLICES; ++q) a = dd_add(a, DD{part[(long long)q * kpad + k].x, part[(long long)q * kpad + k].y});
+    s[k] = w[k] * (a.h + a.l);
 }
 
 // ---- symmetric GEMM: G[i][j] = colscale[j] * sum_k T[i][k] s[k] T[j][k] -----------------
@@ -661,6 +678,8 @@ struct MixCtx {
     size_t ntiles = 0;
     DevBuf T[4];            // (0,0), (2,0), (2,2), (2,-2)
     DevBuf Ts;              // T diag(s) of the product in hand (k_mixmat_gemm_dma)
+    DevBuf xi_part;         // slices of the node weights of the mask in hand (k_xi_partial)
+    int rows0_pad = 0;      // rows of T[0]: it also serves the node weights, whose sum runs to l3max
     bool have[4] = {false, false, false, false};
     // binned rows (hx_mixctx_set_bins): bin lists of the output multipole, binned tables Tb_t[nbpad][kpad] per product
     int nbins = 0, nbpad = 0, l2pad = 0, ksplit = 1, kchunk = 0;
@@ -720,17 +739,21 @@ static int mix_ctx_table(MixCtx &c, int t)
 {
     if (c.have[t]) return HX_OK;
     hipStream_t st = rt().stream;
+    // (the (0,0) table = P_l(x_k) also feeds the node weights xi(x_k) of every mask, a sum over l <= l3max: its rows run that far)
+    const int ltop = t == 0 ? std::max(c.L, c.l3max) : c.L;
+    const int rows = t == 0 ? (ltop + 1 + GB - 1) / GB * GB : c.rows_pad;
+    if (t == 0) c.rows0_pad = rows;
     std::vector<WigCoefDD> coef;
-    wigner_coefs_dd(c.L, kAB[t][0], kAB[t][1], coef);
+    wigner_coefs_dd(ltop, kAB[t][0], kAB[t][1], coef);
     DevBuf d_coef;
     HX_TRY(upload_vec(d_coef, coef));
-    HX_TRY(c.T[t].alloc(sizeof(double) * (size_t)c.rows_pad * c.kpad));
-    HX_HIP(hipMemsetAsync(c.T[t].p, 0, sizeof(double) * (size_t)c.rows_pad * c.kpad, st));
+    HX_TRY(c.T[t].alloc(sizeof(double) * (size_t)rows * c.kpad));
+    HX_HIP(hipMemsetAsync(c.T[t].p, 0, sizeof(double) * (size_t)rows * c.kpad, st));
     {
         ProfScope ps("wigner_tables");
         const long double s6 = sqrtl(6.0L) / 4.0L;
         const double s6h = (double)s6, s6l = (double)(s6 - (long double)s6h);
-        hipLaunchKernelGGL(k_wigner_table_dd, dim3((c.n + 63) / 64), dim3(64), 0, st, c.L, kAB[t][0], kAB[t][1], c.n, c.gl.x.as<double>(),
+        hipLaunchKernelGGL(k_wigner_table_dd, dim3((c.n + 63) / 64), dim3(64), 0, st, ltop, kAB[t][0], kAB[t][1], c.n, c.gl.x.as<double>(),
                            c.gl.xlo.as<double>(), d_coef.as<WigCoefDD>(), c.T[t].as<double>(), (long long)c.kpad, 1LL, s6h, s6l);
     }
     HX_HIP(hipStreamSynchronize(st));  // d_coef dies with this scope
@@ -738,13 +761,16 @@ static int mix_ctx_table(MixCtx &c, int t)
     return HX_OK;
 }
 
-// node weights of one mask spectrum (device, l3max + 1 values)
+// node weights s_k = w_k xi(x_k) of one mask spectrum (device, l3max + 1 values): a matrix-vector product over the (0,0) table
 static int mix_ctx_mask(MixCtx &c, const double *d_cl)
 {
     hipStream_t st = rt().stream;
+    HX_TRY(mix_ctx_table(c, 0));
+    HX_TRY(c.xi_part.alloc(sizeof(double2) * (size_t)XI_SLICES * c.kpad));
     HX_HIP(hipMemsetAsync(c.s.p, 0, sizeof(double) * c.kpad, st));
-    hipLaunchKernelGGL(k_weight_xi_dd, dim3((c.n + 63) / 64), dim3(64), 0, st, c.l3max, c.n, c.gl.x.as<double>(), c.gl.xlo.as<double>(),
-                       c.gl.w.as<double>(), d_cl, c.s.as<double>());
+    ProfScope ps("weight_xi");
+    hipLaunchKernelGGL(k_xi_partial, dim3((c.kpad + 63) / 64, XI_SLICES), dim3(256), 0, st, c.l3max, c.kpad, d_cl, c.T[0].as<double>(), c.xi_part.as<double2>());
+    hipLaunchKernelGGL(k_xi_finish, dim3((c.n + 255) / 256), dim3(256), 0, st, c.n, c.kpad, c.gl.w.as<double>(), c.xi_part.as<double2>(), c.s.as<double>());
     HX_HIP(hipGetLastError());
     return HX_OK;
 }

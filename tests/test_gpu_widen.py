@@ -277,7 +277,7 @@ def test_read_vmap_transform_equals_mapper_transform_with_a_weight_file(tmp_path
     # window.  (What healpy does for use_pixel_weights=True with iter > 0 stays parity-unpinned: healpy is absent from this image.)
     from oracle import hxoracle as ho
 
-    full = ho.expand_full_weights(nside, hxw.read_compressed_weights(tmp_path / hxw.weights_filename(nside), nside))
+    full = ho.expand_full_weights(nside, hxw.read_compressed_weights(tmp_path / hxw.weights_filename(nside)))
     ref = ho.map2alm(m[None], nside, lmax, spin=0, pix_weights=full, niter=niter)[0]
     fl = 1.0 / pw[0]
     for mm in range(lmax + 1):
