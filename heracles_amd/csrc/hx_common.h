@@ -65,6 +65,7 @@ struct ProfScope {
 
 // ---- device buffers ----------------------------------------------------------------
 bool is_device_ptr(const void *p);
+bool is_pinned_host(const void *p);  // page-locked host memory the runtime knows (hipHostMalloc / hipHostRegister)
 
 // Owning device allocation.
 struct DevBuf {

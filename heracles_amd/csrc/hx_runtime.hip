@@ -285,6 +285,8 @@ void parallel_memcpy(void *dst, const void *src, size_t n, int nthreads)
     pool->copy(dst, src, n);
 }
 
+}  // namespace
+
 bool is_pinned_host(const void *p)
 {
     hipPointerAttribute_t attr;
@@ -294,8 +296,6 @@ bool is_pinned_host(const void *p)
     }
     return attr.type == hipMemoryTypeHost;
 }
-
-}  // namespace
 
 void stager_reset_events() { stager().reset_events(); }
 
