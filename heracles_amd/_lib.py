@@ -31,7 +31,7 @@ SYMBOLS = (
     "hx_mixmat_eb", "hx_mixmat_batch", "hx_mixctx_create", "hx_mixctx_apply", "hx_mixctx_destroy", "hx_mixctx_set_bins", "hx_mixctx_apply_binned", "hx_cl2corr", "hx_corr2cl", "hx_ang2pix_ring", "hx_map_values", "hx_ud_grade", "hx_reorder", "hx_matvec", "hx_pinv", "hx_alm_resample", "hx_region_maps", "hx_alm_subtract", "hx_fits_unpack_f64", "hx_fits_pack_f64",
     "hx_pointsht_create", "hx_pointsht_destroy", "hx_pointsht_info", "hx_pointsht_adjoint",
     "hx_pixel_weights_size", "hx_pixel_weights_expand",
-    "hx_ring_modes_size", "hx_ring_modes", "hx_legendre_from_modes", "hx_host_alloc", "hx_host_free", "hx_mixmat_gemm_clock", "hx_mixmat_release", "hx_release_caches",
+    "hx_ring_modes_size", "hx_ring_modes", "hx_legendre_from_modes", "hx_allgather_alms", "hx_host_alloc", "hx_host_free", "hx_mixmat_gemm_clock", "hx_mixmat_release", "hx_release_caches",
 )
 
 
@@ -129,6 +129,7 @@ def load():
         L.hx_ring_modes_size.restype = C.c_int64
         L.hx_ring_modes.argtypes = [vp, i, dp, dp, dp, i, vp, vp, i, vp]
         L.hx_legendre_from_modes.argtypes = [vp, i, i, vp, i, i, i, dp, dp]
+        L.hx_allgather_alms.argtypes = [vp, i, vp, dp]
         L.hx_pixel_weights_size.argtypes = [i]
         L.hx_pixel_weights_size.restype = C.c_int64
         L.hx_pixel_weights_expand.argtypes = [i, C.c_int64, dp, dp]

@@ -137,3 +137,75 @@ extern "C" int hx_legendre_from_modes(hx_plan *pl, int spin, int ncomp, const do
     if (hipStreamSynchronize(rt().stream) != hipSuccess && rc == HX_OK) rc = fail(HX_ERR_HIP, "hx_legendre_from_modes: stream error");  // d_tab dies here
     return rc;
 }
+
+// ---- all-gather of alm shards over RCCL for hosts without torch.distributed --------------------------------------
+// The Python layer's collectives live in torch.distributed (heracles_amd/distributed.py).  A host in another language that shards the
+// maps of a job over the GPUs of a node (one process per GPU) gathers the alms with this entry point: in place on the buffer
+// hx_map2alm wrote, shards of unequal length (a rank's components: spin-2 maps count double), one ncclBroadcast per shard inside a
+// group -- over xGMI every shard then travels on all links of its owner at once (a ring all-gather of padded shards is bound by one
+// link).  The library does NO bootstrap: `comm` is an ncclComm_t the host created (ncclCommInitRank with an id it exchanged its own
+// way).  RCCL is bound at the first call (dlopen of librccl.so.1: the copy already in the process if there is one), so the library
+// itself does not depend on it.
+#include <dlfcn.h>
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*group_start)() = nullptr;
+    int (*group_end)() = nullptr;
+    int (*broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*error_string)(int) = nullptr;
+    bool tried = false;
+};
+Rccl &rccl()
+{
+    static Rccl r;
+    if (!r.tried) {
+        r.tried = true;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (r.lib) {
+            r.group_start = reinterpret_cast<int (*)()>(dlsym(r.lib, "ncclGroupStart"));
+            r.group_end = reinterpret_cast<int (*)()>(dlsym(r.lib, "ncclGroupEnd"));
+            r.broadcast = reinterpret_cast<int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)>(dlsym(r.lib, "ncclBroadcast"));
+            r.error_string = reinterpret_cast<const char *(*)(int)>(dlsym(r.lib, "ncclGetErrorString"));
+        }
+    }
+    return r;
+}
+}  // namespace
+
+// counts [nranks]: complex elements of every rank's shard; buf: device, interleaved complex, sum(counts) elements, rank q's shard at
+// offset sum_{p < q} counts[p] (this rank's own shard already in place).  Stream-ordered on the library's stream; complete on return
+// unless hx_set_async(1).
+extern "C" int hx_allgather_alms(void *comm, int nranks, const int64_t *counts, double *buf)
+{
+    using namespace hx;
+    HX_TRY(ensure_ready());
+    if (!comm || nranks < 1 || !counts || !buf) return fail(HX_ERR_ARG, "hx_allgather_alms: bad argument");
+    if (!is_device_ptr(buf)) return fail(HX_ERR_ARG, "hx_allgather_alms: buf must be device memory (the buffer hx_map2alm wrote)");
+    for (int q = 0; q < nranks; ++q)
+        if (counts[q] < 0) return fail(HX_ERR_ARG, "hx_allgather_alms: counts[%d] < 0", q);
+    Rccl &r = rccl();
+    if (!r.lib || !r.group_start || !r.group_end || !r.broadcast)
+        return fail(HX_ERR_UNSUPPORTED, "hx_allgather_alms: librccl.so.1 could not be loaded (%s)", r.lib ? "symbols missing" : dlerror());
+    auto check = [&](int rc, const char *what) {
+        if (rc == 0) return HX_OK;
+        return fail(HX_ERR_HIP, "hx_allgather_alms: %s failed: %s", what, r.error_string ? r.error_string(rc) : "RCCL error");
+    };
+    HX_TRY(check(r.group_start(), "ncclGroupStart"));
+    int64_t off = 0;
+    int rc = HX_OK;
+    for (int q = 0; q < nranks && rc == HX_OK; ++q) {
+        if (counts[q] > 0) {
+            double *p = buf + 2 * off;
+            rc = check(r.broadcast(p, p, (size_t)(2 * counts[q]), /* ncclDouble */ 8, q, comm, rt().stream), "ncclBroadcast");
+        }
+        off += counts[q];
+    }
+    const int rc_end = check(r.group_end(), "ncclGroupEnd");
+    if (rc != HX_OK) return rc;
+    HX_TRY(rc_end);
+    return finish_call();
+}

@@ -147,6 +147,15 @@ int hx_ring_modes(hx_plan *plan, int ncomp, const double *maps, const double *pi
 int hx_legendre_from_modes(hx_plan *plan, int spin, int ncomp, const double *const *comp_modes, int m_first, int m_count, int m_step,
                            double *alms, const double *fl);
 
+/* All-gather of alm shards over RCCL for hosts WITHOUT torch.distributed ("one ncclAllGather of the alm shards
+ * so every rank holds all alms"; the loops being sharded are heracles/mapping.py:151-172 and heracles/twopoint.py:198-215).  In place on
+ * the buffer hx_map2alm wrote: buf (device, interleaved complex) holds sum(counts) elements, rank q's shard of counts[q] complex
+ * elements at offset sum_{p<q} counts[p], this rank's own shard already there; shards may differ in length (one ncclBroadcast per shard
+ * in a group: over xGMI each shard travels on all links of its owner at once).  comm: an ncclComm_t the HOST created (ncclCommInitRank;
+ * the library does no bootstrap); RCCL is bound at the first call (librccl.so.1), HX_ERR_UNSUPPORTED if it cannot be loaded.  The Python
+ * layer does not use this: its collectives are torch.distributed's (heracles_amd/distributed.py). */
+int hx_allgather_alms(void *comm, int nranks, const int64_t *counts, double *buf);
+
 /* ---- two-point reduction -------------------------------------------------------- */
 /* Replaces heracles.twopoint.alm2cl (heracles/twopoint.py:63-101) for a whole list of
  * component pairs in one launch.  alms[i] points to component i with lmax_i[i];

@@ -250,3 +250,40 @@ def test_bench_line_survives_a_failure_of_the_growing_job(tmp_path):
     assert out["value_weak"] is None and "HX_BENCH_FAIL_WEAK" in out["weak_scaling"]["error"]
     assert out["verify_multi"]["ok"] and out["verified"] is True
     assert out["roofline"]["launches"] > 0  # the per-GPU kernel figures come from the local transforms
+
+
+@pytest.mark.gpu
+def test_allgather_alms_runs_over_rccl_with_a_one_rank_communicator():
+    """``hx_allgather_alms`` (the all-gather of alm shards as a C entry point, for hosts without torch.distributed): the
+    only thing one GPU can show is that the entry point binds RCCL, takes a communicator the HOST created and runs its grouped
+    broadcasts on the library's stream -- a one-rank communicator, whose gather leaves the buffer as it is.  More ranks need more GPUs
+    (RCCL refuses two ranks on one device): unmeasured on hardware, like every N > 1 path here."""
+    import ctypes as C
+
+    import torch
+
+    import heracles_amd as hx
+    from heracles_amd import _lib
+
+    hx.init(0)
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        rccl = C.CDLL("librccl.so")
+    comm = C.c_void_p()
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, (C.c_int * 1)(0)) == 0
+    try:
+        buf = torch.randn(12345, dtype=torch.complex128, device="cuda")
+        ref = buf.clone()
+        L = _lib.load()
+        _lib.check(L.hx_allgather_alms(comm, 1, (C.c_int64 * 1)(buf.numel()), _lib.ptr(buf)))
+        torch.cuda.synchronize()
+        assert torch.equal(buf, ref)
+        # an empty shard is skipped; a host buffer and a null communicator are refused
+        _lib.check(L.hx_allgather_alms(comm, 1, (C.c_int64 * 1)(0), _lib.ptr(buf)))
+        with pytest.raises(hx.HxError):
+            _lib.check(L.hx_allgather_alms(comm, 1, (C.c_int64 * 1)(4), _lib.ptr(np.zeros(4, dtype=np.complex128))))
+        with pytest.raises(hx.HxError):
+            _lib.check(L.hx_allgather_alms(None, 1, (C.c_int64 * 1)(4), _lib.ptr(buf)))
+    finally:
+        rccl.ncclCommDestroy(comm)
