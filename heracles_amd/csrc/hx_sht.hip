@@ -310,7 +310,7 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_subdft(PlanDev P, const Rin
                     const double2 t = make_double2(fma(sg, e1.x, e0.x), fma(sg, e1.y, e0.y));
                     // (j r + 2 j^2 [Bluestein]) mod 4n = load_phase_num(j, r, n, blu); j < 2^14: 32 bits hold it
                     const unsigned jc = j < n ? j : 0;
-                    const unsigned qn = mod_by_inv(jc * (unsigned)r + (blu ? 2u * jc * jc : 0u), 4u * (unsigned)n, inv4n);
+                    const unsigned qn = blu ? mod_by_inv(jc * (unsigned)r + 2u * jc * jc, 4u * (unsigned)n, inv4n) : jc * (unsigned)r;  // (j r < 4n as it is)
                     buf[j < n ? lds_slot(j) : MP - 1] = cmul(t, phase(qn));
                 }
                 u0 += RING_FB;
@@ -428,7 +428,6 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const Ri
     // components with pixel weights, 15.1 vs 14.3 without, same device.)
     const int nitems = ((nrings + 7) >> 3) * nb * 16;
     const TwFactored twf = load_tw_factored(tw_hi, tw_lo, P.tw, P.twN);
-    const double inv4n = 0.25 / (double)n;
     int tid = threadIdx.x;
     // the phase tables depend on n = M only: built once per group
     for (int a = tid; a <= (4 * n) >> 6; a += nt) ph_hi[a] = expipi(-(double)(a << 6) / (2.0 * n));
@@ -527,11 +526,10 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const Ri
             if (j >= n) continue;
             const double2 e0 = rpair ? csub(z[u][0], z[u][2]) : cadd(z[u][0], z[u][2]);
             const double2 e1 = rpair ? mul_mi(csub(z[u][1], z[u][3])) : cadd(z[u][1], z[u][3]);
-            // load phases exp(-i pi j r / 2n) of r = rpair and r + 2
-            const unsigned q0 = mod_by_inv((unsigned)j * (unsigned)rpair, 4u * (unsigned)n, inv4n);
-            const unsigned q1 = mod_by_inv((unsigned)j * (unsigned)(rpair + 2), 4u * (unsigned)n, inv4n);
-            buf[lds_slot(j)] = cmul(cadd(e0, e1), phase(q0));
-            buf[MP + lds_slot(j)] = cmul(csub(e0, e1), phase(q1));
+            // load phases exp(-i pi j r / 2n) of r = rpair and r + 2: j < n and r <= 3, so j r < 4n needs no reduction, and r = 0 no phase at all
+            const double2 t0 = cadd(e0, e1);
+            buf[lds_slot(j)] = rpair ? cmul(t0, phase((unsigned)j)) : t0;
+            buf[MP + lds_slot(j)] = cmul(csub(e0, e1), phase((unsigned)j * (unsigned)(rpair + 2)));
         }
         __syncthreads();
         // the next item's record: taken HERE, in front of this item's stores -- waited for behind them (their number is not known to
@@ -574,6 +572,9 @@ __global__ __launch_bounds__(RING_NTMAX) void k_ring_pairfft(PlanDev P, const Ri
     }
 }
 
+// (Round 6, measured and not kept: the same work item with its two transforms run one after the other through ONE buffer by half as many threads, so
+// that two independent groups fit a CU -- analysis 51.1 -> 50.6 ms per step, synthesis of ten fields 51.4 -> 56.1 ms: the item is bound by the issue of its
+// vector instructions and by dependent LDS round trips, not by latency a second group could cover.  profiles/r06_pairseq_experiment.txt.)
 // =====================================================================================
 // 1b. rings whose Bluestein convolution does not fit LDS (nside 8192: cap rings with 4096 < n < 8192 need M = 16384 points
 //     = 256 KiB): the length-M cyclic convolution as an EVEN and an ODD half of C = M / 2 points each
