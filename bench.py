@@ -188,7 +188,9 @@ def cpu_baseline_vectorised(nside, lmax, nmaps0, nmaps2, t_map, qu_map, pix_weig
         "legendre_gflops_algorithmic": gf, "legendre_gflops_is": "SURVEY 8d's F0 (spin 0) + 3 F0 (spin 2) / the two Legendre-stage times; ring pruning and "
                                                                 "north/south symmetry remove about half of it, as on the GPU",
         "host_fp64_peak_gflops": peak, "host_clock_ghz": ghz, "host_clock_from": how,
-        "frac_of_host_fp64_peak": gf / peak if peak else None,
+        "algorithmic_frac_of_host_fp64_peak": gf / peak if peak else None,
+        "algorithmic_frac_is": "the ALGORITHMIC rate / (threads x clock x 32 flop per cycle): not a pipe utilisation -- what the cores execute is about half "
+                               "of F0 (as on the GPU, whose algorithmic rate exceeds its peak for the same reason)",
         "note": "this repository's own AVX-512 / OpenMP restatement of the algorithm (oracle/hx_cpu_fast.c), NOT ducc0 / healpy: those engines are "
                 "absent from this image (see engines), so the north star's '>= 10x ducc' stays unmeasured; the GPU/CPU ratio says nothing about "
                 "kernel quality -- roofline.frac does",

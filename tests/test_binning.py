@@ -232,3 +232,38 @@ def test_gpu_release_caches_between_stages():
     np.testing.assert_array_equal(hx.alm2cl(alm[0], alm[1]), c1)
     hx.mixmat_release()
     hx.release_caches()  # (twice in a row: nothing left to free)
+
+
+@pytest.mark.gpu
+def test_gpu_binned_rows_at_bench_size_against_the_3j_oracle(oracle):
+    """The binned rows of the L = 6144 matrices (the bench's size, the configuration file's log bins) against the 3j ORACLE, not against
+    this library's own full matrix: for three bins -- the first, one in the middle, and the last and widest (1 240 rows up to l = 6144) -- the
+    oracle's block of those rows at a handful of columns (on the band, beside it, far from it) is binned on the host and compared with the
+    row the GPU built from its binned Wigner-d tables: spins (0,0), (0,2) and the three spin-2 x spin-2 matrices."""
+    L = 6144
+    l = np.arange(L + 1)
+    wl = 4 * np.pi * 0.35 * np.exp(-l * (l + 1) / 3000.0) + 1e-3 / (1.0 + l) ** 2
+    edges = np.unique(np.geomspace(2, L + 1, 33).astype(int))
+    plan = binning.BinPlan(l, edges, "2l+1")
+    picks = [0, plan.nbins // 2, plan.nbins - 1]
+    with hx.MixmatContext(L, L, L) as ctx:
+        ctx.set_bins(plan)
+        got = {spin: ctx.binned(wl, spin) for spin in ((0, 0), (0, 2), (2, 2))}
+    for b in picks:
+        rows = np.flatnonzero(plan.which == b)
+        lo, hi = int(rows[0]), int(rows[-1])
+        mid = (lo + hi) // 2
+        cols = sorted({max(mid - 1, 0), mid, min(hi + 40, L), min(2 * mid + 7, L), L // 3, L})
+        w = plan.w[lo : hi + 1]
+        for c in cols:
+            ref00 = oracle.mixmat_block(wl, (lo, hi), (c, c), spin=(0, 0))[:, 0]
+            ref02 = oracle.mixmat_block(wl, (lo, hi), (c, c), spin=(0, 2))[:, 0]
+            refeb = oracle.mixmat_eb_block(wl, (lo, hi), (c, c))[:, :, 0]
+            for spin, ref in (((0, 0), ref00), ((0, 2), ref02)):
+                want = (w * ref).sum() / plan.norm[b]
+                scale = np.abs(got[spin]).max()
+                assert abs(got[spin][b, c] - want) <= 1e-12 * scale, (spin, b, c, got[spin][b, c], want)
+            scale = np.abs(got[2, 2]).max()
+            for k in range(3):
+                want = (w * refeb[k]).sum() / plan.norm[b]
+                assert abs(got[2, 2][k, b, c] - want) <= 1e-12 * scale, ("eb", k, b, c, got[2, 2][k, b, c], want)
