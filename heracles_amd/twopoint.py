@@ -507,10 +507,16 @@ def mixing_matrices(fields, cls, *, l1max=None, l2max=None, l3max=None, bins=Non
             return plan.apply(mm, np.ndim(mm) - 2), plan
         if (a, b, c) not in contexts:
             contexts[a, b, c] = MixmatContext(a, b, c)
-            if bins is not None:
+            if bins is not None and plan_for(a + 1).nbins > 0:
                 contexts[a, b, c].set_bins(plan_for(a + 1))
         ctx = contexts[a, b, c]
-        return (ctx(cl, spin), None) if bins is None else (ctx.binned(cl, spin), ctx.plan)
+        if bins is None:
+            return ctx(cl, spin), None
+        if plan_for(a + 1).nbins == 0:  # (a single edge: no bin at all -- empty rows, as the reference returns them)
+            plan = plan_for(a + 1)
+            shape = (3, 0, b + 1) if MixmatContext._kind(spin) == 4 else (0, b + 1)
+            return np.zeros(shape), plan
+        return ctx.binned(cl, spin), ctx.plan
 
     try:
         for n, ck in enumerate(cls, start=1):
