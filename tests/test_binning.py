@@ -267,3 +267,50 @@ def test_gpu_binned_rows_at_bench_size_against_the_3j_oracle(oracle):
             for k in range(3):
                 want = (w * refeb[k]).sum() / plan.norm[b]
                 assert abs(got[2, 2][k, b, c] - want) <= 1e-12 * scale, ("eb", k, b, c, got[2, 2][k, b, c], want)
+
+
+def _config_bins(lmin, lmax, n=32):
+    """the edges ``heracles.cli.bins_from_config`` makes of ``bins = 32 log 2l+1`` (heracles/cli.py:356-362): FLOAT edges, exact ends"""
+    arr = 10 ** np.linspace(np.log10(lmin), np.log10(lmax + 1), n + 1)
+    arr[0], arr[-1] = lmin, lmax + 1
+    return arr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,fields,l1max,l2max", [
+    ("clustering", {"D": ("V", 0)}, 2000, 4000),
+    ("shear", {"G": ("W", 2)}, 3000, 5000),
+    ("ggl", {"D": ("V", 0), "G": ("W", 2)}, 1000, 2000),
+])
+def test_gpu_example_configuration_sections(name, fields, l1max, l2max):
+    """The three [spectra:*] sections of the reference's example configuration (examples/heracles.cfg:4-25: lmin 10, ``bins = 32 log 2l+1``,
+    rectangular lmax / l2max, no l3max: the mask spectra set it -- here 6000, the visibility's lmax) as ``heracles/cli.py:696-716`` runs them:
+    float bin edges, rows below lmin left out.  Binned rows built on the GPU == the host rule on the GPU's own full matrices; angular
+    arrays as the reference defines them."""
+    l3max = 6000
+    l = np.arange(l3max + 1)
+    flds = {k: types.SimpleNamespace(mask=m, spin=s) for k, (m, s) in fields.items()}
+    masks = sorted({m for m, _ in fields.values()})
+    mcls = {}
+    for i, a in enumerate(masks):
+        for b in masks[i:]:
+            mcls[a, b, 0, 1] = 4 * np.pi * 0.3 * np.exp(-l * (l + 1) / (2.0e4 + 3e3 * len(mcls))) + 1e-4 / (1 + l) ** 2
+    edges = _config_bins(10, l1max)
+    assert edges.size == 33 and edges[1] != round(edges[1])
+    mms = hx.mixing_matrices(flds, mcls, l1max=l1max, l2max=l2max, l3max=None, bins=edges, weights="2l+1")
+    plan = binning.BinPlan(np.arange(l1max + 1), edges, "2l+1")
+    assert plan.which[:10].max() == -1 and plan.which[10] == 0 and plan.which[-1] == 31
+    assert len(mms) >= 1
+    with hx.MixmatContext(l1max, l2max, l3max) as ctx:
+        for key, res in mms.items():
+            spin = (flds[key[0]].spin, flds[key[1]].spin)
+            mkey = next(k for k in mcls if {k[0], k[1]} == {flds[key[0]].mask, flds[key[1]].mask} or (k[0] == flds[key[0]].mask and k[1] == flds[key[1]].mask))
+            full = ctx(mcls[mkey], spin)
+            want = plan.apply(full, full.ndim - 2)
+            got = np.asarray(res.array)
+            assert got.shape == ((3,) if all(spin) else ()) + (32, l2max + 1)
+            np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-13 * np.abs(want).max(), err_msg=f"{name} {key}")
+            np.testing.assert_array_equal(res.lower, edges[:-1])
+            np.testing.assert_array_equal(res.upper, edges[1:])
+            np.testing.assert_allclose(res.weight, plan.norm, rtol=1e-14)
+            assert res.axis == (got.ndim - 2,) and tuple(res.spin) == spin
