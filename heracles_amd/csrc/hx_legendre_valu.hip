@@ -456,6 +456,7 @@ struct SynValuParams {
 // (four spin-0 maps: 294 registers if the compiler may -- copies in AGPRs around the checks and hand-overs; held to 256, i.e. two
 // waves per SIMD like the other shapes, the copies become a few scratch accesses outside the steady loop)
 template <int SPIN, int NB>
+// (<0, 4>: two waves per SIMD at the price of 165 spilled registers -- 53.0 ms for four maps against 60.4 at one wave without a spill, round 6)
 __global__ __launch_bounds__(64, (SPIN == 0 && NB == 4) ? 2 : VALU_WAVES) void k_legendre_synth_valu(SynValuParams A, const double2 *__restrict__ coefn, const double *__restrict__ alphan)
 {
     using C = SynValuCfg<SPIN, NB>;
