@@ -58,6 +58,14 @@ def test_no_cpu_fallback_without_gpu():
         heracles_amd.pinned_empty((4, 4))
     with pytest.raises(heracles_amd.HxError):
         heracles_amd.mixmat_eb(np.ones(4), out=np.empty((3, 4, 4)))
+    # round 6's entry points: binned mixing matrices (the context cannot even be created), the driver with bins
+    import types
+
+    with pytest.raises(heracles_amd.HxError):
+        heracles_amd.MixmatContext(8, 8, 8)
+    with pytest.raises(heracles_amd.HxError):
+        heracles_amd.mixing_matrices({"P": types.SimpleNamespace(mask="V", spin=0)}, {("V", "V", 0, 0): np.ones(9)}, bins=np.array([0, 4, 9]))
+    heracles_amd.release_caches()  # (nothing is held: not an error without a device)
     with pytest.raises(heracles_amd.HxError):
         heracles_amd.MixmatContext(3, 3, 3)
     x = np.empty(5)
