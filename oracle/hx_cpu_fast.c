@@ -426,44 +426,56 @@ static void legendre0(const geom *g, int lmax, const double *planes, cplx *alm)
             for (int lb = m; lb <= lmax; lb += LB0) {
                 const int le = lb + LB0 - 1 < lmax ? lb + LB0 - 1 : lmax;
                 for (int q = 0; q <= le - lb; ++q) accr[q] = acci[q] = _mm512_setzero_pd();
-                for (int rv = rv0; rv < nrv; ++rv) {
-                    const v8 x = _mm512_loadu_pd(g->z + rv * 8);
-                    const double *pp = planes + (size_t)m * g->nrp_pad + rv * 8;
-                    const v8 fer = _mm512_loadu_pd(pp), fei = _mm512_loadu_pd(pp + plane), for_ = _mm512_loadu_pd(pp + 2 * plane),
-                             foi = _mm512_loadu_pd(pp + 3 * plane);
-                    v8 vp = svp[rv], vc = svc[rv], fac = sfac[rv];
-                    int wet = swet[rv];
+                /* TWO ring vectors (16 ring pairs) per pass over the block: they share the coefficient broadcasts and -- what matters -- one
+                 * load / store of the sums per step (spin 0 has 2 multiply-adds per step and vector to set against them; one vector per pass:
+                 * 0.60 TFLOP/s algorithmic on 16 cores, two: see profiles/r06_cpu_baseline_threads.txt).  A vector that does not count yet has
+                 * fac = 0 in every lane, so it may ride along. */
+                for (int rv = rv0; rv < nrv; rv += 2) {
+                    const int rb = rv + 1 < nrv ? rv + 1 : rv; /* (an odd tail: the second vector is all zeros) */
+                    const int two = rb != rv;
+                    const v8 xa = _mm512_loadu_pd(g->z + rv * 8), xb = _mm512_loadu_pd(g->z + rb * 8);
+                    const double *pa = planes + (size_t)m * g->nrp_pad + rv * 8, *pb = planes + (size_t)m * g->nrp_pad + rb * 8;
+                    const v8 zero = _mm512_setzero_pd();
+                    const v8 aer = _mm512_loadu_pd(pa), aei = _mm512_loadu_pd(pa + plane), aor = _mm512_loadu_pd(pa + 2 * plane), aoi = _mm512_loadu_pd(pa + 3 * plane);
+                    const v8 ber = two ? _mm512_loadu_pd(pb) : zero, bei = two ? _mm512_loadu_pd(pb + plane) : zero;
+                    const v8 bor = two ? _mm512_loadu_pd(pb + 2 * plane) : zero, boi = two ? _mm512_loadu_pd(pb + 3 * plane) : zero;
+                    v8 vpa = svp[rv], vca = svc[rv], fa = sfac[rv], vpb = two ? svp[rb] : zero, vcb = two ? svc[rb] : zero, fb = two ? sfac[rb] : zero;
+                    int weta = swet[rv], wetb = two ? swet[rb] : 0;
                     int l = lb;
                     if (lb == m) { /* the seed itself is lambda_mm (even parity) */
-                        if (wet) {
-                            const v8 lam = _mm512_mul_pd(vc, fac);
-                            accr[0] = _mm512_fmadd_pd(lam, fer, accr[0]);
-                            acci[0] = _mm512_fmadd_pd(lam, fei, acci[0]);
+                        if (weta | wetb) {
+                            const v8 la = _mm512_mul_pd(vca, fa), lbv = _mm512_mul_pd(vcb, fb);
+                            accr[0] = _mm512_fmadd_pd(lbv, ber, _mm512_fmadd_pd(la, aer, accr[0]));
+                            acci[0] = _mm512_fmadd_pd(lbv, bei, _mm512_fmadd_pd(la, aei, acci[0]));
                         }
                         l = m + 1;
                     }
                     while (l <= le) {
                         const int stop = l + 3 < le ? l + 3 : le; /* four steps, then look at the magnitudes */
+                        const int wet = weta | wetb;
                         for (; l <= stop; ++l) {
-                            const v8 vn = _mm512_mul_pd(_mm512_set1_pd(ca[l]), _mm512_fnmadd_pd(vp, _mm512_set1_pd(ia[l]), _mm512_mul_pd(x, vc)));
-                            vp = vc;
-                            vc = vn;
+                            const v8 c = _mm512_set1_pd(ca[l]), ic = _mm512_set1_pd(ia[l]);
+                            const v8 na = _mm512_mul_pd(c, _mm512_fnmadd_pd(vpa, ic, _mm512_mul_pd(xa, vca)));
+                            const v8 nb = _mm512_mul_pd(c, _mm512_fnmadd_pd(vpb, ic, _mm512_mul_pd(xb, vcb)));
+                            vpa = vca; vca = na; vpb = vcb; vcb = nb;
                             if (wet) {
-                                const v8 lam = _mm512_mul_pd(vc, fac);
+                                const v8 la = _mm512_mul_pd(vca, fa), lbv = _mm512_mul_pd(vcb, fb);
                                 const int q = l - lb;
                                 if ((l - m) & 1) {
-                                    accr[q] = _mm512_fmadd_pd(lam, for_, accr[q]);
-                                    acci[q] = _mm512_fmadd_pd(lam, foi, acci[q]);
+                                    accr[q] = _mm512_fmadd_pd(lbv, bor, _mm512_fmadd_pd(la, aor, accr[q]));
+                                    acci[q] = _mm512_fmadd_pd(lbv, boi, _mm512_fmadd_pd(la, aoi, acci[q]));
                                 } else {
-                                    accr[q] = _mm512_fmadd_pd(lam, fer, accr[q]);
-                                    acci[q] = _mm512_fmadd_pd(lam, fei, acci[q]);
+                                    accr[q] = _mm512_fmadd_pd(lbv, ber, _mm512_fmadd_pd(la, aer, accr[q]));
+                                    acci[q] = _mm512_fmadd_pd(lbv, bei, _mm512_fmadd_pd(la, aei, acci[q]));
                                 }
                             }
                         }
-                        const __mmask8 mk = too_big(vc);
-                        if (mk) wet = rescale(&vc, &vp, sex + rv * 8, &fac, mk);
+                        const __mmask8 ka = too_big(vca), kb = too_big(vcb);
+                        if (ka) weta = rescale(&vca, &vpa, sex + rv * 8, &fa, ka);
+                        if (kb && two) wetb = rescale(&vcb, &vpb, sex + rb * 8, &fb, kb);
                     }
-                    svp[rv] = vp; svc[rv] = vc; sfac[rv] = fac; swet[rv] = wet;
+                    svp[rv] = vpa; svc[rv] = vca; sfac[rv] = fa; swet[rv] = weta;
+                    if (two) { svp[rb] = vpb; svc[rb] = vcb; sfac[rb] = fb; swet[rb] = wetb; }
                 }
                 for (int l = lb; l <= le; ++l) out[l] = hsum(accr[l - lb]) + I * hsum(acci[l - lb]);
             }
