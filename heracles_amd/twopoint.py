@@ -16,7 +16,7 @@ from itertools import combinations_with_replacement, product
 import numpy as np
 
 from . import _lib
-from .binning import BinPlan, binned, plans_for, wrap_binned
+from .binning import BinPlan, binned, wrap_binned
 from .core import DeviceArray, Result, TocDict, toc_match, update_metadata
 
 logger = logging.getLogger(__name__)
