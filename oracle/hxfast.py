@@ -19,7 +19,11 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "hx_cpu_fast.c")):
-            subprocess.check_call(["make", "-C", _HERE, "-s", "libhxcpufast.so"])
+            try:
+                subprocess.check_call(["make", "-C", _HERE, "-s", "libhxcpufast.so"])
+            except (OSError, subprocess.CalledProcessError):
+                if not os.path.exists(_LIB):  # (a prebuilt library whose time stamp did not survive a copy is still the library)
+                    raise
         L = C.CDLL(_LIB)
         L.hxf_map2alm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
