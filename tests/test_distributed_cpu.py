@@ -449,7 +449,7 @@ def _mm_worker(rank, world, port, outdir, bins):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,bins", [(2, False), (2, True), (3, True)])
+@pytest.mark.parametrize("world,bins", [(2, False), (2, True), (3, True), (8, True)])
 def test_mixing_matrix_requests_split_across_ranks(tmp_path, world, bins):
     import torch.multiprocessing as mp
 
