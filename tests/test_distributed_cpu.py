@@ -136,7 +136,7 @@ def _reference(lmax):
     return np.array(rows)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_equals_single(tmp_path, world):
     import torch.multiprocessing as mp
 
@@ -274,7 +274,7 @@ def _ms_worker(rank, world, port, outdir, spins=None):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_m_sharded_equals_single(tmp_path, world):
     """The m-sharded job returns, on every rank, the spectra of the single-process job over all maps (the sum over m is split
     between the ranks: equal to rounding, 1e-12)."""
